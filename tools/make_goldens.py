@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REAL REFERENCE (build container only).
+
+The reference (/root/reference, read-only) is pure Python on PyTorch; timm is not
+installed here, so a small in-memory stub provides the four timm symbols it uses
+(SURVEY.md §8c / Appendix A).  Weights and inputs come from devias_amd/synth.py
+formulae keyed on state_dict names, so only OUTPUTS are committed: per-slot logits,
+slot features, mask predictions, the slot attention map, the five loss terms, the
+matched slot indices, per-parameter gradient norms + 16 sampled gradient elements
+per parameter, and a few intermediate slices for bisecting.
+
+While generating, the CPU oracle (oracle/ref_cpu.py) is checked against the
+reference on the same data; a mismatch aborts.  The fixtures are data only.
+
+Usage (in the build container):  python tools/make_goldens.py [--only NAME]
+This script never runs on the GPU box and nothing under tests/ imports it.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+
+from devias_amd import synth  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+
+
+def install_reference():
+    sys.path.insert(0, REF)
+
+    def _mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def drop_path(x, drop_prob=0., training=False):  # timm 0.4.12 semantics
+        if drop_prob == 0. or not training:
+            return x
+        keep = 1 - drop_prob
+        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        return x.div(keep) * (keep + torch.rand(shape, dtype=x.dtype, device=x.device)).floor_()
+
+    reg = {}
+    _mod("timm"); _mod("timm.models")
+    _mod("timm.models.layers", drop_path=drop_path,
+         to_2tuple=lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v),
+         trunc_normal_=lambda t, mean=0., std=1., a=-2., b=2.: nn.init.trunc_normal_(t, mean, std, a, b))
+    _mod("timm.models.registry", register_model=lambda fn: reg.setdefault(fn.__name__, fn))
+    _mod("timm.utils", accuracy=None, ModelEma=object, get_state_dict=lambda m: m.state_dict())
+    _mod("tensorboardX", SummaryWriter=object)
+    # TrainLoss force-casts the fg masks to fp16 (train_loss.py:136-137) which breaks fp32 backward;
+    # masks are k/256 (exact in fp16) so making .half() the identity is value-preserving (SURVEY §8c caveat 1)
+    torch.Tensor.half = lambda self: self
+    import model.modeling_slot as ms
+    import model.modeling_finetune as mf
+    from agg_block.agg_block import AggregationBlock
+    from utils.loss.train_loss import TrainLoss
+    return reg, ms, mf, AggregationBlock, TrainLoss
+
+
+CONFIGS = {
+    # name: (cfg kwargs, batch)
+    "vitb_t8": (dict(all_frames=8), 2),
+    "vitb_t16": (dict(all_frames=16), 2),
+    "vits_t8": (dict(all_frames=8, embed_dim=384, num_heads=6), 2),
+    "vitb_t8_s4_untied": (dict(all_frames=8, num_latents=4, agg_weights_tie=False, agg_depth=4), 2),
+}
+
+
+def build_reference_student(cfg: ref_cpu.SlotViTConfig, reg, ms, AggregationBlock):
+    if cfg.embed_dim == 768:
+        return reg["slot_vit_base_patch16_224"](
+            num_classes=cfg.num_classes, all_frames=cfg.all_frames, tubelet_size=cfg.tubelet_size,
+            drop_path_rate=0., init_scale=1e-3, num_latents=cfg.num_latents, head_type="linear",
+            slot_matching_method="matching", agg_weights_tie=cfg.agg_weights_tie, agg_depth=cfg.agg_depth,
+            num_scene_classes=cfg.num_scene_classes)
+
+    # D != 768: the reference wrapper hard-wires 768 (modeling_slot.py:199,392; agg_block.py:13,16), so compose the
+    # reference's OWN parametric classes exactly as VisionTransformer.forward (:379-410) wires them (SURVEY §8c caveat 2)
+    D = cfg.embed_dim
+
+    class Composed(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.patch_embed = ms.PatchEmbed(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=3, embed_dim=D,
+                                             num_frames=cfg.all_frames, tubelet_size=cfg.tubelet_size)
+            self.pos_embed = ms.get_sinusoid_encoding_table(self.patch_embed.num_patches, D)
+            nl = partial(nn.LayerNorm, eps=1e-6)
+            self.blocks = nn.ModuleList([ms.Block(dim=D, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
+                                                  norm_layer=nl, init_values=0.) for _ in range(cfg.depth)])
+            self.norm = nl(D)
+            self.agg_block = AggregationBlock(num_latents=cfg.num_latents, weight_tie_layers=cfg.agg_weights_tie,
+                                              depth=cfg.agg_depth, input_channels=D, latent_dim=D)
+            self.mask_predictor = nn.Module()
+            self.mask_predictor.decoder = nn.Sequential(nn.Linear(D, 512), nn.ReLU(), nn.Linear(512, 256), nn.ReLU(),
+                                                        nn.Linear(256, 196), nn.Sigmoid())
+            self.head = nn.Linear(D, cfg.head_width)
+
+        def forward(self, x):
+            x = self.patch_embed(x)
+            x = x + self.pos_embed.expand(x.shape[0], -1, -1).type_as(x)
+            for blk in self.blocks:
+                x = blk(x, return_attn=False)
+            x = self.norm(x)
+            slots, attn = self.agg_block(x)
+            bs, S, _ = slots.size()
+            slots = slots.reshape(-1, D)
+            slots_head = self.head(slots)
+            probs = torch.softmax(slots_head, dim=-1).view(bs, S, -1)
+            a_idx = torch.argmax(probs[:, :, :cfg.num_classes].max(dim=-1).values, dim=1)
+            s_idx = torch.argmax(probs[:, :, cfg.num_classes:].max(dim=-1).values, dim=1)
+            ar = torch.arange(bs)
+            sv, hv = slots.view(bs, S, -1), slots_head.view(bs, S, -1)
+            mask = self.mask_predictor.decoder(slots)
+            mask = mask.squeeze().reshape(slots.shape[0], 196)
+            return (sv[ar, a_idx], sv[ar, s_idx]), (hv[ar, a_idx], hv[ar, s_idx], attn), (slots_head, slots, mask)
+
+    return Composed()
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def sample_idx(name: str, numel: int, k: int = 16) -> np.ndarray:
+    return (synth.hash_u64(7, "gradsample." + name, k) % np.uint64(numel)).astype(np.int64)
+
+
+def tap_summary(t: torch.Tensor) -> np.ndarray:
+    """first 4 tokens x 32 channels of sample 0, then [sum, abs-sum] over everything."""
+    head = t[0, :4, :32].reshape(-1).double().numpy()
+    return np.concatenate([head, [float(t.double().sum()), float(t.double().abs().sum())]])
+
+
+def generate(name: str, ref):
+    reg, ms, mf, AggregationBlock, TrainLoss = ref
+    kw, B = CONFIGS[name]
+    cfg = ref_cpu.SlotViTConfig(**kw)
+    torch.manual_seed(0)
+    model = build_reference_student(cfg, reg, ms, AggregationBlock)
+    model.train()
+    synth.fill_module_(model, seed=0)
+    names = [n for n, _ in model.named_parameters()]
+    shapes = ref_cpu.param_shapes(cfg)
+    assert names == list(shapes.keys()), (set(names) ^ set(shapes.keys()))
+    for n, p in model.named_parameters():
+        assert tuple(p.shape) == shapes[n], n
+
+    N = cfg.num_patches
+    x = synth.video(B, cfg.all_frames, cfg.img_size, seed=1000)
+    y = synth.targets(B, cfg.num_classes, seed=1000)
+    tl = synth.teacher_logits(B, cfg.num_scene_classes, seed=1000)
+    fg = synth.fg_masks(B, N, cfg.grid * cfg.grid, seed=1000)
+
+    taps = {}
+    blocks = model.blocks
+    blocks[0].register_forward_hook(lambda m, i, o: taps.__setitem__("block0", o.detach()))
+    blocks[-1].register_forward_hook(lambda m, i, o: taps.__setitem__(f"block{cfg.depth - 1}", o.detach()))
+    model.norm.register_forward_hook(lambda m, i, o: taps.__setitem__("feats", o.detach()))
+
+    crit = TrainLoss(criterion=None, scene_criterion="KL", num_action_classes=cfg.num_classes,
+                     slot_matching_method="matching", mask_prediction_loss_weight=1.0,
+                     mask_distill_loss_weight=1.0, scene_loss_weight=4000)
+    out = model(x)
+    total, logits, ld = crit(model, out, (None, tl), y, fg_mask=fg)
+    model.zero_grad()
+    total.backward()
+    (af, sf), (al, sl, attn), (slots_head, slots, maskp) = out
+    grads = {n: p.grad.detach() for n, p in model.named_parameters()}
+    assert all(g is not None for g in grads.values())
+
+    # ---- oracle vs reference on identical data -------------------------------------------------
+    P = synth.fill_params(shapes, seed=0)
+    otaps = {}
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    oout = ref_cpu.student_forward(Pg, cfg, x, otaps)
+    ototal, ologits, old, oidx = ref_cpu.train_loss(cfg, oout, tl, y, fg)
+    ototal.backward()
+    checks = {
+        "slots_head": rel_err(oout[2][0], slots_head), "slots": rel_err(oout[2][1], slots),
+        "mask_predictions": rel_err(oout[2][2], maskp), "attn": rel_err(oout[1][2], attn),
+        "action_logit": rel_err(oout[1][0], al), "scene_logit": rel_err(oout[1][1], sl),
+        "total": rel_err(ototal, total), "logits": rel_err(ologits, logits),
+    }
+    for k in ld:
+        checks["loss." + k] = abs(old[k] - ld[k]) / max(abs(ld[k]), 1e-30)
+    # a few gradients are mathematically zero (e.g. the slot-query LayerNorm bias: a shift common to every slot
+    # cancels in the slot-axis softmax) and hold only round-off, so errors are scaled by the global gradient maximum too
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    gerr = {n: float((Pg[n].grad.double() - grads[n].double()).abs().max()
+                     / max(float(grads[n].abs().max()), 1e-6 * gmax)) for n in names}
+    worst_n = max(gerr, key=gerr.get)
+    worst_g = gerr[worst_n]
+    print(f"[{name}] worst gradient: {worst_n} err={worst_g:.2e} |g|max={float(grads[worst_n].abs().max()):.3e} global={gmax:.3e}")
+    checks["grads(worst)"] = worst_g
+    print(f"[{name}] oracle vs reference: " + ", ".join(f"{k}={v:.2e}" for k, v in checks.items()))
+    bad = {k: v for k, v in checks.items() if v > (1e-3 if k.startswith("grads") else 5e-5)}
+    assert not bad, f"oracle disagrees with the reference: {bad}"
+
+    # matched indices the reference used (recover from the returned logits rows)
+    Z = slots_head.view(B, cfg.num_latents, -1)
+    i_star = [int(torch.argmin((Z[b] - logits[b]).abs().sum(-1))) for b in range(B)]
+    assert i_star == oidx[0].tolist()
+
+    fx = {
+        "config": np.array(repr(kw)), "batch": np.array(B),
+        "slots_head": slots_head.detach().numpy(), "slots": slots.detach().numpy(),
+        "mask_predictions": maskp.detach().numpy(), "attn": attn.detach().numpy(),
+        "action_feat": af.detach().numpy(), "scene_feat": sf.detach().numpy(),
+        "action_logit": al.detach().numpy(), "scene_logit": sl.detach().numpy(),
+        "matched_logits": logits.detach().numpy(),
+        "match_action_slot": oidx[0].numpy(), "match_scene_slot": oidx[1].numpy(),
+        "total_loss": np.array(float(total.detach().double())),
+        "loss_names": np.array(list(ld.keys())), "loss_values": np.array([float(ld[k]) for k in ld], dtype=np.float64),
+        "param_names": np.array(names),
+        "grad_norms": np.array([float(grads[n].double().norm()) for n in names], dtype=np.float64),
+        "grad_samples": np.stack([grads[n].reshape(-1)[torch.from_numpy(sample_idx(n, grads[n].numel()))].numpy()
+                                  for n in names]),
+        "tap_names": np.array(sorted(taps.keys())),
+        "taps": np.stack([tap_summary(taps[k]) for k in sorted(taps.keys())]),
+    }
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB) total_loss={float(total):.9f} {ld}")
+
+
+def generate_teacher(ref):
+    """Teacher forward golden ("next" row §8f-1): frozen cls-token ViT-B, 8x224^2, B=2."""
+    reg, ms, mf, _, _ = ref
+    cfg = ref_cpu.SlotViTConfig(all_frames=8)
+    torch.manual_seed(0)
+    teacher = reg["vit_base_patch16_224"](num_classes=365, all_frames=8, tubelet_size=2, use_mean_pooling=False,
+                                          init_scale=1e-3)
+    teacher.eval()
+    synth.fill_module_(teacher, seed=1)
+    shapes = ref_cpu.teacher_param_shapes(cfg)
+    names = [n for n, _ in teacher.named_parameters()]
+    assert sorted(names) == sorted(shapes.keys()), set(names) ^ set(shapes.keys())
+    x = synth.video(2, 8, 224, seed=1000)
+    with torch.no_grad():
+        tok, logits = teacher(x, return_attn=False)
+        P = synth.fill_params(shapes, seed=1)
+        otok, ologits = ref_cpu.teacher_forward(P, cfg, x)
+    e1, e2 = rel_err(otok, tok), rel_err(ologits, logits)
+    print(f"[teacher_vitb_t8] oracle vs reference: token={e1:.2e} logits={e2:.2e}")
+    assert e1 < 5e-5 and e2 < 5e-5
+    path = os.path.join(ROOT, "tests", "golden", "teacher_vitb_t8.npz")
+    np.savez_compressed(path, token=tok.numpy(), logits=logits.numpy())
+    print(f"[teacher_vitb_t8] wrote {path}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count() or 8)
+    ref = install_reference()
+    for name in CONFIGS:
+        if args.only in (None, name):
+            generate(name, ref)
+    if args.only in (None, "teacher"):
+        generate_teacher(ref)
+
+
+if __name__ == "__main__":
+    main()
