@@ -1,0 +1,107 @@
+"""ctypes binding of libdevias_amd.so (the C ABI declared in include/devias_amd.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent, loading raises.
+`import torch` happens first so the HIP runtime bundled with PyTorch (soname libamdhip64.so.7) is the one
+the library binds to -- a second runtime is never pulled into the process.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdevias_amd.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4, 5
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32),
+        ("trans_a", c_int32), ("trans_b", c_int32),
+        ("dtype", c_int32), ("c_f32", c_int32),
+        ("bias", c_void_p), ("act", c_int32),
+        ("aux_in", c_void_p), ("aux_out", c_void_p), ("ld_aux", c_int32),
+        ("res", c_void_p), ("ldr", c_int32), ("res_mod", c_int32),
+        ("beta", c_float), ("split_k", c_int32), ("ws", c_void_p),
+    ]
+
+
+class LossDims(Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "S", "C", "nb", "ns", "D", "G", "N", "nh")] + \
+               [("w_scene", c_float), ("w_mask_pred", c_float), ("w_mask_distill", c_float), ("dtype", c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/devias_amd.h one to one
+_P, _I, _L, _F = c_void_p, c_int32, c_int64, c_float
+PROTOTYPES = {
+    "devias_version": (c_int, []),
+    "devias_last_error": (c_char_p, []),
+    "devias_device_info": (c_int, [c_int, POINTER(c_int64)]),
+    "devias_gemm": (c_int, [POINTER(GemmArgs), _P]),
+    "devias_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
+    "devias_cast": (c_int, [_P, _I, _P, _I, _L, _P]),
+    "devias_patch_im2col": (c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "devias_colsum": (c_int, [_P, _I, _I, _I, _I, _P, _F, _P, _P]),
+    "devias_colsum_workspace_bytes": (c_int64, [_I, _I]),
+    "devias_rows_reduce_mod": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    "devias_rows_broadcast": (c_int, [_P, _I, _I, _P, _I, _I, _P]),
+    "devias_act_bwd": (c_int, [_P, _P, _P, _I, _I, _L, _P]),
+    "devias_add": (c_int, [_P, _P, _P, _I, _L, _P]),
+    "devias_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
+    "devias_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
+    "devias_layernorm_bwd_workspace_bytes": (c_int64, [_I, _I]),
+    "devias_mhsa_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "devias_mhsa_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "devias_slot_attn_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "devias_slot_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "devias_slot_attn_kv_grad": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "devias_slot_attn_workspace_bytes": (c_int64, [_I, _I, _I, _I, _I]),
+    "devias_slot_select": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "devias_head_match_loss_fwd": (c_int, [POINTER(LossDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "devias_head_match_loss_bwd": (c_int, [POINTER(LossDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "devias_head_match_loss_workspace_bytes": (c_int64, [_I]),
+    "devias_adamw_step": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+}
+
+_lib = None
+
+
+class DeviasLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library and bind every prototype; raises DeviasLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DeviasLibraryError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m devias_amd.build` "
+            "(hipcc, gfx950). There is no CPU/PyTorch fallback for the DEVIAS hot path.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise DeviasLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DeviasLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().devias_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,70 @@
+"""Build libdevias_amd.so in-tree with hipcc for gfx950 (no torch / pybind dependency: the ABI is plain C).
+
+    python -m devias_amd.build          # build if sources are newer than the library
+    python -m devias_amd.build --force
+
+The library is linked against libamdhip64.so.7 only; inside a PyTorch process the already-loaded HIP runtime
+bundled with torch (same soname) satisfies it, so no second runtime is pulled in.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdevias_amd.so")
+SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "layernorm.hip", "attention.hip", "slot_attn.hip", "loss.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
+         "-fno-gpu-rdc", "-mllvm", "-amdgpu-early-inline-all=true"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
+                                                       os.path.join(HERE, "..", "include", "devias_amd.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "devias_amd.h")]
+    if os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
+        return obj
+    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB
+    if not os.path.exists(HIPCC):
+        raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libdevias_amd.so")
+    if force:
+        for s in SOURCES:
+            o = os.path.join(CSRC, s.replace(".hip", ".o"))
+            if os.path.exists(o):
+                os.remove(o)
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.2f} MB)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,646 @@
+// Encoder multi-head self-attention core for gfx950 (head dim 64, non-causal, arbitrary sequence length N).
+// Reference semantics: softmax((q * dh^-0.5) k^T) v  (model/modeling_slot.py:102-112); the N x N matrix is never
+// materialised (online softmax forward; recompute-from-logsumexp backward).
+//
+// bf16 path (measured mode): MFMA 16x16x32, "key-major" score tiles.  The score tile is computed TRANSPOSED,
+// S^T = K Q^T, so that after the MFMA each lane owns ONE query column (lane & 15) and 4 keys per 16-key tile
+// (rows 4*(lane>>4)+r): the online-softmax row statistics are lane-local plus two cross-lane shuffles, and the
+// probability tile is directly the B operand of the next MFMA (O^T = V^T P^T) with a fixed k-permutation
+// (element j of lane-group g <-> key 16*(2s + (j>>2)) + 4g + (j&3)), matched on the A side by reading V^T with
+// the transposing LDS read ds_read_b64_tr_b16.  No probability tile ever goes through LDS.
+//   forward      : workgroup = 4 waves x 32 queries, K/V tiles of 64 keys double-staged through registers -> LDS
+//   backward dQ  : same decomposition (query on the lane), also produces delta = rowsum(dO * O)
+//   backward dKdV: workgroup = 4 waves x 32 keys (key on the lane, K/V fragments resident in registers),
+//                  Q/dO tiles of 64 queries through LDS (row image + transposed-read image each)
+// fp32 path (parity mode): straightforward VALU kernels (one thread per query / two threads per key), exact fp32.
+//
+// qkv layout is [B, N, 3, H, 64] exactly as produced by the fused QKV GEMM; o / d_o are [B, N, H*64].
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+// ---- LDS images of a [64 rows][64 cols] bf16 tile (8 KiB each) ------------------------------------------
+// row image: 128-byte rows, 16-byte chunk index XOR (row & 7)  -> conflict-free ds_read_b128 of [row][8 cols]
+__device__ __forceinline__ int img_row_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// transposed-read image: 128-byte rows, 32-byte window XOR ((row >> 1) & 3) -> conflict-free ds_read_b64_tr_b16
+__device__ __forceinline__ int img_tr_off(int row, int col) {
+    return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + (col & 15) * 2;
+}
+
+// fragment of the row image: lane holds tile[row = base + (lane&15)][32*ks + 8*(lane>>4) .. +8]
+__device__ __forceinline__ bf16x8 frag_rows(const char* img, int base, int ks, int lane) {
+    int row = base + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(img + img_row_off(row, ks * 4 + (lane >> 4)));
+}
+// fragment of the transposed image for the product over ROWS of the tile (k = tile row, permuted as in the header):
+// lane holds tile[row = 16*(2s + (j>>2)) + 4g + (j&3)][col = cbase + (lane&15)], j = 0..7
+__device__ __forceinline__ bf16x8 frag_tr(const char* img, int cbase, int s, int lane) {
+    int g = lane >> 4, c = lane & 15;
+    int r0 = 32 * s + 4 * g + (c >> 2);
+    int col = cbase + 4 * (c & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + img_tr_off(r0, col)));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + img_tr_off(r0 + 16, col)));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+    bf16x8 r = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+    return r;
+}
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// stage a [64][64] bf16 tile: 512 16-byte chunks, 2 per thread.  rows >= nrows are zero-filled.
+struct TileRegs {
+    u32x4 v[2];
+    __device__ __forceinline__ void load(const bf16* __restrict__ base, int64_t row_stride, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + i * 256, row = c >> 3, ch = c & 7;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            v[i] = (row0 + row < nrows) ? *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + row) * row_stride + ch * 8) : z;
+        }
+    }
+    __device__ __forceinline__ void store_rows(char* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + i * 256, row = c >> 3, ch = c & 7;
+            *reinterpret_cast<u32x4*>(img + img_row_off(row, ch)) = v[i];
+        }
+    }
+    __device__ __forceinline__ void store_tr(char* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int c = tid + i * 256, row = c >> 3, ch = c & 7;
+            *reinterpret_cast<u32x4*>(img + img_tr_off(row, ch * 8)) = v[i];
+        }
+    }
+};
+
+// ======================================= forward (bf16) ===================================================
+__global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                            float* __restrict__ lse, int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[16384];
+    char* imgK = smem;            // row image of K tile  [key][d]
+    char* imgV = smem + 8192;     // transposed-read image of V tile [key][d]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int64_t RS = 3 * (int64_t)D;
+    const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float sl2 = scale * LOG2E;
+
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = min(q0 + 16 * qt + c, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[qt][ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * RS + 32 * ks + 8 * g);
+    }
+    f32x4 acc_o[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+
+    const int nkv = (N + 63) / 64;
+    TileRegs rk, rv;
+    rk.load(base + D, RS, 0, N, tid);
+    rv.load(base + 2 * D, RS, 0, N, tid);
+    for (int t = 0; t < nkv; ++t) {
+        rk.store_rows(imgK, tid);
+        rv.store_tr(imgV, tid);
+        __syncthreads();
+        if (t + 1 < nkv) {
+            rk.load(base + D, RS, (t + 1) * 64, N, tid);
+            rv.load(base + 2 * D, RS, (t + 1) * 64, N, tid);
+        }
+        // S^T tile: acc_s[kt][qt] holds keys 16kt + 4g + r (rows) x query c (col)
+        f32x4 acc_s[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                bf16x8 kf = frag_rows(imgK, 16 * kt, ks, lane);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) acc_s[kt][qt] = mfma(kf, qf[qt][ks], acc_s[kt][qt]);
+            }
+        const int k0 = t * 64;
+        const bool tail = k0 + 64 > N;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = acc_s[kt][qt][r] * sl2;
+                    if (tail && (k0 + 16 * kt + 4 * g + r >= N)) s = -INFINITY;
+                    acc_s[kt][qt][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrow[qt], mx);
+            const float alpha = exp2f(mrow[qt] - mnew);
+            mrow[qt] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = exp2f(acc_s[kt][qt][r] - mnew);
+                    acc_s[kt][qt][r] = p;
+                    ps += p;
+                }
+            lrow[qt] = lrow[qt] * alpha + ps;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
+        }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 pf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) pf[qt] = pack8(acc_s[2 * s][qt], acc_s[2 * s + 1][qt]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x8 vf = frag_tr(imgV, 16 * dt, s, lane);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) acc_o[dt][qt] = mfma(vf, pf[qt], acc_o[dt][qt]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lrow[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int q = q0 + 16 * qt + c;
+        if (q < N) {
+            const float inv = 1.0f / l;
+            bf16* orow = o + ((int64_t)b * N + q) * D + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt, acc_o[dt][qt] * inv);
+            if (g == 0) lse[((int64_t)b * H + h) * N + q] = (mrow[qt] + log2f(l)) * LN2;
+        }
+    }
+}
+
+// ======================================= backward dQ (bf16) ==============================================
+__global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                               const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                               float* __restrict__ delta, bf16* __restrict__ dqkv,
+                                                               int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[24576];
+    char* imgK = smem;             // K rows   (S^T = K Q^T)
+    char* imgKt = smem + 8192;     // K transposed-read (dQ^T = K^T dS^T)
+    char* imgV = smem + 16384;     // V rows   (dP^T = V dO^T)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int64_t RS = 3 * (int64_t)D;
+    const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float sl2 = scale * LOG2E;
+
+    bf16x8 qf[2][2], dof[2][2];
+    float lse2[2], dl[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = min(q0 + 16 * qt + c, N - 1);
+        const bf16* orow = o + ((int64_t)b * N + q) * D + h * 64;
+        const bf16* dorow = d_o + ((int64_t)b * N + q) * D + h * 64;
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[qt][ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * RS + 32 * ks + 8 * g);
+            dof[qt][ks] = *reinterpret_cast<const bf16x8*>(dorow + 32 * ks + 8 * g);
+            bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + 32 * ks + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)dof[qt][ks][j] * (float)of[j];
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        dl[qt] = part;
+        lse2[qt] = lse[((int64_t)b * H + h) * N + q] * LOG2E;
+        if (g == 0 && q0 + 16 * qt + c < N) delta[((int64_t)b * H + h) * N + q] = part;
+    }
+    f32x4 acc_dq[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc_dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkv = (N + 63) / 64;
+    TileRegs rk, rv;
+    rk.load(base + D, RS, 0, N, tid);
+    rv.load(base + 2 * D, RS, 0, N, tid);
+    for (int t = 0; t < nkv; ++t) {
+        rk.store_rows(imgK, tid);
+        rk.store_tr(imgKt, tid);
+        rv.store_rows(imgV, tid);
+        __syncthreads();
+        if (t + 1 < nkv) {
+            rk.load(base + D, RS, (t + 1) * 64, N, tid);
+            rv.load(base + 2 * D, RS, (t + 1) * 64, N, tid);
+        }
+        f32x4 acc_s[4][2], acc_dp[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                bf16x8 kf = frag_rows(imgK, 16 * kt, ks, lane);
+                bf16x8 vf = frag_rows(imgV, 16 * kt, ks, lane);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    acc_s[kt][qt] = mfma(kf, qf[qt][ks], acc_s[kt][qt]);
+                    acc_dp[kt][qt] = mfma(vf, dof[qt][ks], acc_dp[kt][qt]);
+                }
+            }
+        const int k0 = t * 64;
+        const bool tail = k0 + 64 > N;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = exp2f(acc_s[kt][qt][r] * sl2 - lse2[qt]);
+                    if (tail && (k0 + 16 * kt + 4 * g + r >= N)) p = 0.f;
+                    acc_s[kt][qt][r] = p * (acc_dp[kt][qt][r] - dl[qt]) * scale;   // dS^T (wrt raw q.k)
+                }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 dsf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) dsf[qt] = pack8(acc_s[2 * s][qt], acc_s[2 * s + 1][qt]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x8 kf = frag_tr(imgKt, 16 * dt, s, lane);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) acc_dq[dt][qt] = mfma(kf, dsf[qt], acc_dq[dt][qt]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + 16 * qt + c;
+        if (q < N) {
+            bf16* row = dqkv + ((int64_t)b * N + q) * RS + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt, acc_dq[dt][qt]);
+        }
+    }
+}
+
+// ======================================= backward dK, dV (bf16) ==========================================
+__global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                 bf16* __restrict__ dqkv, int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 8192 + 512];
+    char* imgQ = smem;              // Q rows    (S = Q K^T)
+    char* imgQt = smem + 8192;      // Q transposed-read (dK^T = Q^T dS)
+    char* imgO = smem + 16384;      // dO rows   (dP = dO V^T)
+    char* imgOt = smem + 24576;     // dO transposed-read (dV^T = dO^T P)
+    float* s_lse = reinterpret_cast<float*>(smem + 32768);   // [64] log2-domain logsumexp (+inf for invalid rows)
+    float* s_dl = s_lse + 64;                                // [64] delta
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int64_t RS = 3 * (int64_t)D;
+    const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
+    const bf16* dobase = d_o + (int64_t)b * N * D + h * 64;
+    const int key0 = blockIdx.x * 128 + wave * 32;
+    const float sl2 = scale * LOG2E;
+
+    bf16x8 kreg[2][2], vreg[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        int key = min(key0 + 16 * kt + c, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kreg[kt][ks] = *reinterpret_cast<const bf16x8*>(base + D + (int64_t)key * RS + 32 * ks + 8 * g);
+            vreg[kt][ks] = *reinterpret_cast<const bf16x8*>(base + 2 * D + (int64_t)key * RS + 32 * ks + 8 * g);
+        }
+    }
+    f32x4 acc_dk[4][2], acc_dv[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc_dk[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nq = (N + 63) / 64;
+    const float* lse_bh = lse + ((int64_t)b * H + h) * N;
+    const float* dl_bh = delta + ((int64_t)b * H + h) * N;
+    TileRegs rq, rdo;
+    float rstat = 0.f;
+    rq.load(base, RS, 0, N, tid);
+    rdo.load(dobase, D, 0, N, tid);
+    if (tid < 64) rstat = tid < N ? lse_bh[tid] * LOG2E : INFINITY;
+    else if (tid < 128) rstat = (tid - 64) < N ? dl_bh[tid - 64] : 0.f;
+    for (int t = 0; t < nq; ++t) {
+        rq.store_rows(imgQ, tid);
+        rq.store_tr(imgQt, tid);
+        rdo.store_rows(imgO, tid);
+        rdo.store_tr(imgOt, tid);
+        if (tid < 128) s_lse[tid] = rstat;      // s_dl follows s_lse contiguously
+        __syncthreads();
+        if (t + 1 < nq) {
+            const int r0 = (t + 1) * 64;
+            rq.load(base, RS, r0, N, tid);
+            rdo.load(dobase, D, r0, N, tid);
+            if (tid < 64) rstat = r0 + tid < N ? lse_bh[r0 + tid] * LOG2E : INFINITY;
+            else if (tid < 128) rstat = r0 + tid - 64 < N ? dl_bh[r0 + tid - 64] : 0.f;
+        }
+        // S and dP tiles: acc[qt][kt] holds queries 16qt + 4g + r (rows) x key c (col)
+        f32x4 acc_s[4][2], acc_dp[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                bf16x8 qfr = frag_rows(imgQ, 16 * qt, ks, lane);
+                bf16x8 dofr = frag_rows(imgO, 16 * qt, ks, lane);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    acc_s[qt][kt] = mfma(qfr, kreg[kt][ks], acc_s[qt][kt]);
+                    acc_dp[qt][kt] = mfma(dofr, vreg[kt][ks], acc_dp[qt][kt]);
+                }
+            }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dl + 16 * qt + 4 * g);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = exp2f(acc_s[qt][kt][r] * sl2 - l4[r]);
+                    acc_s[qt][kt][r] = p;
+                    acc_dp[qt][kt][r] = p * (acc_dp[qt][kt][r] - d4[r]) * scale;
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                pf[kt] = pack8(acc_s[2 * s][kt], acc_s[2 * s + 1][kt]);
+                dsf[kt] = pack8(acc_dp[2 * s][kt], acc_dp[2 * s + 1][kt]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x8 dot = frag_tr(imgOt, 16 * dt, s, lane);
+                bf16x8 qt_ = frag_tr(imgQt, 16 * dt, s, lane);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    acc_dv[dt][kt] = mfma(dot, pf[kt], acc_dv[dt][kt]);
+                    acc_dk[dt][kt] = mfma(qt_, dsf[kt], acc_dk[dt][kt]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = key0 + 16 * kt + c;
+        if (key < N) {
+            bf16* row = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                store4(row + D + 16 * dt, acc_dk[dt][kt]);
+                store4(row + 2 * D + 16 * dt, acc_dv[dt][kt]);
+            }
+        }
+    }
+}
+
+// ======================================= fp32 parity kernels ==============================================
+// forward: 128 threads, one query per thread (q and o in registers), K/V tiles of 32 keys broadcast from LDS
+__global__ __launch_bounds__(128) void mhsa_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                           float* __restrict__ lse, int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) float sk[32][64];
+    __shared__ __attribute__((aligned(16))) float sv[32][64];
+    const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int64_t RS = 3 * (int64_t)D;
+    const float* base = qkv + (int64_t)b * N * RS + h * 64;
+    const int q = blockIdx.x * 128 + tid;
+    const int qc = min(q, N - 1);
+    float qr[64], acc[64];
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)qc * RS + d);
+        qr[d] = v[0] * scale; qr[d + 1] = v[1] * scale; qr[d + 2] = v[2] * scale; qr[d + 3] = v[3] * scale;
+        acc[d] = acc[d + 1] = acc[d + 2] = acc[d + 3] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < 32 * 16; i += 128) {
+            int r = i >> 4, ch = (i & 15) * 4;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bool ok = k0 + r < N;
+            *reinterpret_cast<f32x4*>(&sk[r][ch]) = ok ? *reinterpret_cast<const f32x4*>(base + D + (int64_t)(k0 + r) * RS + ch) : z;
+            *reinterpret_cast<f32x4*>(&sv[r][ch]) = ok ? *reinterpret_cast<const f32x4*>(base + 2 * D + (int64_t)(k0 + r) * RS + ch) : z;
+        }
+        __syncthreads();
+        const int nk = min(32, N - k0);
+        for (int j = 0; j < nk; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) s += qr[d] * sk[j][d];
+            const float mn = fmaxf(m, s);
+            const float alpha = expf(m - mn), p = expf(s - mn);
+            m = mn;
+            l = l * alpha + p;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) acc[d] = acc[d] * alpha + p * sv[j][d];
+        }
+    }
+    if (q < N) {
+        const float inv = 1.0f / l;
+        float* orow = o + ((int64_t)b * N + q) * D + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; d += 4) {
+            f32x4 v = {acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv};
+            *reinterpret_cast<f32x4*>(orow + d) = v;
+        }
+        lse[((int64_t)b * H + h) * N + q] = m + logf(l);
+    }
+}
+
+// backward dQ (+ delta): one query per thread
+__global__ __launch_bounds__(128) void mhsa_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                              const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, float* __restrict__ dqkv,
+                                                              int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) float sk[32][64];
+    __shared__ __attribute__((aligned(16))) float sv[32][64];
+    const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int64_t RS = 3 * (int64_t)D;
+    const float* base = qkv + (int64_t)b * N * RS + h * 64;
+    const int q = blockIdx.x * 128 + tid;
+    const int qc = min(q, N - 1);
+    float qr[64], dor[64], dq[64];
+    float dl = 0.f;
+    const float* orow = o + ((int64_t)b * N + qc) * D + h * 64;
+    const float* dorow = d_o + ((int64_t)b * N + qc) * D + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+        qr[d] = base[(int64_t)qc * RS + d];
+        dor[d] = dorow[d];
+        dl += dor[d] * orow[d];
+        dq[d] = 0.f;
+    }
+    const float ls = lse[((int64_t)b * H + h) * N + qc];
+    if (q < N) delta[((int64_t)b * H + h) * N + q] = dl;
+    for (int k0 = 0; k0 < N; k0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < 32 * 16; i += 128) {
+            int r = i >> 4, ch = (i & 15) * 4;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bool ok = k0 + r < N;
+            *reinterpret_cast<f32x4*>(&sk[r][ch]) = ok ? *reinterpret_cast<const f32x4*>(base + D + (int64_t)(k0 + r) * RS + ch) : z;
+            *reinterpret_cast<f32x4*>(&sv[r][ch]) = ok ? *reinterpret_cast<const f32x4*>(base + 2 * D + (int64_t)(k0 + r) * RS + ch) : z;
+        }
+        __syncthreads();
+        const int nk = min(32, N - k0);
+        for (int j = 0; j < nk; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) { s += qr[d] * sk[j][d]; dp += dor[d] * sv[j][d]; }
+            const float p = expf(s * scale - ls);
+            const float ds = p * (dp - dl) * scale;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) dq[d] += ds * sk[j][d];
+        }
+    }
+    if (q < N) {
+        float* row = dqkv + ((int64_t)b * N + q) * RS + h * 64;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) row[d] = dq[d];
+    }
+}
+
+// backward dK/dV: two threads per key (each owns 32 of the 64 head dims); 128 threads = 64 keys per workgroup
+__global__ __launch_bounds__(128) void mhsa_bwd_dkdv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                float* __restrict__ dqkv, int N, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) float sq[32][64];
+    __shared__ __attribute__((aligned(16))) float sdo[32][64];
+    __shared__ float sl[32], sd[32];
+    const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int64_t RS = 3 * (int64_t)D;
+    const float* base = qkv + (int64_t)b * N * RS + h * 64;
+    const float* dobase = d_o + (int64_t)b * N * D + h * 64;
+    const int key = blockIdx.x * 64 + (tid >> 1);
+    const int half = (tid & 1) * 32;
+    const int kc = min(key, N - 1);
+    float kr[32], vr[32], dk[32], dv[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+        kr[d] = base[D + (int64_t)kc * RS + half + d];
+        vr[d] = base[2 * D + (int64_t)kc * RS + half + d];
+        dk[d] = 0.f; dv[d] = 0.f;
+    }
+    for (int q0 = 0; q0 < N; q0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < 32 * 16; i += 128) {
+            int r = i >> 4, ch = (i & 15) * 4;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bool ok = q0 + r < N;
+            *reinterpret_cast<f32x4*>(&sq[r][ch]) = ok ? *reinterpret_cast<const f32x4*>(base + (int64_t)(q0 + r) * RS + ch) : z;
+            *reinterpret_cast<f32x4*>(&sdo[r][ch]) = ok ? *reinterpret_cast<const f32x4*>(dobase + (int64_t)(q0 + r) * D + ch) : z;
+        }
+        if (tid < 32) {
+            bool ok = q0 + tid < N;
+            sl[tid] = ok ? lse[((int64_t)b * H + h) * N + q0 + tid] : INFINITY;
+            sd[tid] = ok ? delta[((int64_t)b * H + h) * N + q0 + tid] : 0.f;
+        }
+        __syncthreads();
+        const int nq = min(32, N - q0);
+        for (int i = 0; i < nq; ++i) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s += sq[i][half + d] * kr[d]; dp += sdo[i][half + d] * vr[d]; }
+            s += __shfl_xor(s, 1, 64);
+            dp += __shfl_xor(dp, 1, 64);
+            const float p = expf(s * scale - sl[i]);
+            const float ds = p * (dp - sd[i]) * scale;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { dv[d] += p * sdo[i][half + d]; dk[d] += ds * sq[i][half + d]; }
+        }
+    }
+    if (key < N) {
+        float* row = dqkv + ((int64_t)b * N + key) * RS + h * 64 + half;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { row[D + d] = dk[d]; row[2 * D + d] = dv[d]; }
+    }
+}
+
+}  // namespace
+
+extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
+                               int32_t dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0, "devias_mhsa_fwd: bad args");
+    DEVIAS_REQUIRE(aligned16(qkv) && aligned16(o), "devias_mhsa_fwd: qkv/o must be 16-byte aligned");
+    DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_fwd: H and B must be <= 65535");
+    if (dtype == DEVIAS_BF16)
+        hipLaunchKernelGGL(mhsa_fwd_bf16_kernel, dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+    else if (dtype == DEVIAS_F32)
+        hipLaunchKernelGGL(mhsa_fwd_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (float*)o, lse, N, H, scale);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_mhsa_fwd: bad dtype %d", dtype);
+    DEVIAS_CHECK_LAUNCH("devias_mhsa_fwd");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                               int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(qkv && o && d_o && lse && delta && dqkv && B > 0 && N > 0 && H > 0, "devias_mhsa_bwd: bad args");
+    DEVIAS_REQUIRE(aligned16(qkv) && aligned16(o) && aligned16(d_o) && aligned16(dqkv), "devias_mhsa_bwd: unaligned pointer");
+    DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_bwd: H and B must be <= 65535");
+    if (dtype == DEVIAS_BF16) {
+        hipLaunchKernelGGL(mhsa_bwd_dq_bf16_kernel, dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)o,
+                           (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale);
+        DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");
+        hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel, dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
+                           lse, delta, (bf16*)dqkv, N, H, scale);
+        DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv)");
+    } else if (dtype == DEVIAS_F32) {
+        hipLaunchKernelGGL(mhsa_bwd_dq_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)o,
+                           (const float*)d_o, lse, delta, (float*)dqkv, N, H, scale);
+        DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");
+        hipLaunchKernelGGL(mhsa_bwd_dkdv_f32_kernel, dim3(cdiv(N, 64), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)d_o,
+                           lse, delta, (float*)dqkv, N, H, scale);
+        DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv)");
+    } else return devias_set_error(DEVIAS_EINVAL, "devias_mhsa_bwd: bad dtype %d", dtype);
+    return DEVIAS_OK;
+}

@@ -1,0 +1,248 @@
+// HBM-bound helpers: casts, tubelet im2col, column sums (bias gradients), row broadcast / reduce, add, AdamW.
+// All are vectorised to 16 bytes per lane where alignment allows and grid-stride over <= 2048 workgroups.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float ld_as_f32(const void* p, int dt, int64_t i) {
+    return dt == DEVIAS_BF16 ? (float)reinterpret_cast<const bf16*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_from_f32(void* p, int dt, int64_t i, float v) {
+    if (dt == DEVIAS_BF16) reinterpret_cast<bf16*>(p)[i] = (bf16)v;
+    else reinterpret_cast<float*>(p)[i] = v;
+}
+
+// ---- cast -------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n, int vec) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        int64_t n4 = n >> 2;
+        for (int64_t i = i0; i < n4; i += stride) store4(dst + 4 * i, load4(src + 4 * i));
+        for (int64_t i = (n4 << 2) + i0; i < n; i += stride) dst[i] = from_f32<D>(to_f32(src[i]));
+    } else {
+        for (int64_t i = i0; i < n; i += stride) dst[i] = from_f32<D>(to_f32(src[i]));
+    }
+}
+
+// ---- im2col -----------------------------------------------------------------------------------------
+// one thread moves 4 consecutive kw pixels (ps % 4 == 0): 16-byte fp32 reads, 8-byte bf16 writes
+template <typename S, typename D>
+__global__ void im2col_kernel(const S* __restrict__ x, D* __restrict__ out, int B, int C, int T, int H, int W,
+                              int ts, int ps) {
+    const int g_h = H / ps, g_w = W / ps, Tp = T / ts;
+    const int F = C * ts * ps * ps;              // features per token
+    const int64_t total4 = (int64_t)B * Tp * g_h * g_w * F / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e = i * 4;
+        int f = (int)(e % F);
+        int64_t tok = e / F;
+        int kw = f % ps; int r = f / ps;
+        int kh = r % ps; r /= ps;
+        int kt = r % ts; int c = r / ts;
+        int w_ = (int)(tok % g_w); int64_t r2 = tok / g_w;
+        int h_ = (int)(r2 % g_h); r2 /= g_h;
+        int t_ = (int)(r2 % Tp); int b = (int)(r2 / Tp);
+        int64_t src = ((((int64_t)b * C + c) * T + (t_ * ts + kt)) * H + (h_ * ps + kh)) * W + (w_ * ps + kw);
+        store4(out + e, load4(x + src));
+    }
+}
+
+// ---- column sums --------------------------------------------------------------------------------------
+// stage 1: block (64 cols x RB rows) -> partial[rb][n]; stage 2: out[n] = beta*out[n] + sum_rb partial
+enum { CS_ROWS = 512 };
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ x, int M, int N, int ldx, float* __restrict__ part) {
+    // blockDim = (64, 4): 64 columns, 4 row lanes
+    __shared__ float sm[4][64];
+    int n = blockIdx.x * 64 + threadIdx.x;
+    int r0 = blockIdx.y * CS_ROWS;
+    int r1 = min(M, r0 + CS_ROWS);
+    float s = 0.f;
+    if (n < N)
+        for (int r = r0 + threadIdx.y; r < r1; r += 4) s += to_f32(x[(int64_t)r * ldx + n]);
+    sm[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && n < N)
+        part[(int64_t)blockIdx.y * N + n] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out, float beta) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < nparts; ++i) s += part[(int64_t)i * N + n];
+    out[n] = s + (beta != 0.f ? beta * out[n] : 0.f);
+}
+
+template <typename T>
+__global__ void rows_reduce_mod_kernel(const T* __restrict__ x, int M, int N, int mod, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mod * N) return;
+    int r0 = i / N, n = i % N;
+    float s = 0.f;
+    for (int r = r0; r < M; r += mod) s += to_f32(x[(int64_t)r * N + n]);
+    out[i] = s;
+}
+template <typename T>
+__global__ void rows_broadcast_kernel(const float* __restrict__ src, int mod, int N, T* __restrict__ out, int M) {
+    int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / N), n = (int)(i % N);
+        out[i] = from_f32<T>(src[(int64_t)(r % mod) * N + n]);
+    }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n, int vec) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        int64_t n4 = n >> 2;
+        for (int64_t i = i0; i < n4; i += stride) store4(y + 4 * i, load4(a + 4 * i) + load4(b + 4 * i));
+        for (int64_t i = (n4 << 2) + i0; i < n; i += stride) y[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
+    } else {
+        for (int64_t i = i0; i < n; i += stride) y[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
+    }
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, int64_t n, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float g = to_f32(dy[i]), v = to_f32(y[i]);
+        float r = act == DEVIAS_ACT_SIGMOID ? g * v * (1.0f - v) : act == DEVIAS_ACT_RELU ? (v > 0.f ? g : 0.f) : g * dgelu_f(v);
+        dx[i] = from_f32<T>(r);
+    }
+}
+
+// ---- AdamW ------------------------------------------------------------------------------------------
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale;
+        float pi = p[i] * (1.0f - lr * wd);                      // decoupled weight decay (torch.optim.AdamW)
+        float mi = m[i] + (1.0f - b1) * (gi - m[i]);             // exp_avg.lerp_(grad, 1-beta1)
+        float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+inline int grid_for(int64_t n, int per_thread = 1) {
+    int64_t b = (n / per_thread + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int devias_cast(const void* src, int32_t sd, void* dst, int32_t dd, int64_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(src && dst && n >= 0, "devias_cast: bad args");
+    if (n == 0) return DEVIAS_OK;
+    int vec = aligned16(src) && aligned16(dst);
+    dim3 g(grid_for(n, 4)), b(256);
+    if (sd == DEVIAS_F32 && dd == DEVIAS_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), g, b, 0, st, (const float*)src, (bf16*)dst, n, vec);
+    else if (sd == DEVIAS_BF16 && dd == DEVIAS_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), g, b, 0, st, (const bf16*)src, (float*)dst, n, vec);
+    else if (sd == DEVIAS_F32 && dd == DEVIAS_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n, vec);
+    else if (sd == DEVIAS_BF16 && dd == DEVIAS_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), g, b, 0, st, (const bf16*)src, (bf16*)dst, n, vec);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_cast: bad dtypes %d -> %d", sd, dd);
+    DEVIAS_CHECK_LAUNCH("devias_cast");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_patch_im2col(const void* x, int32_t xd, void* out, int32_t od, int32_t B, int32_t C, int32_t T,
+                                   int32_t H, int32_t W, int32_t ts, int32_t ps, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(x && out, "devias_patch_im2col: null pointer");
+    DEVIAS_REQUIRE(ps % 4 == 0 && H % ps == 0 && W % ps == 0 && T % ts == 0 && W % 4 == 0,
+                   "devias_patch_im2col: need ps%%4==0 and H,W divisible by ps, T by ts (got H=%d W=%d T=%d ps=%d ts=%d)", H, W, T, ps, ts);
+    DEVIAS_REQUIRE(aligned16(x) && aligned16(out), "devias_patch_im2col: pointers must be 16-byte aligned");
+    int64_t total4 = (int64_t)B * C * T * H * W / 4;
+    dim3 g(grid_for(total4)), b(256);
+    if (xd == DEVIAS_F32 && od == DEVIAS_F32) hipLaunchKernelGGL((im2col_kernel<float, float>), g, b, 0, st, (const float*)x, (float*)out, B, C, T, H, W, ts, ps);
+    else if (xd == DEVIAS_F32 && od == DEVIAS_BF16) hipLaunchKernelGGL((im2col_kernel<float, bf16>), g, b, 0, st, (const float*)x, (bf16*)out, B, C, T, H, W, ts, ps);
+    else if (xd == DEVIAS_BF16 && od == DEVIAS_BF16) hipLaunchKernelGGL((im2col_kernel<bf16, bf16>), g, b, 0, st, (const bf16*)x, (bf16*)out, B, C, T, H, W, ts, ps);
+    else if (xd == DEVIAS_BF16 && od == DEVIAS_F32) hipLaunchKernelGGL((im2col_kernel<bf16, float>), g, b, 0, st, (const bf16*)x, (float*)out, B, C, T, H, W, ts, ps);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_patch_im2col: bad dtypes");
+    DEVIAS_CHECK_LAUNCH("devias_patch_im2col");
+    return DEVIAS_OK;
+}
+
+extern "C" int64_t devias_colsum_workspace_bytes(int32_t M, int32_t N) { return (int64_t)cdiv(M, CS_ROWS) * N * 4; }
+
+extern "C" int devias_colsum(const void* x, int32_t dtype, int32_t M, int32_t N, int32_t ldx, float* out, float beta,
+                             float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(x && out && ws && M > 0 && N > 0, "devias_colsum: bad args");
+    int nparts = cdiv(M, CS_ROWS);
+    dim3 g(cdiv(N, 64), nparts), b(64, 4);
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), g, b, 0, st, (const bf16*)x, M, N, ldx, ws);
+    else hipLaunchKernelGGL((colsum_partial_kernel<float>), g, b, 0, st, (const float*)x, M, N, ldx, ws);
+    DEVIAS_CHECK_LAUNCH("devias_colsum(partial)");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, ws, nparts, N, out, beta);
+    DEVIAS_CHECK_LAUNCH("devias_colsum(final)");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_rows_reduce_mod(const void* x, int32_t dtype, int32_t M, int32_t N, int32_t mod, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(x && out && mod > 0 && M % mod == 0, "devias_rows_reduce_mod: bad args (M=%d mod=%d)", M, mod);
+    dim3 g(cdiv((int64_t)mod * N, 256)), b(256);
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((rows_reduce_mod_kernel<bf16>), g, b, 0, st, (const bf16*)x, M, N, mod, out);
+    else hipLaunchKernelGGL((rows_reduce_mod_kernel<float>), g, b, 0, st, (const float*)x, M, N, mod, out);
+    DEVIAS_CHECK_LAUNCH("devias_rows_reduce_mod");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_rows_broadcast(const float* src, int32_t mod, int32_t N, void* out, int32_t dtype, int32_t M, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(src && out && mod > 0, "devias_rows_broadcast: bad args");
+    dim3 g(grid_for((int64_t)M * N)), b(256);
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((rows_broadcast_kernel<bf16>), g, b, 0, st, src, mod, N, (bf16*)out, M);
+    else hipLaunchKernelGGL((rows_broadcast_kernel<float>), g, b, 0, st, src, mod, N, (float*)out, M);
+    DEVIAS_CHECK_LAUNCH("devias_rows_broadcast");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_add(const void* a, const void* b_, void* y, int32_t dtype, int64_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(a && b_ && y, "devias_add: null pointer");
+    if (n == 0) return DEVIAS_OK;
+    int vec = aligned16(a) && aligned16(b_) && aligned16(y);
+    dim3 g(grid_for(n, 4)), b(256);
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((add_kernel<bf16>), g, b, 0, st, (const bf16*)a, (const bf16*)b_, (bf16*)y, n, vec);
+    else hipLaunchKernelGGL((add_kernel<float>), g, b, 0, st, (const float*)a, (const float*)b_, (float*)y, n, vec);
+    DEVIAS_CHECK_LAUNCH("devias_add");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_act_bwd(const void* dy, const void* y, void* dx, int32_t act, int32_t dtype, int64_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(dy && y && dx, "devias_act_bwd: null pointer");
+    DEVIAS_REQUIRE(act == DEVIAS_ACT_SIGMOID || act == DEVIAS_ACT_RELU || act == DEVIAS_ACT_GELU, "devias_act_bwd: bad act %d", act);
+    if (n == 0) return DEVIAS_OK;
+    dim3 g(grid_for(n)), b(256);
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16>), g, b, 0, st, (const bf16*)dy, (const bf16*)y, (bf16*)dx, n, act);
+    else if (dtype == DEVIAS_F32) hipLaunchKernelGGL((act_bwd_kernel<float>), g, b, 0, st, (const float*)dy, (const float*)y, (float*)dx, n, act);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_act_bwd: bad dtype %d", dtype);
+    DEVIAS_CHECK_LAUNCH("devias_act_bwd");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                                 void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "devias_adamw_step: bad args");
+    if (n == 0) return DEVIAS_OK;
+    float bc1 = 1.0f - powf(beta1, (float)step);
+    float bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    DEVIAS_CHECK_LAUNCH("devias_adamw_step");
+    return DEVIAS_OK;
+}

@@ -1,0 +1,394 @@
+// Fused GEMM for gfx950: C[M,N] = epi( op(A)[M,K] * op(B)[K,N] ), MFMA 16x16x32 bf16 / 16x16x4 f32, fp32 accumulate.
+//
+// 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA tiles).
+// Operands are staged global -> registers -> LDS (next tile's loads are issued before the MFMAs of the
+// current one).  Two LDS images exist per operand kind:
+//   KC ("k contiguous", e.g. activations [M,K], nn.Linear weights [N,K]): [128 rows][BK] with the 16-byte
+//      chunk index XOR (row & 7) -> conflict-free ds_read_b128 fragment reads;
+//   KS ("k strided", e.g. dY for wgrad, W for dgrad): [BK][128 cols], 32-byte windows XOR f(k) -> conflict-free
+//      ds_read_b64_tr_b16 transposing reads (gfx950), which deliver the MFMA fragment with k contiguous per lane.
+// The MFMA is issued as mfma(Bfrag, Afrag) so each lane ends up with 4 CONSECUTIVE output columns of one row
+// (8-byte bf16 / 16-byte f32 epilogue accesses, bias as one float4).
+#include "common.h"
+
+namespace {
+
+enum { BM = 128, BN = 128, NTHREADS = 256 };
+
+struct GemmP {
+    const void* A; const void* B; void* C;
+    int M, N, K, lda, ldb, ldc;
+    const float* bias; int act;
+    const void* aux_in; void* aux_out; int ld_aux;
+    const void* res; int ldr, res_mod;
+    float beta; int c_f32; int vec_c;
+    float* ws; int k_per_split; int split_k;
+    int tiles_m, tiles_n;
+};
+
+template <typename T> struct Tr;
+template <> struct Tr<bf16> {
+    enum { BK = 64, KSTEP = 32, CH = 8, KC_BYTES = 128 * 128, KS_BYTES = 64 * 256 };
+    typedef bf16x8 frag;
+};
+template <> struct Tr<float> {
+    enum { BK = 16, KSTEP = 4, CH = 4, KC_BYTES = 128 * 20 * 4, KS_BYTES = 16 * 144 * 4 };
+    typedef float frag;
+};
+
+// ---- LDS byte offsets of one element ---------------------------------------------------------------
+__device__ __forceinline__ int ks_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+template <typename T> __device__ __forceinline__ int off_kc(int row, int k);
+template <typename T> __device__ __forceinline__ int off_ks(int k, int col);
+template <> __device__ __forceinline__ int off_kc<bf16>(int row, int k) {
+    return row * 128 + ((((k >> 3) ^ (row & 7))) << 4) + (k & 7) * 2;
+}
+template <> __device__ __forceinline__ int off_ks<bf16>(int k, int col) {
+    return k * 256 + ((((col >> 4) ^ ks_f(k))) << 5) + (col & 15) * 2;
+}
+template <> __device__ __forceinline__ int off_kc<float>(int row, int k) { return (row * 20 + k) * 4; }
+template <> __device__ __forceinline__ int off_ks<float>(int k, int col) { return (k * 144 + col) * 4; }
+
+// ---- staging: global -> registers ------------------------------------------------------------------
+// One operand tile is 128 x BK elements = 256 threads x NCH 16-byte chunks.
+template <typename T, bool KSTRIDED, bool VEC>
+struct Stage {
+    enum { BK = Tr<T>::BK, CH = Tr<T>::CH, NCH = 128 * BK / CH / NTHREADS, NEL = 128 * BK / NTHREADS };
+    u32x4 v[NCH];
+
+    // ptr: operand base; ld: leading dim; r0: first row/col of the 128-wide dim; R: its extent; k0: first k; kend: exclusive k bound
+    __device__ __forceinline__ void load(const T* __restrict__ ptr, int ld, int r0, int R, int k0, int kend, int tid) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                int c = tid + i * NTHREADS;
+                int row, k;
+                if constexpr (!KSTRIDED) { row = c / (BK / CH); k = (c % (BK / CH)) * CH; }
+                else { k = c / (128 / CH); row = (c % (128 / CH)) * CH; }
+                int gr = r0 + row, gk = k0 + k;
+                bool ok = gr < R && gk < kend;
+                const T* src = KSTRIDED ? ptr + (int64_t)gk * ld + gr : ptr + (int64_t)gr * ld + gk;
+                u32x4 z = {0u, 0u, 0u, 0u};
+                v[i] = ok ? *reinterpret_cast<const u32x4*>(src) : z;
+            }
+        } else {
+            // scalar guarded path: pack CH consecutive elements (along the contiguous dim) into one chunk
+            T* e = reinterpret_cast<T*>(v);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                int c = tid + i * NTHREADS;
+                int row, k;
+                if constexpr (!KSTRIDED) { row = c / (BK / CH); k = (c % (BK / CH)) * CH; }
+                else { k = c / (128 / CH); row = (c % (128 / CH)) * CH; }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    int gr = r0 + row + (KSTRIDED ? j : 0), gk = k0 + k + (KSTRIDED ? 0 : j);
+                    bool ok = gr < R && gk < kend;
+                    const T* src = KSTRIDED ? ptr + (int64_t)gk * ld + gr : ptr + (int64_t)gr * ld + gk;
+                    e[i * CH + j] = ok ? *src : from_f32<T>(0.f);
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NTHREADS;
+            int off;
+            if constexpr (!KSTRIDED) { int row = c / (BK / CH), k = (c % (BK / CH)) * CH; off = off_kc<T>(row, k); }
+            else { int k = c / (128 / CH), col = (c % (128 / CH)) * CH; off = off_ks<T>(k, col); }
+            *reinterpret_cast<u32x4*>(lds + off) = v[i];
+        }
+    }
+};
+
+// ---- fragment reads ----------------------------------------------------------------------------------
+// tile16 = index of the 16-wide tile inside the 128-wide dim, ks = k-step inside BK
+template <bool KSTRIDED>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int base16, int ks, int lane, bf16*) {
+    if constexpr (!KSTRIDED) {
+        int row = base16 + (lane & 15);
+        int kch = ks * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kch ^ (row & 7)) << 4));
+    } else {
+        int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
+        int k = ks * 32 + g * 8 + q;
+        int col = base16 + 4 * p;
+        typedef __attribute__((address_space(3))) bf16x4* lp;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lds + off_ks<bf16>(k, col)));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lds + off_ks<bf16>(k + 4, col)));
+        bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+    }
+}
+template <bool KSTRIDED>
+__device__ __forceinline__ float read_frag(const char* lds, int base16, int ks, int lane, float*) {
+    int i = base16 + (lane & 15), k = ks * 4 + (lane >> 4);
+    if constexpr (!KSTRIDED) return *reinterpret_cast<const float*>(lds + off_kc<float>(i, k));
+    else return *reinterpret_cast<const float*>(lds + off_ks<float>(k, i));
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// bijective XCD-aware remap: consecutive logical tile ids land on one XCD (private L2) -- speed only
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+template <typename T, bool TA, bool TB, bool VEC>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmP p) {
+    typedef typename Tr<T>::frag frag;
+    constexpr int BK = Tr<T>::BK, KSTEP = Tr<T>::KSTEP;
+    constexpr int A_BYTES = TA ? Tr<T>::KS_BYTES : Tr<T>::KC_BYTES;
+    constexpr int B_BYTES = TB ? Tr<T>::KS_BYTES : Tr<T>::KC_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[A_BYTES + B_BYTES];
+    char* ldsA = smem;
+    char* ldsB = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tm = t / p.tiles_n, tn = t % p.tiles_n;       // n fastest: neighbours share the A row panel
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int kbeg = z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* B = reinterpret_cast<const T*>(p.B);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Stage<T, TA, VEC> sa;
+    Stage<T, TB, VEC> sb;
+    if (nk > 0) {
+        sa.load(A, p.lda, m0, p.M, kbeg, kend, tid);
+        sb.load(B, p.ldb, n0, p.N, kbeg, kend, tid);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        sa.store(ldsA, tid);
+        sb.store(ldsB, tid);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            sa.load(A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
+            sb.load(B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / KSTEP; ++ks) {
+            frag fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<TA>(ldsA, wm * 64 + i * 16, ks, lane, (T*)nullptr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag<TB>(ldsB, wn * 64 + j * 16, ks, lane, (T*)nullptr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + r], r = 0..3 ----------------
+    const int lm = lane & 15, ln = (lane >> 4) * 4;
+    if (p.split_k > 1) {
+        float* ws = p.ws + (int64_t)z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = m0 + wm * 64 + i * 16 + lm;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int n = n0 + wn * 64 + j * 16 + ln;
+                if (p.vec_c && n + 3 < p.N) {
+                    *reinterpret_cast<f32x4*>(ws + (int64_t)m * p.N + n) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) ws[(int64_t)m * p.N + n + r] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
+
+    const T* res = reinterpret_cast<const T*>(p.res);
+    const T* aux_in = reinterpret_cast<const T*>(p.aux_in);
+    T* aux_out = reinterpret_cast<T*>(p.aux_out);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + wm * 64 + i * 16 + lm;
+        if (m >= p.M) continue;
+        int mr = p.res_mod > 0 ? m % p.res_mod : m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = n0 + wn * 64 + j * 16 + ln;
+            if (n >= p.N) continue;
+            f32x4 v = acc[i][j];
+            bool full = p.vec_c && (n + 3 < p.N);
+            if (p.bias) {
+                if (full) { f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n); v += b; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
+                }
+            }
+            if (p.act == DEVIAS_ACT_GELU) {
+                if (aux_out) {
+                    if (full) store4(aux_out + (int64_t)m * p.ld_aux + n, v);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) aux_out[(int64_t)m * p.ld_aux + n + r] = from_f32<T>(v[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            } else if (p.act == DEVIAS_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (p.act == DEVIAS_ACT_SIGMOID) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+            } else if (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) {
+                f32x4 a;
+                if (full) a = load4(aux_in + (int64_t)m * p.ld_aux + n);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = (n + r < p.N) ? to_f32(aux_in[(int64_t)m * p.ld_aux + n + r]) : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (p.act == DEVIAS_ACT_DGELU) ? v[r] * dgelu_f(a[r]) : (a[r] > 0.f ? v[r] : 0.f);
+            }
+            if (res) {
+                if (full) { f32x4 rr = load4(res + (int64_t)mr * p.ldr + n); v += rr; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += to_f32(res[(int64_t)mr * p.ldr + n + r]);
+                }
+            }
+            if (p.c_f32) {
+                float* C = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+                if (full) {
+                    if (p.beta != 0.f) { f32x4 o = *reinterpret_cast<f32x4*>(C); v += p.beta * o; }
+                    *reinterpret_cast<f32x4*>(C) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) C[r] = v[r] + (p.beta != 0.f ? p.beta * C[r] : 0.f);
+                }
+            } else {
+                T* C = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
+                if (full) store4(C, v);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) C[r] = from_f32<T>(v[r]);
+                }
+            }
+        }
+    }
+}
+
+// C[i] = beta*C[i] + sum_s ws[s][i]   (fixed summation order -> bitwise reproducible)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
+                                     int splits, float beta) {
+    int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * total + i];
+        int m = (int)(i / N), n = (int)(i % N);
+        float* c = C + (int64_t)m * ldc + n;
+        *c = s + (beta != 0.f ? beta * *c : 0.f);
+    }
+}
+
+template <typename T, bool VEC>
+int launch(const GemmP& p, int ta, int tb, hipStream_t st) {
+    dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(NTHREADS);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, VEC>), grid, block, 0, st, p);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, VEC>), grid, block, 0, st, p);
+    else if (ta && tb) hipLaunchKernelGGL((gemm_kernel<T, true, true, VEC>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<T, true, false, VEC>), grid, block, 0, st, p);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t devias_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
+    return split_k > 1 ? (int64_t)split_k * M * N * 4 : 0;
+}
+
+extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(a && a->A && a->B && a->C, "devias_gemm: null operand");
+    DEVIAS_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "devias_gemm: bad dims M=%d N=%d K=%d", a->M, a->N, a->K);
+    DEVIAS_REQUIRE(a->dtype == DEVIAS_F32 || a->dtype == DEVIAS_BF16, "devias_gemm: bad dtype %d", a->dtype);
+    DEVIAS_REQUIRE(a->act >= 0 && a->act <= DEVIAS_ACT_DRELU, "devias_gemm: bad act %d", a->act);
+    if (a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU)
+        DEVIAS_REQUIRE(a->aux_in, "devias_gemm: act %d needs aux_in", a->act);
+    const int es = a->dtype == DEVIAS_BF16 ? 2 : 4;
+    const int ch = 16 / es;
+    GemmP p;
+    p.A = a->A; p.B = a->B; p.C = a->C;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
+    p.bias = a->bias; p.act = a->act; p.aux_in = a->aux_in; p.aux_out = a->aux_out; p.ld_aux = a->ld_aux;
+    p.res = a->res; p.ldr = a->ldr; p.res_mod = a->res_mod;
+    p.c_f32 = (a->c_f32 || a->dtype == DEVIAS_F32) ? 1 : 0;
+    p.beta = p.c_f32 ? a->beta : 0.f;
+    p.tiles_m = cdiv(a->M, BM); p.tiles_n = cdiv(a->N, BN);
+    const int BK = a->dtype == DEVIAS_BF16 ? 64 : 16;
+    int split = a->split_k > 1 ? a->split_k : 1;
+    if (split > 1) {
+        DEVIAS_REQUIRE(p.c_f32 && !a->bias && a->act == DEVIAS_ACT_NONE && !a->res && a->ws,
+                       "devias_gemm: split_k needs fp32 C, a workspace and no bias/act/res epilogue");
+        int kps = cdiv(cdiv(a->K, split), BK) * BK;
+        split = cdiv(a->K, kps);
+        p.k_per_split = kps;
+    } else {
+        p.k_per_split = a->K;
+    }
+    p.split_k = split; p.ws = a->ws;
+    // vector (16-byte) staging needs aligned bases / leading dims and whole chunks along the contiguous dim
+    bool vec = aligned16(a->A) && aligned16(a->B) && (a->lda % ch == 0) && (a->ldb % ch == 0);
+    vec = vec && (a->trans_a ? (a->M % ch == 0) : (a->K % ch == 0));
+    vec = vec && (a->trans_b ? (a->N % ch == 0) : (a->K % ch == 0));
+    // 4-wide epilogue accesses
+    bool vc = (a->N % 4 == 0) && (a->ldc % 4 == 0) && (p.c_f32 ? aligned16(a->C) : aligned8(a->C));
+    if (a->bias) vc = vc && aligned16(a->bias);
+    if (a->res) vc = vc && (a->ldr % 4 == 0) && aligned8(a->res);
+    if (a->aux_in) vc = vc && (a->ld_aux % 4 == 0) && aligned8(a->aux_in);
+    if (a->aux_out) vc = vc && (a->ld_aux % 4 == 0) && aligned8(a->aux_out);
+    if (es == 4) vc = vc && (!a->res || aligned16(a->res)) && (!a->aux_in || aligned16(a->aux_in)) &&
+                      (!a->aux_out || aligned16(a->aux_out)) && aligned16(a->C);
+    p.vec_c = vc ? 1 : 0;
+
+    if (a->dtype == DEVIAS_BF16) {
+        if (vec) launch<bf16, true>(p, a->trans_a, a->trans_b, st);
+        else launch<bf16, false>(p, a->trans_a, a->trans_b, st);
+    } else {
+        if (vec) launch<float, true>(p, a->trans_a, a->trans_b, st);
+        else launch<float, false>(p, a->trans_a, a->trans_b, st);
+    }
+    DEVIAS_CHECK_LAUNCH("devias_gemm");
+    if (split > 1) {
+        int64_t total = (int64_t)a->M * a->N;
+        int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, (float*)a->C, a->M, a->N, a->ldc,
+                           split, a->beta);
+        DEVIAS_CHECK_LAUNCH("devias_gemm(split-k reduce)");
+    }
+    return DEVIAS_OK;
+}

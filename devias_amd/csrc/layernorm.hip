@@ -1,0 +1,222 @@
+// LayerNorm forward / backward for gfx950.  One wave (64 lanes) per row, 4 elements per lane per step, the
+// whole row held in registers (D <= 4096, D % 4 == 0), fp32 statistics with a two-pass (mean, then centred
+// variance) reduction done by wave shuffles.  HBM-bound: x is read once, y written once.
+// Backward fuses (a) dx, (b) the optional residual-branch gradient add and (c) the per-workgroup partial
+// column sums for dgamma/dbeta; a second tiny kernel reduces those partials in a fixed order.
+#include "common.h"
+
+namespace {
+
+enum { LN_WAVES = 4, LN_MAXIT = 16, LNB_ROWS = 64 };   // backward: rows per workgroup (16 per wave)
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * LN_WAVES + wave;
+    if (row >= M) return;
+    const T* xr = x + (int64_t)row * D;
+    f32x4 v[NIT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int c = (it * 64 + lane) * 4;
+        if (c < D) { v[it] = load4(xr + c); s += v[it][0] + v[it][1] + v[it][2] + v[it][3]; }
+        else v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int c = (it * 64 + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float d = v[it][j] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    T* yr = y + (int64_t)row * D;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int c = (it * 64 + lane) * 4;
+        if (c < D) {
+            f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[it][j] - mu) * rs * g[j] + b[j];
+            store4(yr + c, o);
+        }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// backward: workgroup = 4 waves, each wave walks LNB_ROWS/4 rows; lane-owned columns are fixed so the
+// dgamma/dbeta partial sums live in registers and are combined across the 4 waves through LDS at the end.
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ part, int M, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [3 waves][2][NIT*256]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 g[NIT], dg[NIT], db[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int c = (it * 64 + lane) * 4;
+        g[it] = c < D ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dg[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int r0 = blockIdx.x * LNB_ROWS;
+    for (int rr = wave; rr < LNB_ROWS; rr += LN_WAVES) {
+        const int row = r0 + rr;
+        if (row >= M) break;
+        const float mu = mean[row], rs = rstd[row];
+        const T* dyr = dy + (int64_t)row * D;
+        const T* xr = x + (int64_t)row * D;
+        f32x4 a[NIT], xh[NIT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = (it * 64 + lane) * 4;
+            if (c < D) {
+                f32x4 d = load4(dyr + c);
+                f32x4 xv = load4(xr + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float h = (xv[j] - mu) * rs;
+                    xh[it][j] = h;
+                    dg[it][j] += d[j] * h;
+                    db[it][j] += d[j];
+                    float aj = d[j] * g[it][j];
+                    a[it][j] = aj;
+                    s1 += aj; s2 += aj * h;
+                }
+            } else { a[it] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[it] = a[it]; }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+        T* dxr = dx + (int64_t)row * D;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = (it * 64 + lane) * 4;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rs * (a[it][j] - m1 - xh[it][j] * m2);
+                if (dres) o += load4(dres + (int64_t)row * D + c);
+                store4(dxr + c, o);
+            }
+        }
+    }
+    // combine the 4 waves' partials -> part[blockIdx][2][D]
+    const int W = NIT * 256;
+    if (wave > 0) {
+        float* dst = sm + (size_t)(wave - 1) * 2 * W;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = (it * 64 + lane) * 4;
+            *reinterpret_cast<f32x4*>(dst + c) = dg[it];
+            *reinterpret_cast<f32x4*>(dst + W + c) = db[it];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = part + (int64_t)blockIdx.x * 2 * D;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = (it * 64 + lane) * 4;
+            if (c < D) {
+                f32x4 a = dg[it], b = db[it];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    a += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 2 * W + c);
+                    b += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 2 * W + W + c);
+                }
+                *reinterpret_cast<f32x4*>(out + c) = a;
+                *reinterpret_cast<f32x4*>(out + D + c) = b;
+            }
+        }
+    }
+}
+
+// out[i] (i over 2*D: dgamma | dbeta) = beta_acc*out[i] + sum_p part[p][i]; block (64 columns, 16 partial lanes), fixed order
+__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int D, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float beta_acc) {
+    __shared__ float sm[16][64];
+    int i = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.f;
+    if (i < 2 * D)
+        for (int p = threadIdx.y; p < nparts; p += 16) s += part[(int64_t)p * 2 * D + i];
+    sm[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && i < 2 * D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][threadIdx.x];
+        float* dst = i < D ? dgamma + i : dbeta + (i - D);
+        *dst = t + (beta_acc != 0.f ? beta_acc * *dst : 0.f);
+    }
+}
+
+template <typename T>
+int ln_fwd_dispatch(const T* x, const float* g, const float* b, T* y, float* mean, float* rstd, int M, int D, float eps,
+                    hipStream_t st) {
+    dim3 grid(cdiv(M, LN_WAVES)), block(256);
+    int nit = cdiv(D, 256);
+#define LNF(N) hipLaunchKernelGGL((ln_fwd_kernel<T, N>), grid, block, 0, st, x, g, b, y, mean, rstd, M, D, eps)
+    if (nit <= 2) LNF(2); else if (nit <= 3) LNF(3); else if (nit <= 4) LNF(4); else if (nit <= 8) LNF(8); else LNF(16);
+#undef LNF
+    return 0;
+}
+template <typename T>
+int ln_bwd_dispatch(const T* dy, const T* x, const float* g, const float* mean, const float* rstd, const T* dres, T* dx,
+                    float* part, int M, int D, hipStream_t st) {
+    dim3 grid(cdiv(M, LNB_ROWS)), block(256);
+    int nit = cdiv(D, 256);
+#define LNB(N) hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 3 * 2 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D)
+    if (nit <= 2) LNB(2); else if (nit <= 3) LNB(3); else if (nit <= 4) LNB(4); else LNB(8);
+#undef LNB
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int devias_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                    float* rstd, int32_t M, int32_t D, float eps, int32_t dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(x && gamma && beta && y && mean && rstd, "devias_layernorm_fwd: null pointer");
+    DEVIAS_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "devias_layernorm_fwd: need D %% 4 == 0 and D <= 4096 (D=%d)", D);
+    DEVIAS_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "devias_layernorm_fwd: unaligned pointer");
+    if (dtype == DEVIAS_BF16) ln_fwd_dispatch<bf16>((const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, eps, st);
+    else if (dtype == DEVIAS_F32) ln_fwd_dispatch<float>((const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps, st);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_layernorm_fwd: bad dtype %d", dtype);
+    DEVIAS_CHECK_LAUNCH("devias_layernorm_fwd");
+    return DEVIAS_OK;
+}
+
+extern "C" int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
+    return (int64_t)cdiv(M, LNB_ROWS) * 2 * D * 4;
+}
+
+extern "C" int devias_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                    const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                    float beta_acc, int32_t M, int32_t D, int32_t dtype, float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, "devias_layernorm_bwd: null pointer");
+    DEVIAS_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "devias_layernorm_bwd: need D %% 4 == 0 and D <= 2048 (D=%d)", D);
+    DEVIAS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dres || aligned16(dres)) && aligned16(ws),
+                   "devias_layernorm_bwd: unaligned pointer");
+    if (dtype == DEVIAS_BF16)
+        ln_bwd_dispatch<bf16>((const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, ws, M, D, st);
+    else if (dtype == DEVIAS_F32)
+        ln_bwd_dispatch<float>((const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, ws, M, D, st);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_layernorm_bwd: bad dtype %d", dtype);
+    DEVIAS_CHECK_LAUNCH("devias_layernorm_bwd");
+    int nparts = cdiv(M, LNB_ROWS);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64)), dim3(64, 16), 0, st, ws, nparts, D, dgamma, dbeta, beta_acc);
+    DEVIAS_CHECK_LAUNCH("devias_layernorm_bwd(param reduce)");
+    return DEVIAS_OK;
+}

@@ -1,0 +1,335 @@
+"""Tensor-level wrappers over the C ABI (include/devias_amd.h).  PyTorch supplies device memory and the current
+HIP stream; every bit of arithmetic happens in libdevias_amd.so.  No function here has a CPU or eager fallback."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32  # noqa: F401
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_workspaces = {}
+
+
+def dt_code(t: torch.dtype) -> int:
+    try:
+        return _DT[t]
+    except KeyError:
+        raise TypeError(f"devias_amd kernels support float32 and bfloat16 tensors, got {t}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: devias_amd kernels need a GPU tensor (HIP extension only; no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous, got strides {t.stride()}")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only fp32 scratch buffer per device; safe because all kernels of a step are ordered on one stream."""
+    key = (torch.device(device).index or 0)
+    n = (int(nbytes) + 3) // 4
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def device_info(device: int = 0):
+    out = (ctypes.c_int64 * 5)()
+    _lib.check(_lib.load().devias_device_info(device, out), "devias_device_info")
+    return {"cus": out[0], "clock_khz": out[1], "lds_per_block": out[2], "wave": out[3], "gfx": out[4]}
+
+
+def auto_split_k(M: int, N: int, K: int, target_blocks: int = 768, bk: int = 64) -> int:
+    """Split the reduction of a weight-gradient GEMM so that tiles x splits fills the chip (256 CUs x ~3 workgroups)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= target_blocks or K < 8 * bk:
+        return 1
+    s = min((target_blocks + tiles - 1) // tiles, K // (4 * bk), 64)
+    return max(1, s)
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
+         bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux_in: Optional[torch.Tensor] = None,
+         aux_out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, res_mod: int = 0,
+         out: Optional[torch.Tensor] = None, out_f32: bool = False, beta: float = 0.0, split_k: int = 1) -> torch.Tensor:
+    """C[M,N] = epilogue(op(A) @ op(B)); see devias_gemm in include/devias_amd.h.
+    A: [M,K] (or [K,M] if trans_a); B: [N,K] nn.Linear layout (or [K,N] if trans_b)."""
+    _chk(A, "gemm.A"); _chk(B, "gemm.B", A.dtype)
+    assert A.dim() == 2 and B.dim() == 2
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    N, Kb = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if K != Kb:
+        raise ValueError(f"gemm: reduction mismatch {K} vs {Kb}")
+    cdt = torch.float32 if out_f32 else A.dtype
+    if out is None:
+        if beta != 0.0:
+            raise ValueError("gemm: beta needs an existing `out`")
+        out = torch.empty((M, N), dtype=cdt, device=A.device)
+    else:
+        _chk(out, "gemm.out", cdt)
+        assert out.shape == (M, N)
+    a = _lib.GemmArgs()
+    a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldb, a.ldc = A.shape[1], B.shape[1], N
+    a.trans_a, a.trans_b = int(trans_a), int(trans_b)
+    a.dtype = dt_code(A.dtype)
+    a.c_f32 = int(cdt == torch.float32)
+    a.bias = _p(_chk(bias, "gemm.bias", torch.float32)) if bias is not None else None
+    a.act = act
+    a.ld_aux = N
+    if aux_in is not None:
+        _chk(aux_in, "gemm.aux_in", A.dtype); assert aux_in.shape == (M, N)
+        a.aux_in = aux_in.data_ptr()
+    if aux_out is not None:
+        _chk(aux_out, "gemm.aux_out", A.dtype); assert aux_out.shape == (M, N)
+        a.aux_out = aux_out.data_ptr()
+    if res is not None:
+        _chk(res, "gemm.res", A.dtype)
+        assert res.shape[-1] == N and res.numel() // N == (res_mod if res_mod > 0 else M)
+        a.res, a.ldr, a.res_mod = res.data_ptr(), N, res_mod
+    a.beta = beta
+    a.split_k = split_k
+    if split_k > 1:
+        nbytes = _lib.load().devias_gemm_workspace_bytes(M, N, split_k)
+        a.ws = workspace(nbytes, A.device).data_ptr()
+    _lib.check(_lib.load().devias_gemm(ctypes.byref(a), _stream()), "devias_gemm")
+    return out
+
+
+def wgrad(dY: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
+    """dW[N,K] (fp32) = dY[M,N]^T @ X[M,K]   (weight gradient of Y = X W^T); split-K over the long M reduction."""
+    M, N = dY.shape
+    K = X.shape[1]
+    sk = auto_split_k(N, K, M, bk=64 if dY.dtype == torch.bfloat16 else 16)
+    return gemm(dY, X, trans_a=True, trans_b=True, out=out, out_f32=True, beta=beta, split_k=sk)
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(src, "cast.src")
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _chk(out, "cast.out", dtype)
+    _lib.check(_lib.load().devias_cast(src.data_ptr(), dt_code(src.dtype), out.data_ptr(), dt_code(dtype), src.numel(), _stream()),
+               "devias_cast")
+    return out
+
+
+def patch_im2col(x: torch.Tensor, tubelet: int, patch: int, dtype: torch.dtype) -> torch.Tensor:
+    _chk(x, "patch_im2col.x")
+    B, C, T, H, W = x.shape
+    n_tok = (T // tubelet) * (H // patch) * (W // patch)
+    out = torch.empty((B * n_tok, C * tubelet * patch * patch), dtype=dtype, device=x.device)
+    _lib.check(_lib.load().devias_patch_im2col(x.data_ptr(), dt_code(x.dtype), out.data_ptr(), dt_code(dtype), B, C, T, H, W,
+                                               tubelet, patch, _stream()), "devias_patch_im2col")
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
+    _chk(x, "colsum.x")
+    M, N = x.shape
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    ws = workspace(_lib.load().devias_colsum_workspace_bytes(M, N), x.device)
+    _lib.check(_lib.load().devias_colsum(x.data_ptr(), dt_code(x.dtype), M, N, N, out.data_ptr(), beta, ws.data_ptr(), _stream()),
+               "devias_colsum")
+    return out
+
+
+def rows_reduce_mod(x: torch.Tensor, mod: int) -> torch.Tensor:
+    _chk(x, "rows_reduce_mod.x")
+    M, N = x.shape
+    out = torch.empty((mod, N), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().devias_rows_reduce_mod(x.data_ptr(), dt_code(x.dtype), M, N, mod, out.data_ptr(), _stream()),
+               "devias_rows_reduce_mod")
+    return out
+
+
+def rows_broadcast(src: torch.Tensor, M: int, dtype: torch.dtype) -> torch.Tensor:
+    _chk(src, "rows_broadcast.src", torch.float32)
+    mod, N = src.shape
+    out = torch.empty((M, N), dtype=dtype, device=src.device)
+    _lib.check(_lib.load().devias_rows_broadcast(src.data_ptr(), mod, N, out.data_ptr(), dt_code(dtype), M, _stream()),
+               "devias_rows_broadcast")
+    return out
+
+
+def act_bwd(dy: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
+    _chk(dy, "act_bwd.dy"); _chk(y, "act_bwd.y", dy.dtype)
+    dx = torch.empty_like(dy)
+    _lib.check(_lib.load().devias_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), act, dt_code(dy.dtype), dy.numel(), _stream()),
+               "devias_act_bwd")
+    return dx
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _chk(a, "add.a"); _chk(b, "add.b", a.dtype)
+    y = torch.empty_like(a)
+    _lib.check(_lib.load().devias_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), dt_code(a.dtype), a.numel(), _stream()), "devias_add")
+    return y
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    _chk(x, "layernorm_fwd.x"); _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
+    M, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().devias_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                rstd.data_ptr(), M, D, eps, dt_code(x.dtype), _stream()), "devias_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, beta_acc: float = 0.0):
+    _chk(dy, "layernorm_bwd.dy"); _chk(x, "layernorm_bwd.x", dy.dtype)
+    M, D = x.shape
+    dx = torch.empty_like(x)
+    if dgamma is None:
+        assert beta_acc == 0.0
+        dgamma = torch.empty((D,), dtype=torch.float32, device=x.device)
+        dbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
+    if dres is not None:
+        _chk(dres, "layernorm_bwd.dres", dy.dtype)
+    ws = workspace(_lib.load().devias_layernorm_bwd_workspace_bytes(M, D), x.device)
+    _lib.check(_lib.load().devias_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                _p(dres), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), beta_acc, M, D,
+                                                dt_code(x.dtype), ws.data_ptr(), _stream()), "devias_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float):
+    _chk(qkv, "mhsa_fwd.qkv")
+    assert qkv.numel() == B * N * 3 * H * 64, "mhsa: head dim must be 64"
+    o = torch.empty((B * N, H * 64), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().devias_mhsa_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), _stream()),
+               "devias_mhsa_fwd")
+    return o, lse
+
+
+def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float):
+    _chk(qkv, "mhsa_bwd.qkv"); _chk(o, "mhsa_bwd.o", qkv.dtype); _chk(d_o, "mhsa_bwd.d_o", qkv.dtype)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().devias_mhsa_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                           dqkv.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), _stream()), "devias_mhsa_bwd")
+    return dqkv
+
+
+def slot_attn_fwd(q, kv, B, S, N, h, dh, scale, attn_out=None, rsum_out=None):
+    _chk(q, "slot_attn_fwd.q"); _chk(kv, "slot_attn_fwd.kv", q.dtype)
+    dev = q.device
+    attn = attn_out if attn_out is not None else torch.empty((B * h, S, N), dtype=torch.float32, device=dev)
+    rsum = rsum_out if rsum_out is not None else torch.empty((B * h, S), dtype=torch.float32, device=dev)
+    o = torch.empty((B * S, h * dh), dtype=q.dtype, device=dev)
+    ws = workspace(_lib.load().devias_slot_attn_workspace_bytes(B, S, N, h, dh), dev)
+    _lib.check(_lib.load().devias_slot_attn_fwd(q.data_ptr(), kv.data_ptr(), attn.data_ptr(), rsum.data_ptr(), o.data_ptr(), B, S, N,
+                                                h, dh, scale, dt_code(q.dtype), ws.data_ptr(), _stream()), "devias_slot_attn_fwd")
+    return attn, rsum, o
+
+
+def slot_attn_bwd(q, kv, attn, rsum, o, d_o, d_attn_ext, B, S, N, h, dh, scale, ds_out=None):
+    dev = q.device
+    _chk(d_o, "slot_attn_bwd.d_o", q.dtype)
+    dq = torch.empty_like(q)
+    ds = ds_out if ds_out is not None else torch.empty((B * h, S, N), dtype=torch.float32, device=dev)
+    if d_attn_ext is not None:
+        _chk(d_attn_ext, "slot_attn_bwd.d_attn_ext", torch.float32)
+    ws = workspace(_lib.load().devias_slot_attn_workspace_bytes(B, S, N, h, dh), dev)
+    _lib.check(_lib.load().devias_slot_attn_bwd(q.data_ptr(), kv.data_ptr(), attn.data_ptr(), rsum.data_ptr(), o.data_ptr(),
+                                                d_o.data_ptr(), _p(d_attn_ext), dq.data_ptr(), ds.data_ptr(), B, S, N, h, dh, scale,
+                                                dt_code(q.dtype), ws.data_ptr(), _stream()), "devias_slot_attn_bwd")
+    return dq, ds
+
+
+def slot_attn_kv_grad(q_stack, do_stack, ds_stack, attn_stack, rsum_stack, L, B, S, N, h, dh, scale):
+    for t, n in ((q_stack, "q_stack"), (do_stack, "do_stack"), (ds_stack, "ds_stack"), (attn_stack, "attn_stack"),
+                 (rsum_stack, "rsum_stack")):
+        _chk(t, "slot_attn_kv_grad." + n)
+    dkv = torch.empty((B * N, 2 * h * dh), dtype=q_stack.dtype, device=q_stack.device)
+    _lib.check(_lib.load().devias_slot_attn_kv_grad(q_stack.data_ptr(), do_stack.data_ptr(), ds_stack.data_ptr(), attn_stack.data_ptr(),
+                                                    rsum_stack.data_ptr(), dkv.data_ptr(), L, B, S, N, h, dh, scale,
+                                                    dt_code(q_stack.dtype), _stream()), "devias_slot_attn_kv_grad")
+    return dkv
+
+
+def slot_select(slots_head: torch.Tensor, B: int, S: int, nb: int) -> torch.Tensor:
+    _chk(slots_head, "slot_select.slots_head")
+    C = slots_head.shape[-1]
+    idx = torch.empty((B, 2), dtype=torch.int32, device=slots_head.device)
+    _lib.check(_lib.load().devias_slot_select(slots_head.data_ptr(), dt_code(slots_head.dtype), B, S, C, nb, idx.data_ptr(), _stream()),
+               "devias_slot_select")
+    return idx
+
+
+def _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_md):
+    d = _lib.LossDims()
+    d.B = B
+    d.S = slots_head.shape[0] // B
+    d.C = slots_head.shape[1]
+    d.nb, d.ns = nb, teacher.shape[1]
+    d.D, d.G, d.N = slots.shape[1], maskp.shape[1], attn.shape[2]
+    d.nh = attn.shape[0] // B
+    d.w_scene, d.w_mask_pred, d.w_mask_distill = w_scene, w_mp, w_md
+    d.dtype = dt_code(slots_head.dtype)
+    return d
+
+
+def head_match_loss_fwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN, nb, w_scene, w_mp, w_md):
+    B = target.shape[0]
+    for t, n, dt in ((slots_head, "slots_head", None), (slots, "slots", slots_head.dtype), (maskp, "maskp", slots_head.dtype),
+                     (attn, "attn", torch.float32), (teacher, "teacher", torch.float32), (target, "target", torch.int64),
+                     (fg, "fg", torch.float32), (fgN, "fgN", torch.float32)):
+        _chk(t, "head_match_loss_fwd." + n, dt)
+    d = _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_md)
+    dev = slots_head.device
+    losses = torch.empty((6,), dtype=torch.float32, device=dev)
+    match = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    logits = torch.empty((B, d.C), dtype=slots_head.dtype, device=dev)
+    ws = workspace(_lib.load().devias_head_match_loss_workspace_bytes(B), dev)
+    _lib.check(_lib.load().devias_head_match_loss_fwd(ctypes.byref(d), slots_head.data_ptr(), slots.data_ptr(), maskp.data_ptr(),
+                                                      attn.data_ptr(), teacher.data_ptr(), target.data_ptr(), fg.data_ptr(),
+                                                      fgN.data_ptr(), losses.data_ptr(), match.data_ptr(), logits.data_ptr(),
+                                                      ws.data_ptr(), _stream()), "devias_head_match_loss_fwd")
+    return losses, match, logits
+
+
+def head_match_loss_bwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN, match, g_total, nb, w_scene, w_mp, w_md):
+    B = target.shape[0]
+    _chk(g_total, "head_match_loss_bwd.g_total", torch.float32)
+    d = _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_md)
+    dZ = torch.empty_like(slots_head)
+    dslots = torch.empty_like(slots)
+    dmask = torch.empty_like(maskp)
+    dattn = torch.empty_like(attn)
+    _lib.check(_lib.load().devias_head_match_loss_bwd(ctypes.byref(d), slots_head.data_ptr(), slots.data_ptr(), maskp.data_ptr(),
+                                                      attn.data_ptr(), teacher.data_ptr(), target.data_ptr(), fg.data_ptr(),
+                                                      fgN.data_ptr(), match.data_ptr(), g_total.data_ptr(), dZ.data_ptr(),
+                                                      dslots.data_ptr(), dmask.data_ptr(), dattn.data_ptr(), _stream()),
+               "devias_head_match_loss_bwd")
+    return dZ, dslots, dmask, dattn
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, "adamw_step." + n, torch.float32)
+    _lib.check(_lib.load().devias_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(),
+                                             lr, beta1, beta2, eps, weight_decay, step, grad_scale, _stream()), "devias_adamw_step")

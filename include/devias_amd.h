@@ -1,0 +1,205 @@
+/*
+ * devias_amd.h -- C ABI of libdevias_amd.so: hand-written gfx950 (MI355X / CDNA4) HIP kernels for the
+ * DEVIAS slot-ViT training step.
+ *
+ * The reference (KHU-VLL/DEVIAS) is pure Python on PyTorch: it has no FFI of its own.  The "binding" for
+ * this path is therefore the set of ATen ops its modules dispatch to; every entry point below names the
+ * reference code (file:line, relative to the reference root) whose arithmetic it replaces.  The Python
+ * host (the devias_amd Python package) mirrors the reference's timm-style module surface and reaches these symbols
+ * through ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch / STL types cross the boundary.
+ *   - every pointer is DEVICE memory owned by the caller (PyTorch's caching allocator), including
+ *     workspaces; the library allocates nothing.
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (no device sync).
+ *   - return 0 on success, <0 on error (DEVIAS_E*); devias_last_error() gives a thread-local message.
+ *   - dtype codes: DEVIAS_F32 = 0, DEVIAS_BF16 = 1.  "T" below means the activation dtype of the call.
+ *     Accumulation, softmax / LayerNorm statistics, losses and weight gradients are always fp32.
+ *   - one process per GPU (as the reference: torchrun, utils/utils.py:251-277); calls are re-entrant.
+ */
+#ifndef DEVIAS_AMD_H
+#define DEVIAS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEVIAS_OK 0
+#define DEVIAS_EINVAL (-1)
+#define DEVIAS_ELAUNCH (-2)
+#define DEVIAS_EUNSUPPORTED (-3)
+
+#define DEVIAS_F32 0
+#define DEVIAS_BF16 1
+
+/* epilogue activation codes for devias_gemm */
+#define DEVIAS_ACT_NONE 0
+#define DEVIAS_ACT_GELU 1      /* exact erf GELU (nn.GELU(), modeling_slot.py:55,63); pre-activation -> aux_out */
+#define DEVIAS_ACT_RELU 2      /* MaskPredictor ReLU, modeling_slot.py:200-202 */
+#define DEVIAS_ACT_SIGMOID 3   /* MaskPredictor Sigmoid, modeling_slot.py:204 */
+#define DEVIAS_ACT_DGELU 4     /* backward: v *= gelu'(aux_in) with aux_in = saved pre-activation */
+#define DEVIAS_ACT_DRELU 5     /* backward: v = aux_in > 0 ? v : 0 with aux_in = saved ReLU output */
+
+int devias_version(void);
+const char* devias_last_error(void);
+/* fills: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes per block, [3]=wavefront size, [4]=gfx arch number (e.g. 950) */
+int devias_device_info(int device, int64_t* out5);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Generic fused GEMM:  C[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] )
+ *   trans_a = 0: A is [M,K] row-major (lda = row stride);  1: A is stored [K,M] (reduction-major)
+ *   trans_b = 0: B is [N,K] row-major -- the nn.Linear weight layout;  1: B is stored [K,N]
+ *   epilogue order: +bias[n] -> act (GELU stores the pre-activation to aux_out first) -> +res[(m % res_mod or m), n]
+ *   c_f32 = 1 with T = bf16 writes C (and reads it under beta) as fp32: weight-gradient GEMMs.
+ *   split_k > 1 (requires c_f32 or T=f32, no bias/act/res): partial sums go to `ws`
+ *     (split_k * M * N floats) and a second kernel reduces them deterministically: C = beta*C + sum.
+ * Replaces: F.linear / nn.Linear forward, its dgrad and wgrad ATen kernels (mm / addmm) at
+ *   modeling_slot.py:60-67 (Mlp), :97-101 (qkv), :113 (proj), :167-177 (Conv3d patch embed as GEMM), :302/:393 (head),
+ *   :199-204 (MaskPredictor), agg_block/attention.py:66-72 (FeedForward), :108-115,123-126,141 (to_q/to_k/to_v/to_out).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* A; const void* B; void* C;
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc;
+    int32_t trans_a, trans_b;
+    int32_t dtype;            /* DEVIAS_F32 | DEVIAS_BF16 : type of A, B, res, aux and (unless c_f32) C */
+    int32_t c_f32;
+    const float* bias;        /* [N] fp32 or NULL */
+    int32_t act;              /* DEVIAS_ACT_* */
+    const void* aux_in;       /* T [M,N], row stride ld_aux (DGELU / DRELU) */
+    void* aux_out;            /* T [M,N], row stride ld_aux (GELU pre-activation) or NULL */
+    int32_t ld_aux;
+    const void* res;          /* T [*,N] residual, row stride ldr, or NULL */
+    int32_t ldr, res_mod;     /* res_mod > 0: residual row = m % res_mod (positional table broadcast) */
+    float beta;               /* C = acc + beta*C; only honoured for fp32 C */
+    int32_t split_k;          /* >= 1 */
+    float* ws;                /* split-K workspace or NULL */
+} devias_gemm_args;
+int devias_gemm(const devias_gemm_args* args, void* stream);
+/* bytes of workspace devias_gemm needs for the given split_k (0 when split_k <= 1) */
+int64_t devias_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Element-wise / data-movement helpers
+ * ------------------------------------------------------------------------------------------------- */
+/* dst[i] = (T_dst) src[i]; dtype codes as above. Used for the per-step bf16 weight copies and video input. */
+int devias_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream);
+/* Tubelet im2col for PatchEmbed (nn.Conv3d k=s=(ts,ps,ps), modeling_slot.py:167-177; layout SURVEY.md §9):
+ *   out[(b*Np + (t'*g + h')*g + w'), ((c*ts + kt)*ps + kh)*ps + kw] = x[b, c, ts*t'+kt, ps*h'+kh, ps*w'+kw]
+ * x is [B,C,T,H,W] of dtype x_dtype, out is [B*Np, C*ts*ps*ps] of dtype out_dtype. */
+int devias_patch_im2col(const void* x, int32_t x_dtype, void* out, int32_t out_dtype,
+                        int32_t B, int32_t C, int32_t T, int32_t H, int32_t W, int32_t ts, int32_t ps, void* stream);
+/* out[n] = beta*out[n] + sum_m x[m, n]  (bias gradients). x is T [M,N] row stride ldx, out fp32 [N].
+ * ws: >= devias_colsum_workspace_bytes(M,N) bytes. */
+int devias_colsum(const void* x, int32_t dtype, int32_t M, int32_t N, int32_t ldx, float* out, float beta,
+                  float* ws, void* stream);
+int64_t devias_colsum_workspace_bytes(int32_t M, int32_t N);
+/* out[r % mod, n] (fp32 [mod,N]) = sum over rows r of x[r, n]  -- gradient of a row-broadcast (latents repeat over batch,
+ * agg_block/agg_block.py:112-114).  Small inputs only (M*N <= 2^24). */
+int devias_rows_reduce_mod(const void* x, int32_t dtype, int32_t M, int32_t N, int32_t mod, float* out, void* stream);
+/* out[r, :] = (T) src[r % mod, :]  (src fp32 [mod,N]) */
+int devias_rows_broadcast(const float* src, int32_t mod, int32_t N, void* out, int32_t dtype, int32_t M, void* stream);
+/* dx = dy * f'(.) element-wise (T, n elements): act = DEVIAS_ACT_SIGMOID / DEVIAS_ACT_RELU take y = f(x) (the saved OUTPUT),
+ * DEVIAS_ACT_GELU takes the saved pre-activation x. */
+int devias_act_bwd(const void* dy, const void* y_or_x, void* dx, int32_t act, int32_t dtype, int64_t n, void* stream);
+/* y = a + b (same dtype T, n elements); used for gradient fan-in of the residual stream */
+int devias_add(const void* a, const void* b, void* y, int32_t dtype, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (nn.LayerNorm: modeling_slot.py:126,131,297 eps 1e-6; agg_block/attention.py:29-30,
+ * agg_block/agg_block.py:105-107 eps 1e-5).  x,y: T [M,D]; gamma,beta fp32 [D]; mean,rstd fp32 [M] (saved for backward).
+ * backward: dx = LN'(dy) (+ dres if dres != NULL, fusing the residual-branch gradient add);
+ *           dgamma/dbeta (fp32 [D]) = beta_acc * old + column sums; ws >= devias_layernorm_bwd_workspace_bytes.
+ * ------------------------------------------------------------------------------------------------- */
+int devias_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                         int32_t M, int32_t D, float eps, int32_t dtype, void* stream);
+int devias_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                         const void* dres, void* dx, float* dgamma, float* dbeta, float beta_acc,
+                         int32_t M, int32_t D, int32_t dtype, float* ws, void* stream);
+int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Encoder multi-head self-attention core (Attention.forward, modeling_slot.py:102-112): non-causal, no mask,
+ * head dim 64.  qkv: T [B,N,3,H,64] exactly as F.linear produces it (:101-102, no permute copy); o: T [B,N,H*64];
+ * lse: fp32 [B,H,N] = log sum_j exp(scale * q.k_j).  The N x N score matrix is never materialised.
+ * backward: dqkv T [B,N,3,H,64]; delta fp32 [B,H,N] scratch (rowsum(dO*O)).
+ * ------------------------------------------------------------------------------------------------- */
+int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
+                    int32_t dtype, void* stream);
+int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                    int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Slot cross-attention core (agg_block/attention.py:128-140): heads h, head dim dh (4 x 512 in DEVIAS),
+ * softmax over the SLOT axis (:132) then renormalisation over tokens with +1e-7 (:136).
+ *   q: T [B,S,h*dh]; kv: T [B,N,2,h*dh] (to_k | to_v outputs side by side, row stride 2*h*dh)
+ *   attn: fp32 [B*h,S,N] = the slot-softmax A (the tensor the reference returns as `sim_distill`)
+ *   rsum: fp32 [B*h,S] = sum_j A + 1e-7;  o: T [B,S,h*dh] (heads merged 'b n (h d)')
+ *   ws: fp32 workspace >= devias_slot_attn_workspace_bytes
+ * backward (per layer): d_o T [B,S,h*dh], d_attn_ext fp32 [B*h,S,N] or NULL (gradient arriving on the returned attn),
+ *   -> dq T [B,S,h*dh], ds fp32 [B*h,S,N] (kept for the deferred K/V gradient pass).
+ * kv gradient (once per distinct K/V, i.e. once for weight-tied layers): for L stacked layers
+ *   dK[j] = scale * sum_l sum_i ds_l[i,j] q_l[i],  dV[j] = sum_l sum_i (A_l[i,j]/rsum_l[i]) dO_l[i]
+ *   q_stack,do_stack: T [L,B,S,h*dh]; ds_stack, attn_stack: fp32 [L,B*h,S,N]; rsum_stack fp32 [L,B*h,S]; dkv: T [B,N,2,h*dh]
+ * ------------------------------------------------------------------------------------------------- */
+int devias_slot_attn_fwd(const void* q, const void* kv, float* attn, float* rsum, void* o,
+                         int32_t B, int32_t S, int32_t N, int32_t h, int32_t dh, float scale, int32_t dtype,
+                         float* ws, void* stream);
+int devias_slot_attn_bwd(const void* q, const void* kv, const float* attn, const float* rsum, const void* o,
+                         const void* d_o, const float* d_attn_ext, void* dq, float* ds,
+                         int32_t B, int32_t S, int32_t N, int32_t h, int32_t dh, float scale, int32_t dtype,
+                         float* ws, void* stream);
+int devias_slot_attn_kv_grad(const void* q_stack, const void* do_stack, const float* ds_stack, const float* attn_stack,
+                             const float* rsum_stack, void* dkv, int32_t L, int32_t B, int32_t S, int32_t N,
+                             int32_t h, int32_t dh, float scale, int32_t dtype, void* stream);
+int64_t devias_slot_attn_workspace_bytes(int32_t B, int32_t S, int32_t N, int32_t h, int32_t dh);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Slot selection (modeling_slot.py:395-406): p = softmax(slots_head); i_act[b] = argmax_s max_{c<nb} p[b,s,c];
+ * i_scn[b] = argmax_s max_{nb<=c<nb+ns} p[b,s,c]; idx int32 [B,2].
+ * ------------------------------------------------------------------------------------------------- */
+int devias_slot_select(const void* slots_head, int32_t dtype, int32_t B, int32_t S, int32_t C, int32_t nb,
+                       int32_t* idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * TrainLoss 'matching' branch, scene_criterion 'KL' (utils/loss/train_loss.py:85-187), one launch, no host sync:
+ * per-sample S x 2 assignment (== scipy linear_sum_assignment, :112-122), CE(action), KL to the padded teacher
+ * logits * w_scene ('batchmean' on a 1-D input => /C), mask-distill MSE on the head-mean slot attention,
+ * BCE-with-logits on the (already sigmoided) mask prediction, slot cosine loss.
+ *   slots_head T [B*S,C]; slots T [B*S,D]; maskp T [B*S,G]; attn fp32 [B*nh,S,N]; teacher fp32 [B,ns];
+ *   target int64 [B]; fg fp32 [B,G]; fgN fp32 [B,N]
+ *   out_losses fp32 [6] = {action, scene, cosine, mask_prediction, mask_distill, total}
+ *   out_match int32 [B,2] = (action slot i*, scene slot j*); out_logits T [B,C] = slots_head[b, i*]
+ * backward (g = upstream gradient of `total`, read from device fp32 scalar g_total):
+ *   d_slots_head T [B*S,C]; d_slots T [B*S,D] (cosine term only); d_maskp T [B*S,G]; d_attn fp32 [B*nh,S,N]
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, S, C, nb, ns, D, G, N, nh;
+    float w_scene, w_mask_pred, w_mask_distill;
+    int32_t dtype;
+} devias_loss_dims;
+int devias_head_match_loss_fwd(const devias_loss_dims* d, const void* slots_head, const void* slots, const void* maskp,
+                               const float* attn, const float* teacher, const int64_t* target, const float* fg,
+                               const float* fgN, float* out_losses, int32_t* out_match, void* out_logits,
+                               float* ws, void* stream);
+int devias_head_match_loss_bwd(const devias_loss_dims* d, const void* slots_head, const void* slots, const void* maskp,
+                               const float* attn, const float* teacher, const int64_t* target, const float* fg,
+                               const float* fgN, const int32_t* match, const float* g_total,
+                               void* d_slots_head, void* d_slots, void* d_maskp, float* d_attn, void* stream);
+int64_t devias_head_match_loss_workspace_bytes(int32_t B);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused AdamW over a flat fp32 parameter range (torch.optim.AdamW semantics, utils/optim_factory.py:132-133;
+ * decoupled weight decay, bias correction by step).  grad_scale multiplies the gradient first (1/world, loss scale).
+ * ------------------------------------------------------------------------------------------------- */
+int devias_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                      float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEVIAS_AMD_H */

@@ -1,0 +1,296 @@
+"""Per-kernel parity: every C-ABI entry point against a plain PyTorch fp32 statement of the same op (GPU only).
+fp32 kernels are checked tightly (they carry the reference-parity claim); bf16 kernels are checked against the
+fp32 op evaluated on the bf16-rounded inputs, with a bf16-sized tolerance."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from devias_amd import ops as o
+    return o
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 512), (130, 200, 72), (70, 765, 100), (4, 765, 768), (64, 196, 256), (300, 128, 4)])
+def test_gemm_layouts(dtype, ta, tb, M, N, K):
+    o = ops()
+    A = rnd(*((K, M) if ta else (M, K)), dtype=dtype, seed=1)
+    B = rnd(*((K, N) if tb else (N, K)), dtype=dtype, seed=2)
+    C = o.gemm(A, B, trans_a=ta, trans_b=tb)
+    ref = (A.float().t() if ta else A.float()) @ (B.float() if tb else B.float().t())
+    assert C.dtype == dtype and C.shape == (M, N)
+    assert rel(C.float(), ref) < TOL[dtype] * (4 if dtype == torch.bfloat16 else 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (100, 765, 96)])
+def test_gemm_epilogues(dtype, M, N, K):
+    o = ops()
+    A, W = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, scale=0.2, seed=4)
+    bias = rnd(N, seed=5)
+    res = rnd(M, N, dtype=dtype, seed=6)
+    base = A.float() @ W.float().t() + bias
+    tol = TOL[dtype] * (4 if dtype == torch.bfloat16 else 1)
+    # bias + residual
+    assert rel(o.gemm(A, W, bias=bias, res=res).float(), base + res.float()) < tol
+    # bias + residual broadcast by row modulo (positional table)
+    pos = rnd(10, N, dtype=dtype, seed=7)
+    if M % 10 == 0:
+        ref = base + pos.float().repeat(M // 10, 1)
+        assert rel(o.gemm(A, W, bias=bias, res=pos, res_mod=10).float(), ref) < tol
+    # GELU with the pre-activation saved
+    aux = torch.empty(M, N, dtype=dtype, device=DEV)
+    y = o.gemm(A, W, bias=bias, act=o.ACT_GELU, aux_out=aux)
+    assert rel(aux.float(), base) < tol and rel(y.float(), F.gelu(base)) < tol
+    assert rel(o.gemm(A, W, bias=bias, act=o.ACT_RELU).float(), F.relu(base)) < tol
+    assert rel(o.gemm(A, W, bias=bias, act=o.ACT_SIGMOID).float(), torch.sigmoid(base)) < tol
+    # backward epilogues
+    pre = rnd(M, N, dtype=dtype, seed=8)
+    xg = pre.float().clone().requires_grad_(True)
+    F.gelu(xg).backward(torch.ones_like(xg))
+    nb = A.float() @ W.float().t()
+    assert rel(o.gemm(A, W, act=o.ACT_DGELU, aux_in=pre).float(), nb * xg.grad) < tol
+    assert rel(o.gemm(A, W, act=o.ACT_DRELU, aux_in=pre).float(), nb * (pre.float() > 0)) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(2048, 96, 160), (5000, 768, 64), (64, 3072, 768), (4, 768, 2048)])
+def test_wgrad_splitk_and_beta(dtype, M, N, K):
+    o = ops()
+    dY, X = rnd(M, N, dtype=dtype, seed=9), rnd(M, K, dtype=dtype, seed=10)
+    ref = dY.float().t() @ X.float()
+    tol = TOL[dtype] * (4 if dtype == torch.bfloat16 else 2)
+    dW = o.wgrad(dY, X)
+    assert dW.dtype == torch.float32 and rel(dW, ref) < tol
+    dW2 = o.wgrad(dY, X, out=dW.clone(), beta=1.0)
+    assert rel(dW2, 2 * ref) < tol
+    for sk in (1, 3, 8):
+        assert rel(o.gemm(dY, X, trans_a=True, trans_b=True, out_f32=True, split_k=sk), ref) < tol
+    # bitwise reproducible (fixed-order split-K reduce, no atomics)
+    assert torch.equal(o.wgrad(dY, X), o.wgrad(dY, X))
+
+
+# ------------------------------------------------------------------------------------------ element-wise
+def test_cast_im2col_colsum_rows():
+    o = ops()
+    x = rnd(1000003, seed=11)
+    xb = o.cast(x, torch.bfloat16)
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    assert torch.equal(o.cast(xb, torch.float32), xb.float())
+    v = rnd(2, 3, 4, 32, 48, seed=12)
+    for dt in (torch.float32, torch.bfloat16):
+        a = o.patch_im2col(v, 2, 16, dt)
+        ref = v.reshape(2, 3, 2, 2, 2, 16, 3, 16).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(2 * 2 * 2 * 3, 3 * 2 * 16 * 16)
+        assert torch.equal(a, ref.to(dt))
+    for dt in (torch.float32, torch.bfloat16):
+        m = rnd(3001, 765, dtype=dt, seed=13)
+        s = o.colsum(m)
+        assert rel(s, m.float().sum(0)) < 1e-4
+        s2 = o.colsum(m, out=s.clone(), beta=1.0)
+        assert rel(s2, 2 * m.float().sum(0)) < 1e-4
+        r = rnd(12, 40, dtype=dt, seed=14)
+        assert rel(o.rows_reduce_mod(r, 4), r.float().reshape(3, 4, 40).sum(0)) < 1e-5
+        src = rnd(4, 40, seed=15)
+        assert torch.equal(o.rows_broadcast(src, 12, dt), src.repeat(3, 1).to(dt))
+        a_, b_ = rnd(999, dtype=dt, seed=16), rnd(999, dtype=dt, seed=17)
+        assert rel(o.add(a_, b_).float(), (a_.float() + b_.float())) < TOL[dt]
+        y = torch.sigmoid(rnd(50, 20, seed=18)).to(dt)
+        dy = rnd(50, 20, dtype=dt, seed=19)
+        assert rel(o.act_bwd(dy, y, o.ACT_SIGMOID).float(), dy.float() * y.float() * (1 - y.float())) < TOL[dt]
+        assert rel(o.act_bwd(dy, y - 0.5, o.ACT_RELU).float(), dy.float() * ((y - 0.5).float() > 0)) < TOL[dt]
+
+
+# --------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,D,eps", [(4, 768, 1e-6), (1571, 768, 1e-5), (130, 384, 1e-6), (67, 1024, 1e-6)])
+def test_layernorm(dtype, M, D, eps):
+    o = ops()
+    x = rnd(M, D, dtype=dtype, seed=20) * 2 + 0.5
+    g, b = 1 + 0.1 * rnd(D, seed=21), 0.1 * rnd(D, seed=22)
+    y, mean, rstd = o.layernorm_fwd(x, g, b, eps)
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), gr, br, eps)
+    tol = TOL[dtype]
+    assert rel(y.float(), yr) < tol
+    assert rel(mean, x.float().mean(1)) < 1e-5
+    dy = rnd(M, D, dtype=dtype, seed=23)
+    dres = rnd(M, D, dtype=dtype, seed=24)
+    yr.backward(dy.float())
+    dx, dg, db = o.layernorm_bwd(dy, x, g, mean, rstd, dres=dres)
+    assert rel(dx.float(), xr.grad + dres.float()) < tol
+    assert rel(dg, gr.grad) < (1e-4 if dtype == torch.float32 else 1e-3)
+    assert rel(db, br.grad) < (1e-4 if dtype == torch.float32 else 1e-3)
+    dx2, dg2, db2 = o.layernorm_bwd(dy, x, g, mean, rstd, dgamma=dg.clone(), dbeta=db.clone(), beta_acc=1.0)
+    assert rel(dx2.float(), xr.grad) < tol and rel(dg2, 2 * gr.grad) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, B, N, H, scale):
+    q, k, v = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q * scale) @ k.transpose(-1, -2)
+    p = s.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(B * N, H * 64), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,H", [(1, 64, 1), (2, 100, 3), (1, 784, 2), (1, 1569, 1), (2, 200, 6)])
+def test_mhsa_fwd_bwd(dtype, B, N, H):
+    o = ops()
+    scale = 64 ** -0.5
+    qkv = rnd(B * N, 3 * H * 64, dtype=dtype, seed=30)
+    out, lse = o.mhsa_fwd(qkv, B, N, H, scale)
+    x = qkv.float().clone().requires_grad_(True)
+    ro, rl = _attn_ref(x, B, N, H, scale)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel(out.float(), ro) < tol
+    assert rel(lse, rl) < (1e-5 if dtype == torch.float32 else 1e-2)
+    d_o = rnd(B * N, H * 64, dtype=dtype, seed=31)
+    ro.backward(d_o.float())
+    dqkv = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale)
+    g = x.grad.reshape(B, N, 3, H, 64)
+    mine = dqkv.float().reshape(B, N, 3, H, 64)
+    for w, name in enumerate("qkv"):
+        assert rel(mine[:, :, w], g[:, :, w]) < (2e-4 if dtype == torch.float32 else 3e-2), name
+
+
+def test_mhsa_bf16_online_softmax_rescale():
+    """force the running max to jump late in the key sequence (the rare rescale path of the online softmax)"""
+    o = ops()
+    B, N, H = 1, 320, 1
+    qkv = rnd(B * N, 3 * 64, dtype=torch.bfloat16, seed=32) * 0.3
+    q = qkv.view(N, 3, 64)
+    q[:, 1][300] = q[:, 0][5] * 40          # key 300 spikes against query 5 in the last tile
+    out, lse = o.mhsa_fwd(qkv, B, N, H, 0.125)
+    ro, rl = _attn_ref(qkv, B, N, H, 0.125)
+    assert rel(out.float(), ro) < 2e-2 and rel(lse, rl) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------ slot attention
+def _slot_ref(q, kv, B, S, N, h, dh, scale):
+    inner = h * dh
+    qh = q.reshape(B, S, h, dh).permute(0, 2, 1, 3)
+    k = kv.reshape(B, N, 2, h, dh)[:, :, 0].permute(0, 2, 1, 3)
+    v = kv.reshape(B, N, 2, h, dh)[:, :, 1].permute(0, 2, 1, 3)
+    sim = (qh @ k.transpose(-1, -2)) * scale
+    A = sim.softmax(dim=2)
+    r = A.sum(-1, keepdim=True) + 1e-7
+    out = ((A / r) @ v).permute(0, 2, 1, 3).reshape(B * S, inner)
+    return A.reshape(B * h, S, N), r.reshape(B * h, S), out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,N,h", [(2, 2, 100, 4), (1, 4, 784, 2), (3, 3, 65, 1)])
+def test_slot_attention(dtype, B, S, N, h):
+    o = ops()
+    dh, scale = 512, 512 ** -0.5
+    q = rnd(B * S, h * dh, dtype=dtype, seed=40)
+    kv = rnd(B * N, 2 * h * dh, dtype=dtype, seed=41)
+    A, r, out = o.slot_attn_fwd(q, kv, B, S, N, h, dh, scale)
+    qr, kvr = q.float().clone().requires_grad_(True), kv.float().clone().requires_grad_(True)
+    Ar, rr, outr = _slot_ref(qr, kvr, B, S, N, h, dh, scale)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert rel(A, Ar) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert rel(r, rr) < 1e-4 and rel(out.float(), outr) < tol
+    d_o = rnd(B * S, h * dh, dtype=dtype, seed=42)
+    dA = rnd(B * h, S, N, seed=43) * 0.01
+    (outr * d_o.float()).sum().add((Ar * dA).sum()).backward()
+    dq, ds = o.slot_attn_bwd(q, kv, A, r, out, d_o, dA, B, S, N, h, dh, scale)
+    assert rel(dq.float(), qr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    dkv = o.slot_attn_kv_grad(q.unsqueeze(0).contiguous(), d_o.unsqueeze(0).contiguous(), ds.unsqueeze(0).contiguous(),
+                              A.unsqueeze(0).contiguous(), r.unsqueeze(0).contiguous(), 1, B, S, N, h, dh, scale)
+    assert rel(dkv.float(), kvr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+
+
+def test_slot_kv_grad_stacked_layers():
+    """L stacked (weight-tied) layers, more (l,i) pairs than one LDS group holds"""
+    o = ops()
+    L, B, S, N, h, dh = 5, 1, 4, 70, 2, 512
+    scale = dh ** -0.5
+    qs, dos = rnd(L, B * S, h * dh, seed=44), rnd(L, B * S, h * dh, seed=45)
+    ds, A = rnd(L, B * h, S, N, seed=46), rnd(L, B * h, S, N, seed=47).abs()
+    r = rnd(L, B * h, S, seed=48).abs() + 1
+    dkv = o.slot_attn_kv_grad(qs, dos, ds, A, r, L, B, S, N, h, dh, scale)
+    qh = qs.reshape(L, B, S, h, dh).permute(0, 1, 3, 2, 4)      # L,B,h,S,dh
+    doh = dos.reshape(L, B, S, h, dh).permute(0, 1, 3, 2, 4)
+    dK = scale * torch.einsum("lbhsn,lbhsd->bnhd", ds.reshape(L, B, h, S, N), qh)
+    dV = torch.einsum("lbhsn,lbhsd->bnhd", (A / r.unsqueeze(-1)).reshape(L, B, h, S, N), doh)
+    ref = torch.stack([dK, dV], dim=2).reshape(B * N, 2 * h * dh)
+    assert rel(dkv, ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------- selection + loss
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S", [(2, 2), (5, 4), (3, 3)])
+def test_head_match_loss(dtype, B, S):
+    from oracle import ref_cpu
+    o = ops()
+    C, nb, ns, D, G, N, nh = 765, 400, 365, 768, 196, 300, 4
+    cfg = ref_cpu.SlotViTConfig()
+    Z = rnd(B * S, C, dtype=dtype, seed=50) * 2
+    slots = rnd(B * S, D, dtype=dtype, seed=51)
+    maskp = torch.sigmoid(rnd(B * S, G, seed=52)).to(dtype)
+    attn = torch.softmax(rnd(B * nh, S, N, seed=53), dim=1)
+    teacher = rnd(B, ns, seed=54) * 3
+    target = torch.randint(0, nb, (B,), generator=torch.Generator().manual_seed(55)).to(DEV)
+    fg = (torch.randint(0, 257, (B, G), generator=torch.Generator().manual_seed(56)) / 256.0).to(DEV)
+    fgN = (torch.randint(0, 257, (B, N), generator=torch.Generator().manual_seed(57)) / 256.0).to(DEV)
+    losses, match, logits = o.head_match_loss_fwd(Z, slots, maskp, attn, teacher, target, fg, fgN, nb, 4000.0, 1.0, 1.0)
+    # oracle on the same (rounded) values
+    Zc, sc, mc, ac = (t.float().cpu().clone().requires_grad_(True) for t in (Z, slots, maskp, attn))
+    out = (None, (None, None, ac), (Zc, sc, mc))
+    total, rlogits, ld, idx = ref_cpu.train_loss(cfg, out, teacher.cpu(), target.cpu(), (fg.cpu(), fgN.cpu()))
+    assert match[:, 0].cpu().tolist() == idx[0].tolist() and match[:, 1].cpu().tolist() == idx[1].tolist()
+    want = [ld["action_loss"], ld["scene_loss"], ld["cosine_loss"], ld["mask_prediction_loss"], ld["mask_distill_loss"], float(total)]
+    got = losses.cpu().tolist()
+    for g_, w_ in zip(got, want):
+        assert abs(g_ - w_) <= 2e-5 * max(1.0, abs(w_)), (got, want)
+    assert torch.equal(logits.cpu().float(), rlogits.detach())
+    total.backward()
+    g = torch.tensor([1.0], device=DEV)
+    dZ, dsl, dm, da = o.head_match_loss_bwd(Z, slots, maskp, attn, teacher, target, fg, fgN, match, g, nb, 4000.0, 1.0, 1.0)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert rel(dZ.float().cpu(), Zc.grad) < tol
+    assert rel(dsl.float().cpu(), sc.grad) < tol
+    assert rel(dm.float().cpu(), mc.grad) < tol
+    assert rel(da.cpu(), ac.grad) < 1e-4
+    # slot selection (modeling_slot.py:395-401)
+    sel = o.slot_select(Z, B, S, nb).cpu()
+    p = Z.float().cpu().softmax(-1).view(B, S, C)
+    assert sel[:, 0].tolist() == p[:, :, :nb].max(-1).values.argmax(1).tolist()
+    assert sel[:, 1].tolist() == p[:, :, nb:].max(-1).values.argmax(1).tolist()
+
+
+def test_adamw_matches_torch():
+    o = ops()
+    p = rnd(10007, seed=60); g = rnd(10007, seed=61)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        ref.grad = g.clone() * step
+        opt.step()
+        o.adamw_step(p, g * step, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, step)
+    assert rel(p, ref.detach()) < 1e-6
