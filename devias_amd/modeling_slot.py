@@ -1,0 +1,658 @@
+"""MI355X-native slot-DEVIAS student model behind the reference's timm-style surface.
+
+Mirrors model/modeling_slot.py + agg_block/{agg_block,attention}.py of the reference: same constructor kwargs,
+same module tree / parameter names (state_dict compatible), same `forward()` 3-tuple.  The nn.Module
+objects below (nn.Linear, nn.LayerNorm, nn.Conv3d ...) are PARAMETER CONTAINERS only: their own forward() is never
+called.  All arithmetic runs in libdevias_amd.so (hand-written gfx950 HIP kernels) through four autograd Functions,
+one per fused region:
+
+    PatchEmbedFn   tubelet im2col -> GEMM(+bias +sinusoid pos)                       (modeling_slot.py:171-177, :354-355)
+    EncoderBlockFn LN -> QKV GEMM -> flash MHSA -> proj GEMM(+res) -> LN -> fc1 GEMM(+GELU) -> fc2 GEMM(+res)   (:142-152)
+    AggBlockFn     final LN -> [context LN -> K|V GEMM once per distinct weight set] -> depth x slot layer -> LN
+                   (agg_block/agg_block.py:120-139, agg_block/attention.py:32-40,120-141)
+    HeadFn         shared head GEMM + MaskPredictor MLP (ReLU/ReLU/Sigmoid epilogues)     (modeling_slot.py:392-393, :209-216)
+
+`compute_dtype` selects the activation/weight storage type of the kernels: 'fp32' (parity mode: exact fp32 MFMA / VALU
+kernels) or 'bf16' (measured mode: bf16 storage, fp32 accumulation and statistics).  Master parameters are always fp32.
+There is no PyTorch fallback: without a GPU + the built HIP library forward() raises.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import ops
+from .ops import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+_MODEL_REGISTRY: Dict[str, callable] = {}
+
+
+def register_model(fn):
+    """timm.models.registry.register_model stand-in (timm is used when importable, see create_model)."""
+    _MODEL_REGISTRY[fn.__name__] = fn
+    try:  # register with timm too so `timm.create_model('slot_vit_base_patch16_224', ...)` works as in the reference
+        from timm.models.registry import register_model as _timm_register  # type: ignore
+        _timm_register(fn)
+    except Exception:
+        pass
+    return fn
+
+
+def create_model(name: str, pretrained: bool = False, **kwargs):
+    """timm.create_model look-alike: drops None kwargs like timm does (run_slot_finetuning.py:371-390)."""
+    kwargs = {k: v for k, v in kwargs.items() if v is not None}
+    return _MODEL_REGISTRY[name](pretrained=pretrained, **kwargs)
+
+
+def _cfg(url="", **kwargs):
+    return {"url": url, "num_classes": 400, "input_size": (3, 224, 224), "pool_size": None, "crop_pct": .9,
+            "interpolation": "bicubic", "mean": (0.5, 0.5, 0.5), "std": (0.5, 0.5, 0.5), **kwargs}
+
+
+def get_sinusoid_encoding_table(n_position: int, d_hid: int) -> torch.Tensor:
+    """float64 table cast to fp32, [1, N, D] (modeling_slot.py:181-191)."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)
+    angle = pos / np.power(10000.0, 2.0 * (j // 2) / d_hid)[None, :]
+    table = angle.copy()
+    table[:, 0::2] = np.sin(angle[:, 0::2])
+    table[:, 1::2] = np.cos(angle[:, 1::2])
+    return torch.tensor(table, dtype=torch.float32).unsqueeze(0)
+
+
+# =====================================================================================================
+# compute-dtype weight copies (bf16 mode): one cast per parameter per optimizer step, keyed on Tensor._version
+# =====================================================================================================
+class _WeightCache:
+    def __init__(self):
+        self._c = {}
+
+    def get(self, p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        d = p.detach()
+        if d.dim() > 2:
+            d = d.reshape(d.shape[0], -1)
+        if dtype == torch.float32:
+            return d if d.is_contiguous() else d.contiguous()
+        key = id(p)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and hit[2].device == p.device:
+            return hit[2]
+        w = ops.cast(d.contiguous(), dtype)
+        self._c[key] = (p._version, p.data_ptr(), w)
+        return w
+
+    def get_cat(self, ps, dtype: torch.dtype) -> torch.Tensor:
+        """row-concatenation of several weights (to_k | to_v) in the compute dtype, cached like get()."""
+        key = tuple(id(p) for p in ps)
+        ver = tuple((p._version, p.data_ptr()) for p in ps)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == ver and hit[2].device == ps[0].device:
+            return hit[2]
+        w = torch.cat([self.get(p, dtype) for p in ps], dim=0).contiguous()
+        self._c[key] = (ver, None, w)
+        return w
+
+
+_WCACHE = _WeightCache()
+
+
+def _f32(p: torch.Tensor) -> torch.Tensor:
+    d = p.detach()
+    return d if d.dtype == torch.float32 and d.is_contiguous() else d.float().contiguous()
+
+
+# =====================================================================================================
+# autograd Functions (each = one fused region, forward and hand-written backward over the C ABI)
+# =====================================================================================================
+class PatchEmbedFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, pos, meta):
+        ts, ps, cdt = meta
+        A = ops.patch_im2col(x, ts, ps, cdt)                          # [B*N, C*ts*ps*ps]
+        w = _WCACHE.get(weight, cdt)
+        y = ops.gemm(A, w, bias=_f32(bias), res=pos, res_mod=pos.shape[0])
+        ctx.A = A
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dW = ops.wgrad(dy, ctx.A).reshape(ctx.wshape)
+        db = ops.colsum(dy)
+        ctx.A = None
+        return None, dW, db, None, None
+
+
+class EncoderBlockFn(Function):
+    """x -> x + proj(MHSA(LN1 x)) -> + fc2(GELU(fc1(LN2 .)))   (Block.forward, modeling_slot.py:142-152; no LayerScale, drop_path 0)"""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkvw, qb, vb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, meta):
+        B, N, H, eps, cdt = meta
+        scale = 64 ** -0.5
+        n1w_, n1b_, n2w_, n2b_ = _f32(n1w), _f32(n1b), _f32(n2w), _f32(n2b)
+        Wqkv, Wp, W1, W2 = (_WCACHE.get(w, cdt) for w in (qkvw, pw, f1w, f2w))
+        u, mean1, rstd1 = ops.layernorm_fwd(x, n1w_, n1b_, eps)
+        qkv_bias = torch.cat((_f32(qb), torch.zeros_like(_f32(vb)), _f32(vb)))         # modeling_slot.py:97-99
+        qkv = ops.gemm(u, Wqkv, bias=qkv_bias)                                          # [M, 3D] == [B,N,3,H,64]
+        o, lse = ops.mhsa_fwd(qkv, B, N, H, scale)
+        x1 = ops.gemm(o, Wp, bias=_f32(pb), res=x)
+        u2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w_, n2b_, eps)
+        hpre = torch.empty((x.shape[0], W1.shape[0]), dtype=cdt, device=x.device)
+        hact = ops.gemm(u2, W1, bias=_f32(f1b), act=ACT_GELU, aux_out=hpre)
+        x2 = ops.gemm(hact, W2, bias=_f32(f2b), res=x1)
+        ctx.meta = meta
+        ctx.saved = (x, u, mean1, rstd1, qkv, o, lse, x1, u2, mean2, rstd2, hpre, hact, n1w_, n2w_, Wqkv, Wp, W1, W2)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        B, N, H, eps, cdt = ctx.meta
+        scale = 64 ** -0.5
+        (x, u, mean1, rstd1, qkv, o, lse, x1, u2, mean2, rstd2, hpre, hact, n1w_, n2w_, Wqkv, Wp, W1, W2) = ctx.saved
+        ctx.saved = None
+        dx2 = dx2.contiguous()
+        D = x.shape[1]
+        # ---- MLP branch
+        dhpre = ops.gemm(dx2, W2, trans_b=True, act=ACT_DGELU, aux_in=hpre)             # (dx2 W2) * gelu'(pre)
+        dW2 = ops.wgrad(dx2, hact)
+        db2 = ops.colsum(dx2)
+        du2 = ops.gemm(dhpre, W1, trans_b=True)
+        dW1 = ops.wgrad(dhpre, u2)
+        db1 = ops.colsum(dhpre)
+        dx1, dn2w, dn2b = ops.layernorm_bwd(du2, x1, n2w_, mean2, rstd2, dres=dx2)      # + residual gradient
+        # ---- attention branch
+        d_o = ops.gemm(dx1, Wp, trans_b=True)
+        dWp = ops.wgrad(dx1, o)
+        dbp = ops.colsum(dx1)
+        dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale)
+        du = ops.gemm(dqkv, Wqkv, trans_b=True)
+        dWqkv = ops.wgrad(dqkv, u)
+        dbqkv = ops.colsum(dqkv)
+        dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1)
+        return (dx, dn1w, dn1b, dWqkv, dbqkv[:D], dbqkv[2 * D:], dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None)
+
+
+_LAYER_KEYS = ("to_q", "to_k", "to_v", "to_out_w", "to_out_b", "norm_w", "norm_b", "ctx_w", "ctx_b",
+               "ff0_w", "ff0_b", "ff3_w", "ff3_b", "ffn_w", "ffn_b")
+
+
+class AggBlockFn(Function):
+    """encoder output -> final LN -> AggregationBlock -> (slots [B*S, D], attn [B*h, S, N] fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, latents, last_w, last_b, meta, *layer_params):
+        B, N, S, depth, tied, heads, dh, eps_enc, eps_agg, cdt = meta
+        nset = 1 if tied else depth
+        assert len(layer_params) == nset * len(_LAYER_KEYS)
+        LP = [dict(zip(_LAYER_KEYS, layer_params[i * 15:(i + 1) * 15])) for i in range(nset)]
+        inner = heads * dh
+        scale = dh ** -0.5
+        dev = x.device
+        M = x.shape[0]
+        feats, m0, r0 = ops.layernorm_fwd(x, _f32(norm_w), _f32(norm_b), eps_enc)        # modeling_slot.py:373
+        # context LayerNorm + fused K|V projection, once per distinct weight set (the reference redoes it every layer)
+        kvsets = []
+        for P in LP:
+            c, mc, rc = ops.layernorm_fwd(feats, _f32(P["ctx_w"]), _f32(P["ctx_b"]), eps_agg)
+            Wkv = _WCACHE.get_cat((P["to_k"], P["to_v"]), cdt)
+            kv = ops.gemm(c, Wkv)                                                         # [M, 2*inner] == [B,N,2,h,dh]
+            kvsets.append((c, mc, rc, Wkv, kv))
+        xs = ops.rows_broadcast(_f32(latents), B * S, cdt)                                # agg_block.py:112-114
+        q_stack = torch.empty((depth, B * S, inner), dtype=cdt, device=dev)
+        attn_stack = torch.empty((depth, B * heads, S, N), dtype=torch.float32, device=dev)
+        rsum_stack = torch.empty((depth, B * heads, S), dtype=torch.float32, device=dev)
+        layers = []
+        for l in range(depth):
+            P = LP[0 if tied else l]
+            kv = kvsets[0 if tied else l][4]
+            Wq, Wo, W1, W2 = (_WCACHE.get(P[k], cdt) for k in ("to_q", "to_out_w", "ff0_w", "ff3_w"))
+            qn, mq, rq = ops.layernorm_fwd(xs, _f32(P["norm_w"]), _f32(P["norm_b"]), eps_agg)
+            q = ops.gemm(qn, Wq, out=q_stack[l])
+            _, _, o = ops.slot_attn_fwd(q, kv, B, S, N, heads, dh, scale, attn_out=attn_stack[l], rsum_out=rsum_stack[l])
+            xs1 = ops.gemm(o, Wo, bias=_f32(P["to_out_b"]), res=xs)
+            f, mf, rf = ops.layernorm_fwd(xs1, _f32(P["ffn_w"]), _f32(P["ffn_b"]), eps_agg)
+            fpre = torch.empty((B * S, W1.shape[0]), dtype=cdt, device=dev)
+            fact = ops.gemm(f, W1, bias=_f32(P["ff0_b"]), act=ACT_GELU, aux_out=fpre)
+            xs2 = ops.gemm(fact, W2, bias=_f32(P["ff3_b"]), res=xs1)
+            layers.append((xs, mq, rq, qn, o, xs1, mf, rf, f, fpre, fact, Wq, Wo, W1, W2))
+            xs = xs2
+        slots, ml, rl = ops.layernorm_fwd(xs, _f32(last_w), _f32(last_b), eps_agg)
+        ctx.meta = meta
+        ctx.saved = (x, m0, r0, feats, kvsets, layers, q_stack, attn_stack, rsum_stack, xs, ml, rl,
+                     _f32(norm_w), _f32(last_w), [{k: _f32(P[k]) for k in ("norm_w", "ctx_w", "ffn_w")} for P in LP])
+        return slots, attn_stack[depth - 1]
+
+    @staticmethod
+    def backward(ctx, dslots, dattn):
+        B, N, S, depth, tied, heads, dh, eps_enc, eps_agg, cdt = ctx.meta
+        (x, m0, r0, feats, kvsets, layers, q_stack, attn_stack, rsum_stack, xs_last, ml, rl, norm_w, last_w, LNW) = ctx.saved
+        ctx.saved = None
+        nset = 1 if tied else depth
+        inner = heads * dh
+        scale = dh ** -0.5
+        dev = x.device
+        G = [dict() for _ in range(nset)]        # gradient accumulators per distinct weight set
+
+        def acc_w(si, key, dY, X):
+            if key in G[si]:
+                ops.wgrad(dY, X, out=G[si][key], beta=1.0)
+            else:
+                G[si][key] = ops.wgrad(dY, X)
+
+        def acc_b(si, key, dY):
+            if key in G[si]:
+                ops.colsum(dY, out=G[si][key], beta=1.0)
+            else:
+                G[si][key] = ops.colsum(dY)
+
+        def ln_bwd(si, kw, kb, dy, xin, gamma, mean, rstd, dres):
+            if kw in G[si]:
+                dxo, _, _ = ops.layernorm_bwd(dy, xin, gamma, mean, rstd, dres=dres, dgamma=G[si][kw], dbeta=G[si][kb], beta_acc=1.0)
+            else:
+                dxo, G[si][kw], G[si][kb] = ops.layernorm_bwd(dy, xin, gamma, mean, rstd, dres=dres)
+            return dxo
+
+        dxs, dlast_w, dlast_b = ops.layernorm_bwd(dslots.contiguous(), xs_last, last_w, ml, rl)
+        do_stack = torch.empty((depth, B * S, inner), dtype=cdt, device=dev)
+        ds_stack = torch.empty((depth, B * heads, S, N), dtype=torch.float32, device=dev)
+        dattn_ext = dattn.contiguous() if dattn is not None else None
+        for l in reversed(range(depth)):
+            si = 0 if tied else l
+            (xs_in, mq, rq, qn, o, xs1, mf, rf, f, fpre, fact, Wq, Wo, W1, W2) = layers[l]
+            kv = kvsets[si][4]
+            # feed-forward: xs2 = xs1 + W2 gelu(W1 LN(xs1) + b1) + b2
+            dfpre = ops.gemm(dxs, W2, trans_b=True, act=ACT_DGELU, aux_in=fpre)
+            acc_w(si, "ff3_w", dxs, fact); acc_b(si, "ff3_b", dxs)
+            df = ops.gemm(dfpre, W1, trans_b=True)
+            acc_w(si, "ff0_w", dfpre, f); acc_b(si, "ff0_b", dfpre)
+            dxs1 = ln_bwd(si, "ffn_w", "ffn_b", df, xs1, LNW[si]["ffn_w"], mf, rf, dxs)
+            # cross attention: xs1 = xs + Wo o + bo
+            d_o = ops.gemm(dxs1, Wo, trans_b=True, out=do_stack[l])
+            acc_w(si, "to_out_w", dxs1, o); acc_b(si, "to_out_b", dxs1)
+            dq, _ = ops.slot_attn_bwd(q_stack[l], kv, attn_stack[l], rsum_stack[l], o, d_o,
+                                      dattn_ext if l == depth - 1 else None, B, S, N, heads, dh, scale, ds_out=ds_stack[l])
+            dqn = ops.gemm(dq, Wq, trans_b=True)
+            acc_w(si, "to_q", dq, qn)
+            dxs = ln_bwd(si, "norm_w", "norm_b", dqn, xs_in, LNW[si]["norm_w"], mq, rq, dxs1)
+        dlatents = ops.rows_reduce_mod(dxs, S)
+        # deferred K/V gradients: one pass per distinct K/V over all the layers that used it
+        dfeats = None
+        for si in range(nset):
+            c, mc, rc, Wkv, kv = kvsets[si]
+            if tied:
+                dkv = ops.slot_attn_kv_grad(q_stack, do_stack, ds_stack, attn_stack, rsum_stack, depth, B, S, N, heads, dh, scale)
+            else:
+                dkv = ops.slot_attn_kv_grad(q_stack[si:si + 1], do_stack[si:si + 1], ds_stack[si:si + 1], attn_stack[si:si + 1],
+                                            rsum_stack[si:si + 1], 1, B, S, N, heads, dh, scale)
+            dc = ops.gemm(dkv, Wkv, trans_b=True)
+            dWkv = ops.wgrad(dkv, c)
+            G[si]["to_k"], G[si]["to_v"] = dWkv[:inner], dWkv[inner:]
+            dfeats_i, G[si]["ctx_w"], G[si]["ctx_b"] = ops.layernorm_bwd(dc, feats, LNW[si]["ctx_w"], mc, rc, dres=dfeats)
+            dfeats = dfeats_i
+        dx, dnorm_w, dnorm_b = ops.layernorm_bwd(dfeats, x, norm_w, m0, r0)
+        flat = []
+        for si in range(nset):
+            flat += [G[si][k] for k in _LAYER_KEYS]
+        return (dx, dnorm_w, dnorm_b, dlatents, dlast_w, dlast_b, None, *flat)
+
+
+class HeadFn(Function):
+    """slots -> (slots_head = head(slots), mask_predictions = MaskPredictor(slots))  (modeling_slot.py:392-393, 209-216)"""
+
+    @staticmethod
+    def forward(ctx, slots, hw, hb, w0, b0, w2, b2, w4, b4, cdt):
+        Wh, W0, W2, W4 = (_WCACHE.get(w, cdt) for w in (hw, w0, w2, w4))
+        Z = ops.gemm(slots, Wh, bias=_f32(hb))
+        m1 = ops.gemm(slots, W0, bias=_f32(b0), act=ACT_RELU)
+        m2 = ops.gemm(m1, W2, bias=_f32(b2), act=ACT_RELU)
+        Mk = ops.gemm(m2, W4, bias=_f32(b4), act=ACT_SIGMOID)
+        ctx.saved = (slots, m1, m2, Mk, Wh, W0, W2, W4)
+        return Z, Mk
+
+    @staticmethod
+    def backward(ctx, dZ, dM):
+        slots, m1, m2, Mk, Wh, W0, W2, W4 = ctx.saved
+        ctx.saved = None
+        dZ = dZ.contiguous() if dZ is not None else torch.zeros((slots.shape[0], Wh.shape[0]), dtype=slots.dtype, device=slots.device)
+        dM = dM.contiguous() if dM is not None else torch.zeros_like(Mk)
+        dp3 = ops.act_bwd(dM, Mk, ACT_SIGMOID)
+        dW4, db4 = ops.wgrad(dp3, m2), ops.colsum(dp3)
+        dp2 = ops.gemm(dp3, W4, trans_b=True, act=ACT_DRELU, aux_in=m2)
+        dW2, db2 = ops.wgrad(dp2, m1), ops.colsum(dp2)
+        dp1 = ops.gemm(dp2, W2, trans_b=True, act=ACT_DRELU, aux_in=m1)
+        dW0, db0 = ops.wgrad(dp1, slots), ops.colsum(dp1)
+        ds_m = ops.gemm(dp1, W0, trans_b=True)
+        dslots = ops.gemm(dZ, Wh, trans_b=True, res=ds_m)
+        dWh, dbh = ops.wgrad(dZ, slots), ops.colsum(dZ)
+        return dslots, dWh, dbh, dW0, db0, dW2, db2, dW4, db4, None
+
+
+# =====================================================================================================
+# module tree (parameter containers with the reference's names)
+# =====================================================================================================
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., attn_head_dim=None):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads if attn_head_dim is None else attn_head_dim
+        all_head_dim = head_dim * num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, all_head_dim * 3, bias=False)
+        if qkv_bias:
+            self.q_bias = nn.Parameter(torch.zeros(all_head_dim))
+            self.v_bias = nn.Parameter(torch.zeros(all_head_dim))
+        else:
+            self.q_bias = None
+            self.v_bias = None
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(all_head_dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        if head_dim != 64:
+            raise ValueError(f"devias_amd MHSA kernels are built for head_dim 64 (ViT-S/B/L), got {head_dim}")
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
+                 init_values=None, act_layer=nn.GELU, norm_layer=nn.LayerNorm, attn_head_dim=None):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop, attn_head_dim=attn_head_dim)
+        self.drop_path_rate = float(drop_path)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        if init_values and init_values > 0:   # gamma_1/2 exist in the reference but are never applied (:136-152)
+            self.gamma_1 = nn.Parameter(init_values * torch.ones(dim), requires_grad=True)
+            self.gamma_2 = nn.Parameter(init_values * torch.ones(dim), requires_grad=True)
+        else:
+            self.gamma_1, self.gamma_2 = None, None
+
+    def run(self, x, B, N, cdt):
+        a = self.attn
+        if a.q_bias is None:
+            raise NotImplementedError("qkv_bias=False is not used by any DEVIAS entrypoint")
+        if self.training and self.drop_path_rate > 0:
+            raise NotImplementedError("stochastic depth (drop_path > 0) is not implemented in the HIP path yet; "
+                                      "use drop_path_rate=0 (parity / benchmark setting)")
+        meta = (B, N, a.num_heads, self.norm1.eps, cdt)
+        return EncoderBlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight,
+                                    a.proj.bias, self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
+                                    self.mlp.fc2.weight, self.mlp.fc2.bias, meta)
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, num_frames=16, tubelet_size=2):
+        super().__init__()
+        img_size = (img_size, img_size) if not isinstance(img_size, (tuple, list)) else tuple(img_size)
+        patch_size = (patch_size, patch_size) if not isinstance(patch_size, (tuple, list)) else tuple(patch_size)
+        self.tubelet_size = int(tubelet_size)
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0]) * (num_frames // self.tubelet_size)
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.proj = nn.Conv3d(in_channels=in_chans, out_channels=embed_dim,
+                              kernel_size=(self.tubelet_size, patch_size[0], patch_size[1]),
+                              stride=(self.tubelet_size, patch_size[0], patch_size[1]))
+
+
+class MaskPredictor(nn.Module):
+    def __init__(self, dim=768, out=196):
+        super().__init__()
+        self.decoder = nn.Sequential(nn.Linear(dim, 512), nn.ReLU(), nn.Linear(512, 256), nn.ReLU(), nn.Linear(256, out),
+                                     nn.Sigmoid())
+        self.act = nn.ReLU()
+
+
+class PreNorm(nn.Module):
+    def __init__(self, dim, fn, context_dim=None):
+        super().__init__()
+        self.fn = fn
+        self.norm = nn.LayerNorm(dim)
+        self.norm_context = nn.LayerNorm(context_dim) if context_dim is not None else None
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4, dropout=0.):
+        super().__init__()
+        self.activation = nn.GELU()
+        self.net = nn.Sequential(nn.Linear(dim, int(dim * mult)), self.activation, nn.Dropout(dropout),
+                                 nn.Linear(int(dim * mult), dim), nn.Identity())
+
+
+class SlotAttention(nn.Module):
+    """agg_block/attention.py:85-141 (class `Attention` there)."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        context_dim = context_dim if context_dim is not None else query_dim
+        self.heads, self.dim_head = heads, dim_head
+        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
+        self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+
+
+class AggregationBlock(nn.Module):
+    """agg_block/agg_block.py:8-139 with the DEVIAS settings (learned queries, pre-norm, GELU FF x4, no pos-enc, last LN)."""
+
+    def __init__(self, *, depth=4, input_channels=768, num_latents=4, latent_dim=768, weight_tie_layers=True, ff_mult=4):
+        super().__init__()
+        self.num_latents, self.latent_dim, self.input_dim = num_latents, latent_dim, input_channels
+        self.depth, self.weight_tie_layers = depth, weight_tie_layers
+        self.heads, self.dim_head = 4, 512                                        # agg_block.py:83
+        self.latents = nn.Parameter(torch.randn(num_latents, latent_dim))         # agg_block.py:62
+        mk_attn = lambda: PreNorm(latent_dim, SlotAttention(latent_dim, input_channels, heads=self.heads, dim_head=self.dim_head),
+                                  context_dim=input_channels)
+        mk_ff = lambda: PreNorm(latent_dim, FeedForward(latent_dim, mult=ff_mult))
+        self.layers = nn.ModuleList([])
+        cached = None
+        for _ in range(depth):
+            if weight_tie_layers:
+                cached = cached or (mk_attn(), mk_ff())            # cache_fn: the SAME module objects every layer
+                a, f = cached
+            else:
+                a, f = mk_attn(), mk_ff()
+            self.layers.append(nn.ModuleList([a, nn.Identity(), f, nn.Identity()]))
+        self.last_layer = nn.Sequential(nn.LayerNorm(latent_dim))
+
+    def layer_params(self) -> List[torch.Tensor]:
+        out = []
+        for l in range(1 if self.weight_tie_layers else self.depth):
+            a, _, f, _ = self.layers[l]
+            out += [a.fn.to_q.weight, a.fn.to_k.weight, a.fn.to_v.weight, a.fn.to_out[0].weight, a.fn.to_out[0].bias,
+                    a.norm.weight, a.norm.bias, a.norm_context.weight, a.norm_context.bias,
+                    f.fn.net[0].weight, f.fn.net[0].bias, f.fn.net[3].weight, f.fn.net[3].bias, f.norm.weight, f.norm.bias]
+        return out
+
+
+class VisionTransformer(nn.Module):
+    """Slot-DEVIAS student (model/modeling_slot.py:219-413).  Extra kwarg: compute_dtype in {'bf16', 'fp32'}."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4., qkv_bias=False, qk_scale=None, fc_drop_rate=0., drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=nn.LayerNorm, init_values=0., use_learnable_pos_emb=False, init_scale=0.,
+                 all_frames=16, tubelet_size=2, use_checkpoint=False, num_latents=4, head_type='linear',
+                 slot_matching_method='hard_select', num_scene_classes=365, agg_weights_tie=False, agg_depth=4,
+                 slot_matching=None, compute_dtype='bf16'):
+        super().__init__()
+        if slot_matching is not None:          # the reference's driver passes this misspelt kwarg (run_slot_finetuning.py:386)
+            slot_matching_method = slot_matching
+        if slot_matching_method not in ('hard_select', 'matching'):
+            raise ValueError("incorrent slot_matching_method")
+        if head_type != 'linear':
+            raise NotImplementedError("head_type='mlp' is not used by the DEVIAS recipes; only 'linear' is built")
+        if fc_drop_rate or drop_rate or attn_drop_rate:
+            raise NotImplementedError("dropout > 0 is not implemented in the HIP path (all DEVIAS recipes use 0)")
+        if use_learnable_pos_emb:
+            raise NotImplementedError("learnable pos-emb is not used by DEVIAS (sinusoid table only)")
+        self.num_slots = num_latents
+        self.num_classes = num_classes
+        self.num_scene_classes = num_scene_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.tubelet_size = tubelet_size
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      num_frames=all_frames, tubelet_size=tubelet_size)
+        num_patches = self.patch_embed.num_patches
+        self.use_checkpoint = use_checkpoint   # accepted and ignored: no activation checkpointing is needed in 288 GB
+        self.slot_matching_method = slot_matching_method
+        self.head_type = head_type
+        self.select_slots_info = [[0, 0] for _ in range(self.num_slots)]
+        self.pos_embed = get_sinusoid_encoding_table(num_patches, embed_dim)     # plain attribute, not in state_dict
+        self._pos_cache = {}
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                  attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, init_values=init_values)
+            for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.fc_dropout = nn.Identity()
+        self.agg_block = AggregationBlock(num_latents=num_latents, weight_tie_layers=agg_weights_tie, depth=agg_depth,
+                                          input_channels=embed_dim, latent_dim=embed_dim)
+        grid = (img_size // patch_size) if not isinstance(img_size, (tuple, list)) else (img_size[0] // patch_size)
+        self.mask_predictor = MaskPredictor(embed_dim, grid * grid)
+        self.head = nn.Linear(embed_dim, num_classes + num_scene_classes) if num_classes > 0 else nn.Identity()
+        nn.init.trunc_normal_(self.head.weight, std=.02)
+        self.apply(self._init_weights)
+        self.head.weight.data.mul_(init_scale)
+        self.head.bias.data.mul_(init_scale)
+        self.set_compute_dtype(compute_dtype)
+
+    # ---- reference surface -------------------------------------------------------------------------------
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def get_num_layers(self):
+        return len(self.blocks)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def get_select_slot_info(self):
+        print("action slot : " + " | ".join(str(s[0]) for s in self.select_slots_info))
+        print("scene slot : " + " | ".join(str(s[1]) for s in self.select_slots_info))
+
+    def reset_select_slot_info(self):
+        self.select_slots_info = [[0, 0] for _ in range(self.num_slots)]
+
+    def set_compute_dtype(self, compute_dtype):
+        table = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, torch.bfloat16: torch.bfloat16,
+                 'fp32': torch.float32, 'float32': torch.float32, torch.float32: torch.float32}
+        if compute_dtype not in table:
+            raise ValueError(f"compute_dtype must be 'bf16' or 'fp32', got {compute_dtype!r}")
+        self.compute_dtype = table[compute_dtype]
+        return self
+
+    # ---- forward -----------------------------------------------------------------------------------------
+    def _pos(self, device, dtype):
+        key = (str(device), dtype)
+        if key not in self._pos_cache:
+            self._pos_cache[key] = self.pos_embed[0].to(device=device, dtype=dtype).contiguous()
+        return self._pos_cache[key]
+
+    def _prep_input(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("devias_amd.VisionTransformer runs on an MI355X only (HIP kernels; no CPU fallback): "
+                               "move the model and the input to cuda")
+        B, C, T, H, W = x.shape
+        assert H == self.patch_embed.img_size[0] and W == self.patch_embed.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.patch_embed.img_size[0]}*{self.patch_embed.img_size[1]})."
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()          # fp16 clips (samples.half(), engine_for_slot.py:108) are widened losslessly
+        return x.contiguous()
+
+    def forward_features(self, x, return_attn=False):
+        if return_attn:
+            raise NotImplementedError("per-block attention maps are never materialised by the fused MHSA kernel")
+        x = self._prep_input(x)
+        B = x.shape[0]
+        N = self.patch_embed.num_patches
+        cdt = self.compute_dtype
+        pe = self.patch_embed
+        h = PatchEmbedFn.apply(x, pe.proj.weight, pe.proj.bias, self._pos(x.device, cdt), (pe.tubelet_size, pe.patch_size[0], cdt))
+        for blk in self.blocks:
+            h = blk.run(h, B, N, cdt)
+        return h          # [B*N, D], BEFORE the final LayerNorm (it is fused into AggBlockFn)
+
+    def forward(self, x, return_attn=False):
+        B = x.shape[0]
+        N = self.patch_embed.num_patches
+        D = self.embed_dim
+        cdt = self.compute_dtype
+        h = self.forward_features(x, return_attn)
+        ab = self.agg_block
+        S = ab.num_latents
+        meta = (B, N, S, ab.depth, ab.weight_tie_layers, ab.heads, ab.dim_head, self.norm.eps, ab.last_layer[0].eps, cdt)
+        slots, attn = AggBlockFn.apply(h, self.norm.weight, self.norm.bias, ab.latents, ab.last_layer[0].weight,
+                                       ab.last_layer[0].bias, meta, *ab.layer_params())
+        if self.slot_matching_method == 'hard_select':
+            raise NotImplementedError("only slot_matching_method='matching' is on the DEVIAS training path "
+                                      "(the reference's hard_select branch returns empty lists, modeling_slot.py:388)")
+        mp = self.mask_predictor.decoder
+        slots_head, mask_predictions = HeadFn.apply(slots, self.head.weight, self.head.bias, mp[0].weight, mp[0].bias,
+                                                    mp[2].weight, mp[2].bias, mp[4].weight, mp[4].bias, cdt)
+        idx = ops.slot_select(slots_head.detach(), B, S, self.num_classes).long()      # modeling_slot.py:395-401
+        ar = torch.arange(B, device=x.device)
+        sv, hv = slots.view(B, S, D), slots_head.view(B, S, -1)
+        action_feat, scene_feat = sv[ar, idx[:, 0]], sv[ar, idx[:, 1]]
+        action_logit, scene_logit = hv[ar, idx[:, 0]], hv[ar, idx[:, 1]]
+        return (action_feat, scene_feat), (action_logit, scene_logit, attn), (slots_head, slots, mask_predictions)
+
+
+@register_model
+def slot_vit_base_patch16_224(pretrained=False, **kwargs):
+    model = VisionTransformer(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                              norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    model.default_cfg = _cfg()
+    return model
+
+
+@register_model
+def slot_vit_small_patch16_224(pretrained=False, **kwargs):
+    """not in the reference (its wrapper hard-wires 768); needed by BASELINE config 1"""
+    model = VisionTransformer(patch_size=16, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True,
+                              norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    model.default_cfg = _cfg()
+    return model
+
+
+@register_model
+def slot_vit_large_patch16_224(pretrained=False, **kwargs):
+    """not in the reference; BASELINE config 4 (D=1024, 24 blocks, 16 heads)"""
+    model = VisionTransformer(patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True,
+                              norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    model.default_cfg = _cfg()
+    return model

@@ -1,0 +1,94 @@
+"""End-to-end parity of the HIP path (through the C ABI) against the golden fixtures produced by the real reference
+and against the CPU oracle, on the same formula weights / inputs.  fp32 kernel mode carries the 1e-3 gate of
+BASELINE.json's north_star; bf16 mode deviation is measured and bounded loosely."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from devias_amd import synth
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+TOL_FP32 = 1e-3          # north_star: per-slot logits and total loss within 1e-3 relative (fp32)
+
+
+def build(cfg, dtype):
+    from devias_amd.modeling_slot import VisionTransformer
+    from functools import partial
+    m = VisionTransformer(patch_size=16, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4,
+                          qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_classes=cfg.num_classes,
+                          all_frames=cfg.all_frames, tubelet_size=cfg.tubelet_size, init_scale=1e-3,
+                          num_latents=cfg.num_latents, head_type="linear", slot_matching_method="matching",
+                          agg_weights_tie=cfg.agg_weights_tie, agg_depth=cfg.agg_depth,
+                          num_scene_classes=cfg.num_scene_classes, compute_dtype=dtype)
+    synth.fill_module_(m, seed=0)
+    return m.cuda().train()
+
+
+def run_step(model, cfg, B):
+    from devias_amd.train_loss import TrainLoss
+    x, y, tl, fg = gu.inputs(cfg, B)
+    crit = TrainLoss(criterion=None, scene_criterion="KL", num_action_classes=cfg.num_classes, slot_matching_method="matching",
+                     mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0, scene_loss_weight=4000)
+    out = model(x.cuda())
+    total, logits, ld = crit(model, out, (None, tl.cuda()), y.cuda(), fg_mask=(fg[0].cuda(), fg[1].cuda()))
+    model.zero_grad()
+    total.backward()
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    assert all(g is not None for g in grads.values())
+    return out, total, logits, ld, grads, crit.last_match
+
+
+@pytest.mark.parametrize("name", gu.STUDENT_GOLDENS)
+def test_fp32_step_matches_reference_golden(name):
+    fx, cfg, B = gu.load(name)
+    model = build(cfg, "fp32")
+    out, total, logits, ld, grads, match = run_step(model, cfg, B)
+    idx = (match[:, 0].cpu().tolist(), match[:, 1].cpu().tolist())
+    errs, gerrs = gu.check_against_golden(fx, out, float(total), logits, ld, grads, tol_out=TOL_FP32, tol_grad=5e-3, idx=idx)
+    print(name, "max output err", max(errs.values()), "max grad err", max(gerrs.values()))
+    # intermediate taps are not exposed by the fused path; outputs + 186 gradient norms pin every parameter's path
+
+
+def test_fp32_forward_is_deterministic():
+    fx, cfg, B = gu.load("vitb_t8")
+    model = build(cfg, "fp32")
+    o1, t1, l1, _, g1, _ = run_step(model, cfg, B)
+    o2, t2, l2, _, g2, _ = run_step(model, cfg, B)
+    assert torch.equal(o1[2][0], o2[2][0]) and torch.equal(t1, t2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n          # split-K / LN / colsum reductions have a fixed order (no atomics)
+
+
+@pytest.mark.parametrize("name", ["vitb_t8", "vits_t8"])
+def test_bf16_step_close_to_reference(name):
+    """bf16 storage / fp32 accumulate: not gated at 1e-3; bound the deviation and check the matching agrees."""
+    fx, cfg, B = gu.load(name)
+    model = build(cfg, "bf16")
+    out, total, logits, ld, grads, match = run_step(model, cfg, B)
+    e_logit = gu.rel(out[2][0].float().cpu(), fx["slots_head"])
+    e_total = abs(float(total) - float(fx["total_loss"])) / abs(float(fx["total_loss"]))
+    names = [str(n) for n in fx["param_names"]]
+    gn = np.array([float(grads[n].double().norm()) for n in names])
+    e_gn = np.abs(gn - fx["grad_norms"]) / np.maximum(fx["grad_norms"], 1e-6 * fx["grad_norms"].max())
+    print(f"{name} bf16: logits rel {e_logit:.3e}, total loss rel {e_total:.3e}, grad-norm rel median {np.median(e_gn):.3e} max {e_gn.max():.3e}")
+    assert e_logit < 5e-2 and e_total < 2e-2 and np.median(e_gn) < 5e-2
+    assert torch.isfinite(total).all()
+
+
+def test_surface_attributes_used_by_the_reference_driver():
+    """attributes run_slot_finetuning.py reads (:433,475-479,532,541) and the misspelt kwarg it passes (:386)"""
+    from devias_amd import create_model
+    m = create_model("slot_vit_base_patch16_224", pretrained=False, num_classes=400, all_frames=16, tubelet_size=2, fc_drop_rate=0.0,
+                     drop_rate=0.0, drop_path_rate=0.0, attn_drop_rate=0.0, drop_block_rate=None, use_checkpoint=False,
+                     init_scale=0.001, num_latents=2, head_type="linear", slot_matching="matching", agg_weights_tie=True,
+                     agg_depth=8, num_scene_classes=365)
+    assert m.patch_embed.patch_size == (16, 16) and m.patch_embed.num_patches == 1568 and m.patch_embed.tubelet_size == 2
+    assert tuple(m.pos_embed.shape) == (1, 1568, 768) and m.get_num_layers() == 12
+    assert m.no_weight_decay() == {"pos_embed", "cls_token"} and m.slot_matching_method == "matching"
+    with pytest.raises(ValueError):
+        create_model("slot_vit_base_patch16_224", slot_matching_method="bogus")
+    with pytest.raises(AssertionError):
+        m.cuda()(torch.zeros(1, 3, 16, 112, 112, device="cuda"))
