@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the DEVIAS slot-ViT training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = student forward (a1-a13) + fused matching loss (a14) + full backward to every parameter gradient
+(+ bucketed RCCL gradient all-reduce when N > 1) on ONE batch of 32 synthetic 16x224^2 clips per GPU, bf16 storage with
+fp32 accumulation, inputs resident in HBM before the timed region.  Teacher scene logits are an input tensor
+(primary metric of SURVEY.md §8d).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (dense; MI355X_MICROARCH.md chip table)
+TRAIN_GFLOP_PER_CLIP = {           # algorithmic (tied K/V once), BASELINE.md §3
+    ("vit_base", 16, 224): 1109.3, ("vit_small", 8, 224): 143.7, ("vit_large", 16, 224): 3617.4,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--model", default="vit_base", choices=["vit_base", "vit_small", "vit_large"])
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    from devias_amd import create_model, synth
+    name = {"vit_base": "slot_vit_base_patch16_224", "vit_small": "slot_vit_small_patch16_224",
+            "vit_large": "slot_vit_large_patch16_224"}[args.model]
+    model = create_model(name, num_classes=400, all_frames=args.frames, tubelet_size=2, drop_path_rate=0.0, init_scale=0.001,
+                         num_latents=2, head_type="linear", slot_matching="matching", agg_weights_tie=True, agg_depth=8,
+                         num_scene_classes=365, compute_dtype=args.dtype)
+    synth.fill_module_(model, seed=0)        # formula weights: identical on every rank, no broadcast needed
+    return model.to(device).train()
+
+
+def cpu_baseline(args):
+    """The oracle (a PyTorch-CPU restatement pinned to the reference by goldens) timed on this box's host cores on a bounded
+    sample of the same workload: B=2 clips, fp32, 1 warm-up + cpu_steps timed steps."""
+    from devias_amd import synth
+    from oracle import ref_cpu
+    kw = {"vit_base": {}, "vit_small": dict(embed_dim=384, num_heads=6), "vit_large": dict(embed_dim=1024, num_heads=16, depth=24)}[args.model]
+    cfg = ref_cpu.SlotViTConfig(all_frames=args.frames, **kw)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 2
+    P = synth.fill_params(ref_cpu.param_shapes(cfg), seed=0)
+    x = synth.video(B, cfg.all_frames, cfg.img_size)
+    y, tl, fg = synth.targets(B), synth.teacher_logits(B), synth.fg_masks(B, cfg.num_patches)
+    ref_cpu.train_step(P, cfg, x, y, tl, fg)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        ref_cpu.train_step(P, cfg, x, y, tl, fg)
+    dt = (time.perf_counter() - t0) / args.cpu_steps
+    return {"value": B / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/ref_cpu.py student fwd+loss+bwd, B={B} clips x {args.cpu_steps} timed steps (+1 warm-up), fp32, "
+                      f"{args.model} {args.frames}x224^2"}
+
+
+def dominant_kernel_probe(args, device):
+    """Live HIP-event timing (on torch's current stream = the stream the kernels are launched on) of the dominant kernel
+    class, the 128x128 MFMA GEMM, on the fc1 shape of this workload."""
+    from devias_amd import ops
+    D = {"vit_base": 768, "vit_small": 384, "vit_large": 1024}[args.model]
+    M = args.batch * (args.frames // 2) * 196
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    a = torch.randn(M, D, device=device).to(dt)
+    w = (torch.randn(4 * D, D, device=device) * 0.02).to(dt)
+    for _ in range(3):
+        ops.gemm(a, w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        ops.gemm(a, w)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    fl = 2.0 * M * 4 * D * D
+    return {"name": "gemm_kernel<bf16,NT,128x128x64> (fc1 shape)", "flop_per_launch": fl, "avg_ms": ms,
+            "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS}
+
+
+def main():
+    args = parse()
+    from devias_amd import synth
+    from devias_amd.parallel import GradSync, init_distributed_from_env
+    from devias_amd.train_loss import TrainLoss
+    rank, local, world = init_distributed_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    model = build_model(args, device)
+    B = args.batch
+    N = model.patch_embed.num_patches
+    first = rank * B                                   # rank r owns clips [B r, B r + B) of the global batch (weak scaling)
+    x = synth.video(B, args.frames, 224, seed=1000, first=first).to(device)
+    y = synth.targets(B, 400, seed=1000, first=first).to(device)
+    tl = synth.teacher_logits(B, 365, seed=1000, first=first).to(device)
+    fg196, fgN = (t.to(device) for t in synth.fg_masks(B, N, 196, seed=1000, first=first))
+    crit = TrainLoss(scene_criterion="KL", num_action_classes=400, slot_matching_method="matching", scene_loss_weight=4000,
+                     mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0, sync_loss_dict=False)
+    sync = GradSync(model) if world > 1 else None
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        out = model(x)
+        total, logits, ld = crit(model, out, (None, tl), y, fg_mask=(fg196, fgN))
+        total.backward()
+        if sync is not None:
+            sync.finish()
+        return total
+
+    for _ in range(args.warmup):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        loss = step()
+    e1.record()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    t = torch.tensor([wall], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t)
+    loss_value = float(loss.detach().float().sum())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    clips_per_s = world * B * args.steps / wall
+    gflop = TRAIN_GFLOP_PER_CLIP.get((args.model, args.frames, 224))
+    ach = clips_per_s / world * gflop / 1e3 if gflop else None       # per-GPU TFLOP/s
+    peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    line = {
+        "metric": "clips/sec fwd+bwd, ViT-B/16 16x224^2 slot head, bs=32/GPU" if args.model == "vit_base" and args.frames == 16
+                  else f"clips/sec fwd+bwd, {args.model} {args.frames}x224^2 slot head, bs={B}/GPU",
+        "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"slot-{args.model} 16-patch {args.frames}x224^2 ({N} tokens), S=2 slots, tied agg depth 8, "
+                               f"B={B} clips/GPU, student fwd + matching loss + bwd" + (" + RCCL grad all-reduce (fp32, 64 MiB buckets)" if world > 1 else ""),
+                   "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
+                   "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False},
+        "device_ms_per_step": dev_ms / args.steps, "final_loss": loss_value, "peak_mem_gib": peak_mem,
+    }
+    if ach is not None:
+        line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                            "scope": f"whole step per GPU: {gflop} algorithmic GFLOP/clip x {B} clips / step time",
+                            "dominant_kernel": dominant_kernel_probe(args, device)}
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

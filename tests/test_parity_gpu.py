@@ -68,7 +68,7 @@ def test_bf16_step_close_to_reference(name):
     fx, cfg, B = gu.load(name)
     model = build(cfg, "bf16")
     out, total, logits, ld, grads, match = run_step(model, cfg, B)
-    e_logit = gu.rel(out[2][0].float().cpu(), fx["slots_head"])
+    e_logit = gu.rel(out[2][0].detach().float().cpu(), fx["slots_head"])
     e_total = abs(float(total) - float(fx["total_loss"])) / abs(float(fx["total_loss"]))
     names = [str(n) for n in fx["param_names"]]
     gn = np.array([float(grads[n].double().norm()) for n in names])
