@@ -19,7 +19,8 @@ LIB = os.path.join(HERE, "libdevias_amd.so")
 SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "layernorm.hip", "attention.hip", "slot_attn.hip", "loss.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
-         "-fno-gpu-rdc", "-mllvm", "-amdgpu-early-inline-all=true"]
+         "-fno-gpu-rdc", "-mllvm", "-amdgpu-early-inline-all=true",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]   # keep MFMA accumulators in VGPRs: no v_accvgpr_* shuffles around the VALU epilogues
 
 
 def _stale() -> bool:

@@ -52,6 +52,8 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
     bf16x8 r = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
     return r;
 }
+// raw v_exp_f32: arguments here are <= 0 (or -inf), results below the normal range may flush to 0 -- harmless for softmax
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -155,14 +157,14 @@ __global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restri
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mnew = fmaxf(mrow[qt], mx);
-            const float alpha = exp2f(mrow[qt] - mnew);
+            const float alpha = fast_exp2(mrow[qt] - mnew);
             mrow[qt] = mnew;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = exp2f(acc_s[kt][qt][r] - mnew);
+                    float p = fast_exp2(acc_s[kt][qt][r] - mnew);
                     acc_s[kt][qt][r] = p;
                     ps += p;
                 }
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __res
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = exp2f(acc_s[kt][qt][r] * sl2 - lse2[qt]);
+                    float p = fast_exp2(acc_s[kt][qt][r] * sl2 - lse2[qt]);
                     if (tail && (k0 + 16 * kt + 4 * g + r >= N)) p = 0.f;
                     acc_s[kt][qt][r] = p * (acc_dp[kt][qt][r] - dl[qt]) * scale;   // dS^T (wrt raw q.k)
                 }
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = exp2f(acc_s[qt][kt][r] * sl2 - l4[r]);
+                    float p = fast_exp2(acc_s[qt][kt][r] * sl2 - l4[r]);
                     acc_s[qt][kt][r] = p;
                     acc_dp[qt][kt][r] = p * (acc_dp[qt][kt][r] - d4[r]) * scale;
                 }

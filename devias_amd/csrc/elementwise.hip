@@ -50,29 +50,58 @@ __global__ void im2col_kernel(const S* __restrict__ x, D* __restrict__ out, int 
 }
 
 // ---- column sums --------------------------------------------------------------------------------------
-// stage 1: block (64 cols x RB rows) -> partial[rb][n]; stage 2: out[n] = beta*out[n] + sum_rb partial
-enum { CS_ROWS = 512 };
+// stage 1: workgroup = 32 column lanes x 8 row lanes; each lane owns 8 consecutive columns (one 16-byte bf16 / two 16-byte
+// fp32 loads per row), so a wave reads 2 rows x 512 contiguous bytes per instruction.  CS_ROWS rows per workgroup ->
+// partial[rb][n]; stage 2: out[n] = beta*out[n] + sum_rb partial (fixed order).
+enum { CS_ROWS = 256, CS_COLS = 256 };
 template <typename T>
-__global__ void colsum_partial_kernel(const T* __restrict__ x, int M, int N, int ldx, float* __restrict__ part) {
-    // blockDim = (64, 4): 64 columns, 4 row lanes
-    __shared__ float sm[4][64];
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int M, int N, int ldx, float* __restrict__ part, int vec) {
+    __shared__ float sm[8][CS_COLS + 8];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n0 = blockIdx.x * CS_COLS + tx * 8;
+    const int r0 = blockIdx.y * CS_ROWS;
+    const int r1 = min(M, r0 + CS_ROWS);
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (vec && n0 + 7 < N) {
+        for (int r = r0 + ty; r < r1; r += 8) {
+            f32x4 a = load4(x + (int64_t)r * ldx + n0), b = load4(x + (int64_t)r * ldx + n0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += a[j]; s[4 + j] += b[j]; }
+        }
+    } else {
+        for (int r = r0 + ty; r < r1; r += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (n0 + j < N) s[j] += to_f32(x[(int64_t)r * ldx + n0 + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sm[ty][tx * 8 + j] = s[j];
+    __syncthreads();
+    const int c = threadIdx.x;              // 256 threads <-> 256 columns
+    const int n = blockIdx.x * CS_COLS + c;
+    if (n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][c];
+        part[(int64_t)blockIdx.y * N + n] = t;
+    }
+}
+// block (64 columns, 16 partial lanes)
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out, float beta) {
+    __shared__ float sm[16][64];
     int n = blockIdx.x * 64 + threadIdx.x;
-    int r0 = blockIdx.y * CS_ROWS;
-    int r1 = min(M, r0 + CS_ROWS);
     float s = 0.f;
     if (n < N)
-        for (int r = r0 + threadIdx.y; r < r1; r += 4) s += to_f32(x[(int64_t)r * ldx + n]);
+        for (int i = threadIdx.y; i < nparts; i += 16) s += part[(int64_t)i * N + n];
     sm[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.y == 0 && n < N)
-        part[(int64_t)blockIdx.y * N + n] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out, float beta) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += part[(int64_t)i * N + n];
-    out[n] = s + (beta != 0.f ? beta * out[n] : 0.f);
+    if (threadIdx.y == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][threadIdx.x];
+        out[n] = t + (beta != 0.f ? beta * out[n] : 0.f);
+    }
 }
 
 template <typename T>
@@ -179,11 +208,12 @@ extern "C" int devias_colsum(const void* x, int32_t dtype, int32_t M, int32_t N,
     hipStream_t st = (hipStream_t)stream;
     DEVIAS_REQUIRE(x && out && ws && M > 0 && N > 0, "devias_colsum: bad args");
     int nparts = cdiv(M, CS_ROWS);
-    dim3 g(cdiv(N, 64), nparts), b(64, 4);
-    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), g, b, 0, st, (const bf16*)x, M, N, ldx, ws);
-    else hipLaunchKernelGGL((colsum_partial_kernel<float>), g, b, 0, st, (const float*)x, M, N, ldx, ws);
+    dim3 g(cdiv(N, CS_COLS), nparts), b(256);
+    int vec = (ldx % 8 == 0) && aligned16(x);
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), g, b, 0, st, (const bf16*)x, M, N, ldx, ws, vec);
+    else hipLaunchKernelGGL((colsum_partial_kernel<float>), g, b, 0, st, (const float*)x, M, N, ldx, ws, vec);
     DEVIAS_CHECK_LAUNCH("devias_colsum(partial)");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, ws, nparts, N, out, beta);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64, 16), 0, st, ws, nparts, N, out, beta);
     DEVIAS_CHECK_LAUNCH("devias_colsum(final)");
     return DEVIAS_OK;
 }

@@ -10,6 +10,7 @@
 // The MFMA is issued as mfma(Bfrag, Afrag) so each lane ends up with 4 CONSECUTIVE output columns of one row
 // (8-byte bf16 / 16-byte f32 epilogue accesses, bias as one float4).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -302,6 +303,166 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmP p) {
     }
 }
 
+
+// =====================================================================================================================
+// 256 x 256 x 64 tile, 512 threads (8 waves as 2(M) x 4(N), 128 x 64 per wave), bf16 only, full tiles only.
+// Operands go global -> LDS directly with global_load_lds_dwordx4 (LDS-DMA: no VGPR staging, no ds_write pass) into a
+// 2-stage ring (2 x (32 KiB A + 32 KiB B) = 128 KiB, one workgroup per CU); ONE barrier per K-tile: the loads of tile
+// t+1 are issued right after the barrier that publishes tile t and fly during its 64 MFMAs per wave.
+// LDS-DMA writes 64 lanes x 16 B linearly, so the XOR swizzles of the two images are applied to the per-lane SOURCE
+// address (and again on the fragment reads): same images / same conflict-free reads as the 128 x 128 kernel.
+// =====================================================================================================================
+enum { T2 = 256, NT2 = 512, STAGE2 = 65536 };
+
+__device__ __forceinline__ int off_kc2(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ int off_ks2(int k, int col) { return k * 512 + ((((col >> 4) ^ ks_f(k))) << 5) + (col & 15) * 2; }
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+// issue the 4 LDS-DMA instructions this wave owns for one 256 x 64 operand tile
+template <bool KSTRIDED>
+__device__ __forceinline__ void glds_tile(const bf16* __restrict__ ptr, int ld, int r0, int k0, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (!KSTRIDED) {
+            const int r8 = wave * 32 + i * 8;                    // 8 rows x 128 B = 1 KiB per instruction
+            const int row = r8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ (row & 7);
+            const bf16* src = ptr + (int64_t)(r0 + row) * ld + k0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + r8 * 128), 16, 0, 0);
+        } else {
+            const int k2 = wave * 8 + i * 2;                     // 2 k-rows x 512 B = 1 KiB per instruction
+            const int k = k2 + (lane >> 5);
+            const int slot = lane & 31;
+            const int col = (((slot >> 1) ^ ks_f(k)) << 4) + (slot & 1) * 8;
+            const bf16* src = ptr + (int64_t)(k0 + k) * ld + r0 + col;
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + k2 * 512), 16, 0, 0);
+        }
+    }
+}
+
+template <bool KSTRIDED>
+__device__ __forceinline__ bf16x8 read_frag2(const char* lds, int base16, int ks, int lane) {
+    if constexpr (!KSTRIDED) {
+        int row = base16 + (lane & 15);
+        return *reinterpret_cast<const bf16x8*>(lds + off_kc2(row, ks * 4 + (lane >> 4)));
+    } else {
+        int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
+        int k = ks * 32 + g * 8 + q;
+        int col = base16 + 4 * p;
+        typedef __attribute__((address_space(3))) bf16x4* lp;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lds + off_ks2(k, col)));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lds + off_ks2(k + 4, col)));
+        bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tm = t / p.tiles_n, tn = t % p.tiles_n;
+    const int m0 = tm * T2, n0 = tn * T2;
+    const int z = blockIdx.y;
+    const int kbeg = z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg) / 64;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        glds_tile<TA>(A, p.lda, m0, kbeg, smem, wave, lane);
+        glds_tile<TB>(B, p.ldb, n0, kbeg, smem + 32768, wave, lane);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
+        __syncthreads();
+        char* cur = smem + (kt & 1) * STAGE2;
+        if (kt + 1 < nk) {
+            char* nxt = smem + ((kt + 1) & 1) * STAGE2;
+            glds_tile<TA>(A, p.lda, m0, kbeg + (kt + 1) * 64, nxt, wave, lane);
+            glds_tile<TB>(B, p.ldb, n0, kbeg + (kt + 1) * 64, nxt + 32768, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[8], fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag2<TB>(cur + 32768, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = read_frag2<TA>(cur, wm * 128 + i * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+        }
+    }
+
+    const int lm = lane & 15, ln = (lane >> 4) * 4;
+    if (p.split_k > 1) {
+        float* ws = p.ws + (int64_t)z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int m = m0 + wm * 128 + i * 16 + lm;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int n = n0 + wn * 64 + j * 16 + ln;
+                *reinterpret_cast<f32x4*>(ws + (int64_t)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+    const bf16* res = reinterpret_cast<const bf16*>(p.res);
+    const bf16* aux_in = reinterpret_cast<const bf16*>(p.aux_in);
+    bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + lm;
+        const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + ln;
+            f32x4 v = acc[i][j];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.act == DEVIAS_ACT_GELU) {
+                if (aux_out) store4(aux_out + (int64_t)m * p.ld_aux + n, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            } else if (p.act == DEVIAS_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (p.act == DEVIAS_ACT_SIGMOID) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+            } else if (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) {
+                f32x4 a = load4(aux_in + (int64_t)m * p.ld_aux + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = (p.act == DEVIAS_ACT_DGELU) ? v[r] * dgelu_f(a[r]) : (a[r] > 0.f ? v[r] : 0.f);
+            }
+            if (res) v += load4(res + (int64_t)mr * p.ldr + n);
+            if (p.c_f32) {
+                float* C = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+                if (p.beta != 0.f) { f32x4 o = *reinterpret_cast<f32x4*>(C); v += p.beta * o; }
+                *reinterpret_cast<f32x4*>(C) = v;
+            } else {
+                store4(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n, v);
+            }
+        }
+    }
+}
+
 // C[i] = beta*C[i] + sum_s ws[s][i]   (fixed summation order -> bitwise reproducible)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
                                      int splits, float beta) {
@@ -375,7 +536,18 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
                       (!a->aux_out || aligned16(a->aux_out)) && aligned16(a->C);
     p.vec_c = vc ? 1 : 0;
 
-    if (a->dtype == DEVIAS_BF16) {
+    static const int use256 = [] { const char* e = getenv("DEVIAS_GEMM256"); return e ? atoi(e) : 1; }();
+    const bool big = use256 && a->dtype == DEVIAS_BF16 && vec && vc && (a->M % T2 == 0) && (a->N % T2 == 0) && (a->K % 64 == 0) &&
+                     (p.k_per_split % 64 == 0);
+    if (big) {
+        p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;
+        dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(NT2);
+        const int ta = a->trans_a, tb = a->trans_b;
+        if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, block, 0, st, p);
+        else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, block, 0, st, p);
+        else if (ta && tb) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, block, 0, st, p);
+    } else if (a->dtype == DEVIAS_BF16) {
         if (vec) launch<bf16, true>(p, a->trans_a, a->trans_b, st);
         else launch<bf16, false>(p, a->trans_a, a->trans_b, st);
     } else {

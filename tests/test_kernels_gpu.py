@@ -33,7 +33,7 @@ TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True), (True, False)])
-@pytest.mark.parametrize("M,N,K", [(256, 384, 512), (130, 200, 72), (70, 765, 100), (4, 765, 768), (64, 196, 256), (300, 128, 4)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 512), (512, 256, 128), (256, 768, 192), (768, 512, 64), (130, 200, 72), (70, 765, 100), (4, 765, 768), (64, 196, 256), (300, 128, 4)])
 def test_gemm_layouts(dtype, ta, tb, M, N, K):
     o = ops()
     A = rnd(*((K, M) if ta else (M, K)), dtype=dtype, seed=1)
@@ -45,7 +45,7 @@ def test_gemm_layouts(dtype, ta, tb, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (100, 765, 96)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (510, 512, 256), (100, 765, 96)])
 def test_gemm_epilogues(dtype, M, N, K):
     o = ops()
     A, W = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, scale=0.2, seed=4)
@@ -76,7 +76,7 @@ def test_gemm_epilogues(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(2048, 96, 160), (5000, 768, 64), (64, 3072, 768), (4, 768, 2048)])
+@pytest.mark.parametrize("M,N,K", [(2048, 96, 160), (4096, 768, 512), (1024, 256, 256), (5000, 768, 64), (64, 3072, 768), (4, 768, 2048)])
 def test_wgrad_splitk_and_beta(dtype, M, N, K):
     o = ops()
     dY, X = rnd(M, N, dtype=dtype, seed=9), rnd(M, K, dtype=dtype, seed=10)
