@@ -22,9 +22,10 @@ struct GemmP {
     const float* bias; int act;
     const void* aux_in; void* aux_out; int ld_aux;
     const void* res; int ldr, res_mod;
-    float beta; int c_f32; int vec_c;
+    float beta; int c_f32; int vec_c; int vec16;
     float* ws; int k_per_split; int split_k;
     int tiles_m, tiles_n;
+    int debug;            // timing ablations only (DEVIAS_GEMM_DEBUG): 1 = one K-tile, 2 = no epilogue stores, 4 = no LDS-DMA after tile 0
 };
 
 template <typename T> struct Tr;
@@ -144,6 +145,91 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+
+// ---- LDS-staged epilogue (bf16 activations, full tiles, 16-byte aligned rows) ---------------------------------------
+// The MFMA layout gives each lane 4 columns of 16 different rows: stored directly that is 16 partial 128-B lines per
+// wave-instruction and the store path, not HBM, bounds the kernel (measured: 105 of 260 us on the QKV shape).  So the
+// accumulators (+bias) of one wave go through a private fp32 LDS region ([16*TPP rows][64 cols], 256-B rows, 16-B chunk
+// index XOR (row & 15): conflict-free both ways), TPP row-tiles per pass, and every global access of the epilogue --
+// C, the saved pre-activation, the residual, aux_in, split-K slabs -- is row-contiguous, 16 bytes per lane, whole lines.
+template <int NI, int TPP>
+__device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI][4], char* reg, int mrow0, int ncol0, int z, int lane) {
+    const int lm = lane & 15, g = lane >> 4;
+    const int rr = lane >> 3, c0 = (lane & 7) * 2;     // read-back: row inside an 8-row group, first of two 16-B chunks
+    const int ncol = ncol0 + (lane & 7) * 8;           // first of this lane's 8 output columns
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16* res = reinterpret_cast<const bf16*>(p.res);
+    const bf16* aux_in = reinterpret_cast<const bf16*>(p.aux_in);
+    bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
+#pragma unroll
+    for (int pass = 0; pass < NI / TPP; ++pass) {
+#pragma unroll
+        for (int i4 = 0; i4 < TPP; ++i4) {
+            const int row = i4 * 16 + lm;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(reg + row * 256 + (((4 * j + g) ^ (row & 15)) << 4)) = acc[pass * TPP + i4][j] + bias4[j];
+        }
+#pragma unroll
+        for (int it = 0; it < 2 * TPP; ++it) {
+            const int row = it * 8 + rr;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * 256 + ((c0 ^ (row & 15)) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * 256 + (((c0 + 1) ^ (row & 15)) << 4));
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const int m = mrow0 + pass * 16 * TPP + row;
+            if (p.split_k > 1) {
+                float* w = p.ws + ((int64_t)z * p.M + m) * p.N + ncol;
+                *reinterpret_cast<f32x4*>(w) = lo;
+                *reinterpret_cast<f32x4*>(w + 4) = hi;
+                continue;
+            }
+            if (p.act == DEVIAS_ACT_GELU) {
+                if (aux_out) {
+                    bf16x8 pre = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+                    *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            } else if (p.act == DEVIAS_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == DEVIAS_ACT_SIGMOID) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+            } else if (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) {
+                const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)m * p.ld_aux + ncol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = (float)a8[e];
+                    v[e] = (p.act == DEVIAS_ACT_DGELU) ? v[e] * dgelu_f(a) : (a > 0.f ? v[e] : 0.f);
+                }
+            }
+            if (res) {
+                const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+                const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + (int64_t)mr * p.ldr + ncol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+            }
+            if (p.c_f32) {
+                float* C = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + ncol;
+                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                if (p.beta != 0.f) {
+                    o0 += p.beta * *reinterpret_cast<const f32x4*>(C);
+                    o1 += p.beta * *reinterpret_cast<const f32x4*>(C + 4);
+                }
+                *reinterpret_cast<f32x4*>(C) = o0;
+                *reinterpret_cast<f32x4*>(C + 4) = o1;
+            } else {
+                bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
+            }
+        }
+    }
+}
+
 template <typename T, bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmP p) {
     typedef typename Tr<T>::frag frag;
@@ -203,6 +289,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmP p) {
         __syncthreads();
     }
 
+    if constexpr (sizeof(T) == 2) {
+        if (p.vec16 && m0 + BM <= p.M && n0 + BN <= p.N) {       // full tile, 16-byte aligned rows: LDS-staged epilogue
+            epilogue_staged<4, 2>(p, acc, smem + wave * 8192, m0 + wm * 64, n0 + wn * 64, z, lane);
+            return;
+        }
+    }
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + r], r = 0..3 ----------------
     const int lm = lane & 15, ln = (lane >> 4) * 4;
     if (p.split_k > 1) {
@@ -372,10 +464,13 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     const int z = blockIdx.y;
     const int kbeg = z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
-    const int nk = (kend - kbeg) / 64;
+    int nk = (kend - kbeg) / 64;
+    if (p.debug & 1) nk = min(nk, 1);
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+    if (p.debug & 8) st0 = __builtin_amdgcn_s_memrealtime();
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -387,10 +482,12 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
         glds_tile<TB>(B, p.ldb, n0, kbeg, smem + 32768, wave, lane);
     }
     for (int kt = 0; kt < nk; ++kt) {
+        if ((p.debug & 8) && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
         __syncthreads();
+        if ((p.debug & 8) && kt == 0) st2 = __builtin_amdgcn_s_memrealtime();
         char* cur = smem + (kt & 1) * STAGE2;
-        if (kt + 1 < nk) {
+        if (kt + 1 < nk && !(p.debug & 4)) {
             char* nxt = smem + ((kt + 1) & 1) * STAGE2;
             glds_tile<TA>(A, p.lda, m0, kbeg + (kt + 1) * 64, nxt, wave, lane);
             glds_tile<TB>(B, p.ldb, n0, kbeg + (kt + 1) * 64, nxt + 32768, wave, lane);
@@ -409,58 +506,23 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
         }
     }
 
-    const int lm = lane & 15, ln = (lane >> 4) * 4;
-    if (p.split_k > 1) {
-        float* ws = p.ws + (int64_t)z * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int m = m0 + wm * 128 + i * 16 + lm;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int n = n0 + wn * 64 + j * 16 + ln;
-                *reinterpret_cast<f32x4*>(ws + (int64_t)m * p.N + n) = acc[i][j];
-            }
-        }
-        return;
-    }
-    const bf16* res = reinterpret_cast<const bf16*>(p.res);
-    const bf16* aux_in = reinterpret_cast<const bf16*>(p.aux_in);
-    bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + lm;
-        const int mr = p.res_mod > 0 ? m % p.res_mod : m;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + ln;
-            f32x4 v = acc[i][j];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-            if (p.act == DEVIAS_ACT_GELU) {
-                if (aux_out) store4(aux_out + (int64_t)m * p.ld_aux + n, v);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-            } else if (p.act == DEVIAS_ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            } else if (p.act == DEVIAS_ACT_SIGMOID) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
-            } else if (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) {
-                f32x4 a = load4(aux_in + (int64_t)m * p.ld_aux + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = (p.act == DEVIAS_ACT_DGELU) ? v[r] * dgelu_f(a[r]) : (a[r] > 0.f ? v[r] : 0.f);
-            }
-            if (res) v += load4(res + (int64_t)mr * p.ldr + n);
-            if (p.c_f32) {
-                float* C = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
-                if (p.beta != 0.f) { f32x4 o = *reinterpret_cast<f32x4*>(C); v += p.beta * o; }
-                *reinterpret_cast<f32x4*>(C) = v;
-            } else {
-                store4(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n, v);
-            }
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    // The MFMA layout gives each lane 4 columns of 16 different rows: stored directly that is 16 partial 128-B lines per
+    // wave-instruction and the store path, not HBM, bounds the kernel (measured: 105 of 260 us on the QKV shape).  So the
+    // accumulators (+bias) go through LDS (the operand ring is dead by now: one 16 KiB fp32 region per wave, two passes of
+    // 64 rows) and every global access of the epilogue -- C, the saved pre-activation, the residual, aux_in, split-K slabs --
+    // is row-contiguous, 16 bytes per lane, whole 128-B lines.
+    if (p.debug & 8) {
+        st3 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 6;
+            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3;
+            d[4] = __builtin_amdgcn_s_getreg(0x1800 | 20) /* HW_REG_XCC_ID */; d[5] = t;
         }
     }
+    if ((p.debug & 2) && acc[0][0][0] != 12345.678f) return;
+    __syncthreads();                                   // every wave is done reading the operand stages
+    epilogue_staged<8, 4>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, z, lane);
 }
 
 // C[i] = beta*C[i] + sum_s ws[s][i]   (fixed summation order -> bitwise reproducible)
@@ -535,10 +597,21 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     if (es == 4) vc = vc && (!a->res || aligned16(a->res)) && (!a->aux_in || aligned16(a->aux_in)) &&
                       (!a->aux_out || aligned16(a->aux_out)) && aligned16(a->C);
     p.vec_c = vc ? 1 : 0;
+    { const char* e = getenv("DEVIAS_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
 
     static const int use256 = [] { const char* e = getenv("DEVIAS_GEMM256"); return e ? atoi(e) : 1; }();
-    const bool big = use256 && a->dtype == DEVIAS_BF16 && vec && vc && (a->M % T2 == 0) && (a->N % T2 == 0) && (a->K % 64 == 0) &&
-                     (p.k_per_split % 64 == 0);
+    // 16 bytes per lane in the staged epilogue (8 bf16 / 2 x 4 fp32): leading dims % 8 and 16-byte aligned bases
+    const bool v16 = vc && (a->N % 8 == 0) && (a->ldc % 8 == 0) && aligned16(a->C) && (!a->bias || aligned16(a->bias)) &&
+                     (!a->res || ((a->ldr % 8 == 0) && aligned16(a->res))) &&
+                     (!a->aux_in || ((a->ld_aux % 8 == 0) && aligned16(a->aux_in))) &&
+                     (!a->aux_out || ((a->ld_aux % 8 == 0) && aligned16(a->aux_out))) && (split == 1 || aligned16(a->ws));
+    p.vec16 = (v16 && a->dtype == DEVIAS_BF16) ? 1 : 0;
+    bool big = use256 && a->dtype == DEVIAS_BF16 && vec && vc && (a->M % T2 == 0) && (a->N % T2 == 0) && (a->K % 64 == 0) &&
+               (p.k_per_split % 64 == 0);
+    // measured on MI355X: the 256^2 tile wins once the grid is >= ~4 rounds of 256 CUs (or for the long-K wgrad reductions);
+    // below that its 1-workgroup-per-CU tail costs more than the 128^2 kernel's extra L2 traffic (use256 = 2 forces it)
+    if (use256 != 2 && !a->trans_a && (int64_t)(a->M / T2) * (a->N / T2) * split < 1000) big = false;
+    big = big && v16;
     if (big) {
         p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;
         dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(NT2);
