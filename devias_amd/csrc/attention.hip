@@ -141,36 +141,41 @@ __global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restri
                 for (int qt = 0; qt < 2; ++qt) acc_s[kt][qt] = mfma(kf, qf[qt][ks], acc_s[kt][qt]);
             }
         const int k0 = t * 64;
-        const bool tail = k0 + 64 > N;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float mx = -INFINITY;
+        if (k0 + 64 > N) {                    // ragged last tile only (wave-uniform branch): mask keys >= N
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float s = acc_s[kt][qt][r] * sl2;
-                    if (tail && (k0 + 16 * kt + 4 * g + r >= N)) s = -INFINITY;
-                    acc_s[kt][qt][r] = s;
-                    mx = fmaxf(mx, s);
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + 16 * kt + 4 * g + r >= N) { acc_s[kt][0][r] = -INFINITY; acc_s[kt][1][r] = -INFINITY; }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            // running max is kept in RAW score units; scale*log2(e) is folded into the exponent's FMA
+            float mx = fmaxf(fmaxf(acc_s[0][qt][0], acc_s[0][qt][1]), fmaxf(acc_s[0][qt][2], acc_s[0][qt][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt)
+                mx = fmaxf(mx, fmaxf(fmaxf(acc_s[kt][qt][0], acc_s[kt][qt][1]), fmaxf(acc_s[kt][qt][2], acc_s[kt][qt][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(mrow[qt], mx);
-            const float alpha = fast_exp2(mrow[qt] - mnew);
-            mrow[qt] = mnew;
+            if (__any(mx > mrow[qt])) {       // some row's max grew: rescale (rare after the first tiles)
+                const float mnew = fmaxf(mrow[qt], mx);
+                const float alpha = fast_exp2((mrow[qt] - mnew) * sl2);
+                mrow[qt] = mnew;
+                lrow[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
+            }
+            const float nb = -mrow[qt] * sl2;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = fast_exp2(acc_s[kt][qt][r] - mnew);
+                    const float p = fast_exp2(fmaf(acc_s[kt][qt][r], sl2, nb));
                     acc_s[kt][qt][r] = p;
                     ps += p;
                 }
-            lrow[qt] = lrow[qt] * alpha + ps;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
+            lrow[qt] += ps;
         }
         // O^T += V^T P^T
 #pragma unroll
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restri
             bf16* orow = o + ((int64_t)b * N + q) * D + h * 64 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt, acc_o[dt][qt] * inv);
-            if (g == 0) lse[((int64_t)b * H + h) * N + q] = (mrow[qt] + log2f(l)) * LN2;
+            if (g == 0) lse[((int64_t)b * H + h) * N + q] = (mrow[qt] * sl2 + log2f(l)) * LN2;
         }
     }
 }
@@ -279,16 +284,21 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __res
                 }
             }
         const int k0 = t * 64;
-        const bool tail = k0 + 64 > N;
+        if (k0 + 64 > N) {                    // ragged last tile only: p = exp2(-inf) = 0 for keys >= N
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + 16 * kt + 4 * g + r >= N) { acc_s[kt][0][r] = -INFINITY; acc_s[kt][1][r] = -INFINITY; }
+        }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = fast_exp2(acc_s[kt][qt][r] * sl2 - lse2[qt]);
-                    if (tail && (k0 + 16 * kt + 4 * g + r >= N)) p = 0.f;
-                    acc_s[kt][qt][r] = p * (acc_dp[kt][qt][r] - dl[qt]) * scale;   // dS^T (wrt raw q.k)
+                    const float p = fast_exp2(fmaf(acc_s[kt][qt][r], sl2, -lse2[qt]));
+                    acc_s[kt][qt][r] = p * (acc_dp[kt][qt][r] - dl[qt]);       // dS^T / scale (scale applied once at the end)
                 }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __res
         if (q < N) {
             bf16* row = dqkv + ((int64_t)b * N + q) * RS + h * 64 + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt, acc_dq[dt][qt]);
+            for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt, acc_dq[dt][qt] * scale);
         }
     }
 }
@@ -400,9 +410,9 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = fast_exp2(acc_s[qt][kt][r] * sl2 - l4[r]);
+                    const float p = fast_exp2(fmaf(acc_s[qt][kt][r], sl2, -l4[r]));
                     acc_s[qt][kt][r] = p;
-                    acc_dp[qt][kt][r] = p * (acc_dp[qt][kt][r] - d4[r]) * scale;
+                    acc_dp[qt][kt][r] = p * (acc_dp[qt][kt][r] - d4[r]);            // dS / scale (scale applied once at the end)
                 }
         }
 #pragma unroll
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             bf16* row = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                store4(row + D + 16 * dt, acc_dk[dt][kt]);
+                store4(row + D + 16 * dt, acc_dk[dt][kt] * scale);
                 store4(row + 2 * D + 16 * dt, acc_dv[dt][kt]);
             }
         }

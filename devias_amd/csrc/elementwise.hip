@@ -139,7 +139,7 @@ template <typename T>
 __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, int64_t n, int act) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float g = to_f32(dy[i]), v = to_f32(y[i]);
-        float r = act == DEVIAS_ACT_SIGMOID ? g * v * (1.0f - v) : act == DEVIAS_ACT_RELU ? (v > 0.f ? g : 0.f) : g * dgelu_f(v);
+        float r = act == DEVIAS_ACT_SIGMOID ? g * v * (1.0f - v) : act == DEVIAS_ACT_RELU ? (v > 0.f ? g : 0.f) : g * dgelu_t<T>(v);
         dx[i] = from_f32<T>(r);
     }
 }

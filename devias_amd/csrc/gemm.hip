@@ -192,7 +192,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
                     *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
             } else if (p.act == DEVIAS_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -204,7 +204,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float a = (float)a8[e];
-                    v[e] = (p.act == DEVIAS_ACT_DGELU) ? v[e] * dgelu_f(a) : (a > 0.f ? v[e] : 0.f);
+                    v[e] = (p.act == DEVIAS_ACT_DGELU) ? v[e] * dgelu_fast(a) : (a > 0.f ? v[e] : 0.f);
                 }
             }
             if (res) {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmP p) {
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = gelu_t<T>(v[r]);
             } else if (p.act == DEVIAS_ACT_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmP p) {
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    v[r] = (p.act == DEVIAS_ACT_DGELU) ? v[r] * dgelu_f(a[r]) : (a[r] > 0.f ? v[r] : 0.f);
+                    v[r] = (p.act == DEVIAS_ACT_DGELU) ? v[r] * dgelu_t<T>(a[r]) : (a[r] > 0.f ? v[r] : 0.f);
             }
             if (res) {
                 if (full) { f32x4 rr = load4(res + (int64_t)mr * p.ldr + n); v += rr; }
@@ -525,6 +525,108 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     epilogue_staged<8, 4>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, z, lane);
 }
 
+
+// =====================================================================================================================
+// 256 x 128 x 64 tile, 256 threads (4 waves as 2(M) x 2(N), 128 x 64 per wave), ONE 48 KiB LDS stage filled by LDS-DMA,
+// three workgroups per CU: load/compute overlap and -- the point -- epilogue/compute overlap come from the co-resident
+// workgroups (independent waves, independent vmcnt), not from an in-kernel software pipeline.
+// =====================================================================================================================
+enum { SS_BM = 256, SS_BN = 128, SS_NT = 256, SS_ABYTES = 32768, SS_BBYTES = 16384 };
+
+template <bool KSTRIDED, int ROWS>      // ROWS = extent of the non-K dim of the tile (256 for A, 128 for B)
+__device__ __forceinline__ void glds_tile_ss(const bf16* __restrict__ ptr, int ld, int r0, int k0, char* lds, int wave, int lane) {
+    constexpr int NI = ROWS * 128 / 1024 / 4;          // 1-KiB instructions per wave (4 waves)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if constexpr (!KSTRIDED) {
+            const int r8 = (wave * NI + i) * 8;
+            const int row = r8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ (row & 7);
+            const bf16* src = ptr + (int64_t)(r0 + row) * ld + k0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + r8 * 128), 16, 0, 0);
+        } else {
+            constexpr int RB = ROWS * 2;                 // bytes per k-row
+            constexpr int KPI = 1024 / RB;               // k-rows per instruction (2 for 256 cols, 4 for 128 cols)
+            const int kb = (wave * NI + i) * KPI;
+            const int k = kb + lane / (64 / KPI);
+            const int slot = lane % (64 / KPI);          // 16-byte slot inside the row
+            const int col = (((slot >> 1) ^ ks_f(k)) << 4) + (slot & 1) * 8;
+            const bf16* src = ptr + (int64_t)(k0 + k) * ld + r0 + col;
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + kb * RB), 16, 0, 0);
+        }
+    }
+}
+
+template <bool KSTRIDED, int ROWS>
+__device__ __forceinline__ bf16x8 read_frag_ss(const char* lds, int base16, int ks, int lane) {
+    if constexpr (!KSTRIDED) {
+        int row = base16 + (lane & 15);
+        return *reinterpret_cast<const bf16x8*>(lds + off_kc2(row, ks * 4 + (lane >> 4)));
+    } else {
+        int g = lane >> 4, t = lane & 15, q = t >> 2, p = t & 3;
+        int k = ks * 32 + g * 8 + q;
+        int col = base16 + 4 * p;
+        typedef __attribute__((address_space(3))) bf16x4* lp;
+        constexpr int RB = ROWS * 2;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lds + k * RB + ((((col >> 4) ^ ks_f(k))) << 5) + (col & 15) * 2));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(lds + (k + 4) * RB + ((((col >> 4) ^ ks_f(k + 4))) << 5) + (col & 15) * 2));
+        bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+    }
+}
+
+template <bool TA, bool TB, int OCC>
+__global__ __launch_bounds__(SS_NT, OCC) void gemm_ss_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[SS_ABYTES + SS_BBYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tm = t / p.tiles_n, tn = t % p.tiles_n;
+    const int m0 = tm * SS_BM, n0 = tn * SS_BN;
+    const int z = blockIdx.y;
+    const int kbeg = z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg) / 64;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    char* ldsA = smem;
+    char* ldsB = smem + SS_ABYTES;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt > 0) __syncthreads();                         // every wave is done reading the previous K-tile
+        glds_tile_ss<TA, SS_BM>(A, p.lda, m0, kbeg + kt * 64, ldsA, wave, lane);
+        glds_tile_ss<TB, SS_BN>(B, p.ldb, n0, kbeg + kt * 64, ldsB, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag_ss<TB, SS_BN>(ldsB, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                bf16x8 fa[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = read_frag_ss<TA, SS_BM>(ldsA, wm * 128 + (ih * 4 + i) * 16, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ih * 4 + i][j] = mfma16(fb[j], fa[i], acc[ih * 4 + i][j]);
+            }
+        }
+    }
+    __syncthreads();
+    epilogue_staged<8, 2>(p, acc, smem + wave * 12288, m0 + wm * 128, n0 + wn * 64, z, lane);
+}
+
 // C[i] = beta*C[i] + sum_s ws[s][i]   (fixed summation order -> bitwise reproducible)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
                                      int splits, float beta) {
@@ -608,11 +710,34 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     p.vec16 = (v16 && a->dtype == DEVIAS_BF16) ? 1 : 0;
     bool big = use256 && a->dtype == DEVIAS_BF16 && vec && vc && (a->M % T2 == 0) && (a->N % T2 == 0) && (a->K % 64 == 0) &&
                (p.k_per_split % 64 == 0);
-    // measured on MI355X: the 256^2 tile wins once the grid is >= ~4 rounds of 256 CUs (or for the long-K wgrad reductions);
-    // below that its 1-workgroup-per-CU tail costs more than the 128^2 kernel's extra L2 traffic (use256 = 2 forces it)
-    if (use256 != 2 && !a->trans_a && (int64_t)(a->M / T2) * (a->N / T2) * split < 1000) big = false;
     big = big && v16;
-    if (big) {
+    // Kernel choice, measured on MI355X at the ViT-B shapes (M = 50176; tools/gemm_ablate.py):
+    //   * 256x128 single-stage kernel (2 workgroups/CU): best for every dgrad (B k-strided) and wgrad (both k-strided) shape
+    //     and for NT shapes with a small grid (proj) -- co-resident workgroups hide each other's HBM-write-bound epilogue;
+    //   * 256x256 two-stage kernel (1 workgroup/CU): best steady state (1.38 PFLOP/s per K-tile), wins the NT forward
+    //     GEMMs with >= ~4 rounds of 256 tiles (qkv, fc1, fc2, agg K|V);
+    //   * 128x128 register-staged kernel: ragged / unaligned / fp32 shapes.
+    // DEVIAS_GEMM_SS = 0 disables / 1 forces the single-stage kernel; DEVIAS_GEMM256 = 0 disables / 2 forces the 256^2 kernel.
+    static const int use_ss = [] { const char* e = getenv("DEVIAS_GEMM_SS"); return e ? atoi(e) : -1; }();
+    bool ss = use_ss != 0 && a->dtype == DEVIAS_BF16 && vec && v16 && (a->M % SS_BM == 0) && (a->N % SS_BN == 0) && (a->K % 64 == 0) &&
+              (p.k_per_split % 64 == 0);
+    if (ss && use_ss < 0 && use256 != 2) {
+        const bool nt = !a->trans_a && !a->trans_b;
+        if (nt && big && (int64_t)(a->M / T2) * (a->N / T2) * split >= 1000) ss = false;     // 256^2 wins the big NT grids
+    }
+    if (use256 == 2 && big) ss = false;
+    if (ss) {
+        p.tiles_m = a->M / SS_BM; p.tiles_n = a->N / SS_BN;
+        dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(SS_NT);
+        const int ta = a->trans_a, tb = a->trans_b;
+#define SS_LAUNCH(OCC)                                                                                      \
+        if (!ta && !tb) hipLaunchKernelGGL((gemm_ss_kernel<false, false, OCC>), grid, block, 0, st, p);     \
+        else if (!ta && tb) hipLaunchKernelGGL((gemm_ss_kernel<false, true, OCC>), grid, block, 0, st, p);  \
+        else if (ta && tb) hipLaunchKernelGGL((gemm_ss_kernel<true, true, OCC>), grid, block, 0, st, p);    \
+        else hipLaunchKernelGGL((gemm_ss_kernel<true, false, OCC>), grid, block, 0, st, p)
+        SS_LAUNCH(2);
+#undef SS_LAUNCH
+    } else if (big) {
         p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;
         dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(NT2);
         const int ta = a->trans_a, tb = a->trans_b;
