@@ -25,6 +25,8 @@ struct GemmP {
     float beta; int c_f32; int vec_c; int vec16;
     float* ws; int k_per_split; int split_k;
     int tiles_m, tiles_n;
+    int group_m;          // tile rasterisation: GM row-tiles per group (m fastest inside a group); 1 = n fastest
+    int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
     int debug;            // timing ablations only (DEVIAS_GEMM_DEBUG): 1 = one K-tile, 2 = no epilogue stores, 4 = no LDS-DMA after tile 0
 };
 
@@ -228,6 +230,19 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
             }
         }
     }
+}
+
+
+// tile id -> (tm, tn): groups of GM row-tiles, m fastest inside a group (GM = 1: n fastest)
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
+    if (GM <= 1) { tm = t / tiles_n; tn = t % tiles_n; return; }
+    const int per_group = GM * tiles_n;
+    const int group = t / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int r = t - group * per_group;
+    tm = first_m + r % gsz;
+    tn = r / gsz;
 }
 
 template <typename T, bool TA, bool TB, bool VEC>
@@ -459,7 +474,8 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int t = xcd_remap(blockIdx.x, ntiles);
-    const int tm = t / p.tiles_n, tn = t % p.tiles_n;
+    int tm, tn;
+    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     const int m0 = tm * T2, n0 = tn * T2;
     const int z = blockIdx.y;
     const int kbeg = z * p.k_per_split;
@@ -583,7 +599,8 @@ __global__ __launch_bounds__(SS_NT, OCC) void gemm_ss_kernel(GemmP p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int t = xcd_remap(blockIdx.x, ntiles);
-    const int tm = t / p.tiles_n, tn = t % p.tiles_n;
+    int tm, tn;
+    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     const int m0 = tm * SS_BM, n0 = tn * SS_BN;
     const int z = blockIdx.y;
     const int kbeg = z * p.k_per_split;
@@ -626,6 +643,7 @@ __global__ __launch_bounds__(SS_NT, OCC) void gemm_ss_kernel(GemmP p) {
     __syncthreads();
     epilogue_staged<8, 2>(p, acc, smem + wave * 12288, m0 + wm * 128, n0 + wn * 64, z, lane);
 }
+
 
 // C[i] = beta*C[i] + sum_s ws[s][i]   (fixed summation order -> bitwise reproducible)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
@@ -700,6 +718,12 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
                       (!a->aux_out || aligned16(a->aux_out)) && aligned16(a->C);
     p.vec_c = vc ? 1 : 0;
     { const char* e = getenv("DEVIAS_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
+    {   // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
+        // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
+        static const int gm = [] { const char* e = getenv("DEVIAS_GEMM_GROUPM"); return e ? atoi(e) : 0; }();
+        p.group_m = gm > 0 ? gm : ((!a->trans_a && a->N >= 2048) ? 8 : 1);
+    }
+    { static const int nt = [] { const char* e = getenv("DEVIAS_GEMM_NTA"); return e ? atoi(e) : 0; }(); p.nt_a = nt; }
 
     static const int use256 = [] { const char* e = getenv("DEVIAS_GEMM256"); return e ? atoi(e) : 1; }();
     // 16 bytes per lane in the staged epilogue (8 bf16 / 2 x 4 fp32): leading dims % 8 and 16-byte aligned bases
