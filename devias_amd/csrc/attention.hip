@@ -58,35 +58,38 @@ __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// stage a [64][64] bf16 tile: 512 16-byte chunks, 2 per thread.  rows >= nrows are zero-filled.
+// stage a [64][64] bf16 tile: 512 16-byte chunks, 512/NT per thread.  rows >= nrows are zero-filled.
+template <int NT>
 struct TileRegs {
-    u32x4 v[2];
+    enum { NCH = 512 / NT };
+    u32x4 v[NCH];
     __device__ __forceinline__ void load(const bf16* __restrict__ base, int64_t row_stride, int row0, int nrows, int tid) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int c = tid + i * 256, row = c >> 3, ch = c & 7;
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NT, row = c >> 3, ch = c & 7;
             u32x4 z = {0u, 0u, 0u, 0u};
             v[i] = (row0 + row < nrows) ? *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + row) * row_stride + ch * 8) : z;
         }
     }
     __device__ __forceinline__ void store_rows(char* img, int tid) const {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int c = tid + i * 256, row = c >> 3, ch = c & 7;
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NT, row = c >> 3, ch = c & 7;
             *reinterpret_cast<u32x4*>(img + img_row_off(row, ch)) = v[i];
         }
     }
     __device__ __forceinline__ void store_tr(char* img, int tid) const {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int c = tid + i * 256, row = c >> 3, ch = c & 7;
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + i * NT, row = c >> 3, ch = c & 7;
             *reinterpret_cast<u32x4*>(img + img_tr_off(row, ch * 8)) = v[i];
         }
     }
 };
 
 // ======================================= forward (bf16) ===================================================
-__global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+template <int QT, int NW>
+__global__ __launch_bounds__(NW * 64) void mhsa_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                             float* __restrict__ lse, int N, int H, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[16384];
     char* imgK = smem;            // row image of K tile  [key][d]
@@ -96,26 +99,28 @@ __global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restri
     const int D = H * 64;
     const int64_t RS = 3 * (int64_t)D;
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (NW * 16 * QT) + wave * (16 * QT);
     const float sl2 = scale * LOG2E;
 
-    bf16x8 qf[2][2];
+    bf16x8 qf[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         int q = min(q0 + 16 * qt + c, N - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             qf[qt][ks] = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * RS + 32 * ks + 8 * g);
     }
-    f32x4 acc_o[4][2];
+    f32x4 acc_o[4][QT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc_o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+        for (int j = 0; j < QT; ++j) acc_o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[QT], lrow[QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) { mrow[j] = -INFINITY; lrow[j] = 0.f; }
 
     const int nkv = (N + 63) / 64;
-    TileRegs rk, rv;
+    TileRegs<NW * 64> rk, rv;
     rk.load(base + D, RS, 0, N, tid);
     rv.load(base + 2 * D, RS, 0, N, tid);
     for (int t = 0; t < nkv; ++t) {
@@ -127,18 +132,18 @@ __global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restri
             rv.load(base + 2 * D, RS, (t + 1) * 64, N, tid);
         }
         // S^T tile: acc_s[kt][qt] holds keys 16kt + 4g + r (rows) x query c (col)
-        f32x4 acc_s[4][2];
+        f32x4 acc_s[4][QT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < QT; ++j) acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 bf16x8 kf = frag_rows(imgK, 16 * kt, ks, lane);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) acc_s[kt][qt] = mfma(kf, qf[qt][ks], acc_s[kt][qt]);
+                for (int qt = 0; qt < QT; ++qt) acc_s[kt][qt] = mfma(kf, qf[qt][ks], acc_s[kt][qt]);
             }
         const int k0 = t * 64;
         if (k0 + 64 > N) {                    // ragged last tile only (wave-uniform branch): mask keys >= N
@@ -146,10 +151,13 @@ __global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restri
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (k0 + 16 * kt + 4 * g + r >= N) { acc_s[kt][0][r] = -INFINITY; acc_s[kt][1][r] = -INFINITY; }
+                    if (k0 + 16 * kt + 4 * g + r >= N) {
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) acc_s[kt][qt][r] = -INFINITY;
+                    }
         }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             // running max is kept in RAW score units; scale*log2(e) is folded into the exponent's FMA
             float mx = fmaxf(fmaxf(acc_s[0][qt][0], acc_s[0][qt][1]), fmaxf(acc_s[0][qt][2], acc_s[0][qt][3]));
 #pragma unroll
@@ -180,20 +188,20 @@ __global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restri
         // O^T += V^T P^T
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 pf[2];
+            bf16x8 pf[QT];
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) pf[qt] = pack8(acc_s[2 * s][qt], acc_s[2 * s + 1][qt]);
+            for (int qt = 0; qt < QT; ++qt) pf[qt] = pack8(acc_s[2 * s][qt], acc_s[2 * s + 1][qt]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 bf16x8 vf = frag_tr(imgV, 16 * dt, s, lane);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) acc_o[dt][qt] = mfma(vf, pf[qt], acc_o[dt][qt]);
+                for (int qt = 0; qt < QT; ++qt) acc_o[dt][qt] = mfma(vf, pf[qt], acc_o[dt][qt]);
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float l = lrow[qt];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
@@ -209,7 +217,8 @@ __global__ __launch_bounds__(256) void mhsa_fwd_bf16_kernel(const bf16* __restri
 }
 
 // ======================================= backward dQ (bf16) ==============================================
-__global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+template <int QT, int NW>
+__global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                                int N, int H, float scale) {
@@ -222,13 +231,13 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __res
     const int D = H * 64;
     const int64_t RS = 3 * (int64_t)D;
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (NW * 16 * QT) + wave * (16 * QT);
     const float sl2 = scale * LOG2E;
 
-    bf16x8 qf[2][2], dof[2][2];
-    float lse2[2], dl[2];
+    bf16x8 qf[QT][2], dof[QT][2];
+    float lse2[QT], dl[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         int q = min(q0 + 16 * qt + c, N - 1);
         const bf16* orow = o + ((int64_t)b * N + q) * D + h * 64;
         const bf16* dorow = d_o + ((int64_t)b * N + q) * D + h * 64;
@@ -247,14 +256,14 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __res
         lse2[qt] = lse[((int64_t)b * H + h) * N + q] * LOG2E;
         if (g == 0 && q0 + 16 * qt + c < N) delta[((int64_t)b * H + h) * N + q] = part;
     }
-    f32x4 acc_dq[4][2];
+    f32x4 acc_dq[4][QT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc_dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < QT; ++j) acc_dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkv = (N + 63) / 64;
-    TileRegs rk, rv;
+    TileRegs<NW * 64> rk, rv;
     rk.load(base + D, RS, 0, N, tid);
     rv.load(base + 2 * D, RS, 0, N, tid);
     for (int t = 0; t < nkv; ++t) {
@@ -266,11 +275,11 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __res
             rk.load(base + D, RS, (t + 1) * 64, N, tid);
             rv.load(base + 2 * D, RS, (t + 1) * 64, N, tid);
         }
-        f32x4 acc_s[4][2], acc_dp[4][2];
+        f32x4 acc_s[4][QT], acc_dp[4][QT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int j = 0; j < QT; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __res
                 bf16x8 kf = frag_rows(imgK, 16 * kt, ks, lane);
                 bf16x8 vf = frag_rows(imgV, 16 * kt, ks, lane);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     acc_s[kt][qt] = mfma(kf, qf[qt][ks], acc_s[kt][qt]);
                     acc_dp[kt][qt] = mfma(vf, dof[qt][ks], acc_dp[kt][qt]);
                 }
@@ -289,10 +298,13 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __res
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (k0 + 16 * kt + 4 * g + r >= N) { acc_s[kt][0][r] = -INFINITY; acc_s[kt][1][r] = -INFINITY; }
+                    if (k0 + 16 * kt + 4 * g + r >= N) {
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) acc_s[kt][qt][r] = -INFINITY;
+                    }
         }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -302,20 +314,20 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_bf16_kernel(const bf16* __res
                 }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 dsf[2];
+            bf16x8 dsf[QT];
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) dsf[qt] = pack8(acc_s[2 * s][qt], acc_s[2 * s + 1][qt]);
+            for (int qt = 0; qt < QT; ++qt) dsf[qt] = pack8(acc_s[2 * s][qt], acc_s[2 * s + 1][qt]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 bf16x8 kf = frag_tr(imgKt, 16 * dt, s, lane);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) acc_dq[dt][qt] = mfma(kf, dsf[qt], acc_dq[dt][qt]);
+                for (int qt = 0; qt < QT; ++qt) acc_dq[dt][qt] = mfma(kf, dsf[qt], acc_dq[dt][qt]);
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const int q = q0 + 16 * qt + c;
         if (q < N) {
             bf16* row = dqkv + ((int64_t)b * N + q) * RS + h * 64 + 4 * g;
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
     const int nq = (N + 63) / 64;
     const float* lse_bh = lse + ((int64_t)b * H + h) * N;
     const float* dl_bh = delta + ((int64_t)b * H + h) * N;
-    TileRegs rq, rdo;
+    TileRegs<256> rq, rdo;
     float rstat = 0.f;
     rq.load(base, RS, 0, N, tid);
     rdo.load(dobase, D, 0, N, tid);
@@ -625,7 +637,13 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
     DEVIAS_REQUIRE(aligned16(qkv) && aligned16(o), "devias_mhsa_fwd: qkv/o must be 16-byte aligned");
     DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_fwd: H and B must be <= 65535");
     if (dtype == DEVIAS_BF16)
-        hipLaunchKernelGGL(mhsa_fwd_bf16_kernel, dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        {
+        static const int cfg = [] { const char* e = getenv("DEVIAS_ATTN_CFG"); return e ? atoi(e) : 0; }();
+        if (cfg == 1) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 2>), dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        else if (cfg == 2) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 4>), dim3(cdiv(N, 256), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        else if (cfg == 3) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 2>), dim3(cdiv(N, 64), H, B), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        else hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+    }
     else if (dtype == DEVIAS_F32)
         hipLaunchKernelGGL(mhsa_fwd_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (float*)o, lse, N, H, scale);
     else return devias_set_error(DEVIAS_EINVAL, "devias_mhsa_fwd: bad dtype %d", dtype);
@@ -640,8 +658,13 @@ extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, 
     DEVIAS_REQUIRE(aligned16(qkv) && aligned16(o) && aligned16(d_o) && aligned16(dqkv), "devias_mhsa_bwd: unaligned pointer");
     DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_bwd: H and B must be <= 65535");
     if (dtype == DEVIAS_BF16) {
-        hipLaunchKernelGGL(mhsa_bwd_dq_bf16_kernel, dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)o,
-                           (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale);
+        static const int cfg = [] { const char* e = getenv("DEVIAS_ATTN_CFG"); return e ? atoi(e) : 0; }();
+#define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale
+        if (cfg == 1) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 2>), dim3(cdiv(N, 128), H, B), dim3(128), 0, st, DQ_ARGS);
+        else if (cfg == 2) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 4>), dim3(cdiv(N, 256), H, B), dim3(256), 0, st, DQ_ARGS);
+        else if (cfg == 3) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 2>), dim3(cdiv(N, 64), H, B), dim3(128), 0, st, DQ_ARGS);
+        else hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 4>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, DQ_ARGS);
+#undef DQ_ARGS
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");
         hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel, dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
                            lse, delta, (bf16*)dqkv, N, H, scale);

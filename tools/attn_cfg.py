@@ -1,0 +1,28 @@
+import os, sys, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import torch
+    from devias_amd import ops as o
+    from tools.microbench import timeit
+    B, N, H = 32, 1568, 12
+    qkv = torch.randn(B * N, 3 * H * 64, device="cuda").bfloat16()
+    out, lse = o.mhsa_fwd(qkv, B, N, H, 0.125)
+    do = torch.randn_like(out)
+    fl = 4.0 * B * H * N * N * 64 / 1e9
+    t = timeit(lambda: o.mhsa_fwd(qkv, B, N, H, 0.125), iters=20)
+    t2 = timeit(lambda: o.mhsa_bwd(qkv, out, do, lse, B, N, H, 0.125), iters=20)
+    # correctness spot check vs cfg-independent torch reference on a small case
+    q2 = torch.randn(2 * 200, 3 * 2 * 64, device="cuda").bfloat16()
+    o2, l2 = o.mhsa_fwd(q2, 2, 200, 2, 0.125)
+    q, k, v = q2.float().reshape(2, 200, 3, 2, 64).permute(2, 0, 3, 1, 4)
+    ref = ((q * 0.125) @ k.transpose(-1, -2)).softmax(-1) @ v
+    err = (o2.float().reshape(2, 200, 2, 64).permute(0, 2, 1, 3) - ref).abs().max().item()
+    print(f"  fwd {t*1e3:7.1f} us {fl/t:7.1f} TF | bwd {t2*1e3:7.1f} us {2.5*fl/t2:7.1f} TF (algorithmic)  err {err:.3e}")
+else:
+    for env in sys.argv[1:]:
+        e = dict(os.environ)
+        for kv in env.split(","):
+            if "=" in kv:
+                k, v = kv.split("="); e[k] = v
+        print(f"== {env}"); sys.stdout.flush()
+        subprocess.run([sys.executable, __file__, "child"], env=e)
