@@ -30,6 +30,7 @@ class GemmArgs(Structure):
         ("aux_in", c_void_p), ("aux_out", c_void_p), ("ld_aux", c_int32),
         ("res", c_void_p), ("ldr", c_int32), ("res_mod", c_int32),
         ("beta", c_float), ("split_k", c_int32), ("ws", c_void_p),
+        ("colsum", c_void_p), ("colsum_beta", c_float),
     ]
 
 
@@ -55,7 +56,7 @@ PROTOTYPES = {
     "devias_act_bwd": (c_int, [_P, _P, _P, _I, _I, _L, _P]),
     "devias_add": (c_int, [_P, _P, _P, _I, _L, _P]),
     "devias_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
-    "devias_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P]),
+    "devias_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P, _P]),
     "devias_layernorm_bwd_workspace_bytes": (c_int64, [_I, _I]),
     "devias_mhsa_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "devias_mhsa_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),

@@ -25,6 +25,7 @@ struct GemmP {
     float beta; int c_f32; int vec_c; int vec16;
     float* ws; int k_per_split; int split_k;
     int tiles_m, tiles_n;
+    float* colsum_part;   // optional: per-(wave row-tile) partial column sums of the stored output, [M / (16*NI)][N]
     int group_m;          // tile rasterisation: GM row-tiles per group (m fastest inside a group); 1 = n fastest
     int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
     int debug;            // timing ablations only (DEVIAS_GEMM_DEBUG): 1 = one K-tile, 2 = no epilogue stores, 4 = no LDS-DMA after tile 0
@@ -166,6 +167,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
     const bf16* res = reinterpret_cast<const bf16*>(p.res);
     const bf16* aux_in = reinterpret_cast<const bf16*>(p.aux_in);
     bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // column sums of what this lane stores (bias gradient fusion)
 #pragma unroll
     for (int pass = 0; pass < NI / TPP; ++pass) {
 #pragma unroll
@@ -215,6 +217,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += v[e];
             if (p.c_f32) {
                 float* C = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + ncol;
                 f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
@@ -228,6 +232,20 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
                 bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
             }
+        }
+    }
+    if (p.colsum_part && p.split_k == 1) {
+        // lanes with equal (lane & 7) own the same 8 columns (rows differ): fold the 8 row-lanes, fixed order
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cs[e] += __shfl_xor(cs[e], 8, 64);
+            cs[e] += __shfl_xor(cs[e], 16, 64);
+            cs[e] += __shfl_xor(cs[e], 32, 64);
+        }
+        if (lane < 8) {
+            float* dst = p.colsum_part + (int64_t)(mrow0 / (16 * NI)) * p.N + ncol;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
         }
     }
 }
@@ -645,16 +663,50 @@ __global__ __launch_bounds__(SS_NT, OCC) void gemm_ss_kernel(GemmP p) {
 }
 
 
-// C[i] = beta*C[i] + sum_s ws[s][i]   (fixed summation order -> bitwise reproducible)
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc,
-                                     int splits, float beta) {
-    int64_t total = (int64_t)M * N;
+// C[i] = epilogue(sum_s ws[s][i])   (fixed summation order -> bitwise reproducible); the full fused epilogue is available
+// here too so that small-M, long-K GEMMs (the B*S = 64-row slot MLPs) can be split along K to fill the chip
+template <typename T>
+__global__ void splitk_reduce_kernel(GemmP p) {
+    const int64_t total = (int64_t)p.M * p.N;
+    const T* res = reinterpret_cast<const T*>(p.res);
+    const T* aux_in = reinterpret_cast<const T*>(p.aux_in);
+    T* aux_out = reinterpret_cast<T*>(p.aux_out);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += ws[(int64_t)z * total + i];
-        int m = (int)(i / N), n = (int)(i % N);
-        float* c = C + (int64_t)m * ldc + n;
-        *c = s + (beta != 0.f ? beta * *c : 0.f);
+        float v = 0.f;
+        for (int z = 0; z < p.split_k; ++z) v += p.ws[(int64_t)z * total + i];
+        const int m = (int)(i / p.N), n = (int)(i % p.N);
+        if (p.bias) v += p.bias[n];
+        if (p.act == DEVIAS_ACT_GELU) {
+            if (aux_out) aux_out[(int64_t)m * p.ld_aux + n] = from_f32<T>(v);
+            v = gelu_t<T>(v);
+        } else if (p.act == DEVIAS_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == DEVIAS_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        else if (p.act == DEVIAS_ACT_DGELU) v *= dgelu_t<T>(to_f32(aux_in[(int64_t)m * p.ld_aux + n]));
+        else if (p.act == DEVIAS_ACT_DRELU) v = to_f32(aux_in[(int64_t)m * p.ld_aux + n]) > 0.f ? v : 0.f;
+        if (res) v += to_f32(res[(int64_t)(p.res_mod > 0 ? m % p.res_mod : m) * p.ldr + n]);
+        if (p.c_f32) {
+            float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+            *c = v + (p.beta != 0.f ? p.beta * *c : 0.f);
+        } else {
+            reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(v);
+        }
+    }
+}
+
+// out[n] = beta*out[n] + sum_p part[p][n]; block (64 columns, 16 partial lanes), fixed order
+__global__ void gemm_colsum_final_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out, float beta) {
+    __shared__ float sm[16][64];
+    int n = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.f;
+    if (n < N)
+        for (int i = threadIdx.y; i < nparts; i += 16) s += part[(int64_t)i * N + n];
+    sm[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][threadIdx.x];
+        out[n] = t + (beta != 0.f ? beta * out[n] : 0.f);
     }
 }
 
@@ -695,8 +747,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     const int BK = a->dtype == DEVIAS_BF16 ? 64 : 16;
     int split = a->split_k > 1 ? a->split_k : 1;
     if (split > 1) {
-        DEVIAS_REQUIRE(p.c_f32 && !a->bias && a->act == DEVIAS_ACT_NONE && !a->res && a->ws,
-                       "devias_gemm: split_k needs fp32 C, a workspace and no bias/act/res epilogue");
+        DEVIAS_REQUIRE(a->ws, "devias_gemm: split_k needs a workspace");
         int kps = cdiv(cdiv(a->K, split), BK) * BK;
         split = cdiv(a->K, kps);
         p.k_per_split = kps;
@@ -704,6 +755,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         p.k_per_split = a->K;
     }
     p.split_k = split; p.ws = a->ws;
+    p.colsum_part = nullptr;
     // vector (16-byte) staging needs aligned bases / leading dims and whole chunks along the contiguous dim
     bool vec = aligned16(a->A) && aligned16(a->B) && (a->lda % ch == 0) && (a->ldb % ch == 0);
     vec = vec && (a->trans_a ? (a->M % ch == 0) : (a->K % ch == 0));
@@ -750,6 +802,11 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         if (nt && big && (int64_t)(a->M / T2) * (a->N / T2) * split >= 1000) ss = false;     // 256^2 wins the big NT grids
     }
     if (use256 == 2 && big) ss = false;
+    bool colsum_fused = false;
+    if (a->colsum) {
+        DEVIAS_REQUIRE(split == 1 && a->ws && !p.c_f32, "devias_gemm: colsum needs split_k == 1, a workspace (M/128 * N floats) and a T-typed C");
+        if (ss || big) { p.colsum_part = a->ws; colsum_fused = true; }      // the full-tile kernels fold it into their epilogue
+    }
     if (ss) {
         p.tiles_m = a->M / SS_BM; p.tiles_n = a->N / SS_BN;
         dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(SS_NT);
@@ -777,11 +834,20 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         else launch<float, false>(p, a->trans_a, a->trans_b, st);
     }
     DEVIAS_CHECK_LAUNCH("devias_gemm");
+    if (a->colsum) {
+        if (colsum_fused) {
+            hipLaunchKernelGGL(gemm_colsum_final_kernel, dim3(cdiv(a->N, 64)), dim3(64, 16), 0, st, a->ws, a->M / 128, a->N, a->colsum, a->colsum_beta);
+            DEVIAS_CHECK_LAUNCH("devias_gemm(colsum)");
+        } else {
+            int rc = devias_colsum(a->C, a->dtype, a->M, a->N, a->ldc, a->colsum, a->colsum_beta, a->ws, stream);
+            if (rc) return rc;
+        }
+    }
     if (split > 1) {
         int64_t total = (int64_t)a->M * a->N;
         int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, (float*)a->C, a->M, a->N, a->ldc,
-                           split, a->beta);
+        if (a->dtype == DEVIAS_BF16) hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3(blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
         DEVIAS_CHECK_LAUNCH("devias_gemm(split-k reduce)");
     }
     return DEVIAS_OK;

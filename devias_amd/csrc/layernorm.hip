@@ -60,15 +60,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ part, int M, int D) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [3 waves][2][NIT*256]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [3 waves][3][NIT*256]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 g[NIT], dg[NIT], db[NIT];
+    f32x4 g[NIT], dg[NIT], db[NIT], dc[NIT];     // dc: column sums of the stored dx
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         int c = (it * 64 + lane) * 4;
         g[it] = c < D ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         dg[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int r0 = blockIdx.x * LNB_ROWS;
     for (int rr = wave; rr < LNB_ROWS; rr += LN_WAVES) {
@@ -107,55 +108,61 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rs * (a[it][j] - m1 - xh[it][j] * m2);
                 if (dres) o += load4(dres + (int64_t)row * D + c);
+                dc[it] += o;
                 store4(dxr + c, o);
             }
         }
     }
-    // combine the 4 waves' partials -> part[blockIdx][2][D]
+    // combine the 4 waves' partials -> part[blockIdx][3][D]
     const int W = NIT * 256;
     if (wave > 0) {
-        float* dst = sm + (size_t)(wave - 1) * 2 * W;
+        float* dst = sm + (size_t)(wave - 1) * 3 * W;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int c = (it * 64 + lane) * 4;
             *reinterpret_cast<f32x4*>(dst + c) = dg[it];
             *reinterpret_cast<f32x4*>(dst + W + c) = db[it];
+            *reinterpret_cast<f32x4*>(dst + 2 * W + c) = dc[it];
         }
     }
     __syncthreads();
     if (wave == 0) {
-        float* out = part + (int64_t)blockIdx.x * 2 * D;
+        float* out = part + (int64_t)blockIdx.x * 3 * D;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int c = (it * 64 + lane) * 4;
             if (c < D) {
-                f32x4 a = dg[it], b = db[it];
+                f32x4 a = dg[it], b = db[it], cc = dc[it];
 #pragma unroll
                 for (int w = 0; w < 3; ++w) {
-                    a += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 2 * W + c);
-                    b += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 2 * W + W + c);
+                    a += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 3 * W + c);
+                    b += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 3 * W + W + c);
+                    cc += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 3 * W + 2 * W + c);
                 }
                 *reinterpret_cast<f32x4*>(out + c) = a;
                 *reinterpret_cast<f32x4*>(out + D + c) = b;
+                *reinterpret_cast<f32x4*>(out + 2 * D + c) = cc;
             }
         }
     }
 }
 
-// out[i] (i over 2*D: dgamma | dbeta) = beta_acc*out[i] + sum_p part[p][i]; block (64 columns, 16 partial lanes), fixed order
+// out[i] (i over 3*D: dgamma | dbeta | dx column sums) = beta_acc*out[i] + sum_p part[p][i]; block (64 columns, 16 partial lanes)
 __global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int D, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float beta_acc) {
+                                       float* __restrict__ dbeta, float* __restrict__ dxsum, float beta_acc) {
     __shared__ float sm[16][64];
+    const int lim = dxsum ? 3 * D : 2 * D;
     int i = blockIdx.x * 64 + threadIdx.x;
     float s = 0.f;
-    if (i < 2 * D)
-        for (int p = threadIdx.y; p < nparts; p += 16) s += part[(int64_t)p * 2 * D + i];
+    if (i < lim)
+        for (int p = threadIdx.y; p < nparts; p += 16) s += part[(int64_t)p * 3 * D + i];
     sm[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.y == 0 && i < 2 * D) {
+    if (threadIdx.y == 0 && i < lim) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sm[k][threadIdx.x];
+        if (i >= 2 * D) { dxsum[i - 2 * D] = t; return; }
         float* dst = i < D ? dgamma + i : dbeta + (i - D);
         *dst = t + (beta_acc != 0.f ? beta_acc * *dst : 0.f);
     }
@@ -176,7 +183,7 @@ int ln_bwd_dispatch(const T* dy, const T* x, const float* g, const float* mean, 
                     float* part, int M, int D, hipStream_t st) {
     dim3 grid(cdiv(M, LNB_ROWS)), block(256);
     int nit = cdiv(D, 256);
-#define LNB(N) hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 3 * 2 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D)
+#define LNB(N) hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 3 * 3 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D)
     if (nit <= 2) LNB(2); else if (nit <= 3) LNB(3); else if (nit <= 4) LNB(4); else LNB(8);
 #undef LNB
     return 0;
@@ -198,12 +205,12 @@ extern "C" int devias_layernorm_fwd(const void* x, const float* gamma, const flo
 }
 
 extern "C" int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
-    return (int64_t)cdiv(M, LNB_ROWS) * 2 * D * 4;
+    return (int64_t)cdiv(M, LNB_ROWS) * 3 * D * 4;
 }
 
 extern "C" int devias_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                     const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                    float beta_acc, int32_t M, int32_t D, int32_t dtype, float* ws, void* stream) {
+                                    float beta_acc, float* dx_colsum, int32_t M, int32_t D, int32_t dtype, float* ws, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     DEVIAS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && ws, "devias_layernorm_bwd: null pointer");
     DEVIAS_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "devias_layernorm_bwd: need D %% 4 == 0 and D <= 2048 (D=%d)", D);
@@ -216,7 +223,7 @@ extern "C" int devias_layernorm_bwd(const void* dy, const void* x, const float* 
     else return devias_set_error(DEVIAS_EINVAL, "devias_layernorm_bwd: bad dtype %d", dtype);
     DEVIAS_CHECK_LAUNCH("devias_layernorm_bwd");
     int nparts = cdiv(M, LNB_ROWS);
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(2 * D, 64)), dim3(64, 16), 0, st, ws, nparts, D, dgamma, dbeta, beta_acc);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(3 * D, 64)), dim3(64, 16), 0, st, ws, nparts, D, dgamma, dbeta, dx_colsum, beta_acc);
     DEVIAS_CHECK_LAUNCH("devias_layernorm_bwd(param reduce)");
     return DEVIAS_OK;
 }

@@ -102,6 +102,22 @@ class _WeightCache:
 _WCACHE = _WeightCache()
 
 
+# column sums of a residual-stream gradient, produced for free by the LayerNorm-backward kernel that wrote it and consumed
+# by the next backward region as the bias gradient of its last Linear (keyed on the gradient's storage address)
+_DX_COLSUM: Dict[int, torch.Tensor] = {}
+
+
+def _publish_colsum(dx: torch.Tensor, cs: torch.Tensor) -> None:
+    _DX_COLSUM[dx.data_ptr()] = cs
+
+
+def _take_colsum(dy: torch.Tensor) -> torch.Tensor:
+    cs = _DX_COLSUM.pop(dy.data_ptr(), None)
+    if cs is None or cs.numel() != dy.shape[1] or cs.device != dy.device:
+        cs = ops.colsum(dy)
+    return cs
+
+
 def _f32(p: torch.Tensor) -> torch.Tensor:
     d = p.detach()
     return d if d.dtype == torch.float32 and d.is_contiguous() else d.float().contiguous()
@@ -125,7 +141,7 @@ class PatchEmbedFn(Function):
     def backward(ctx, dy):
         dy = dy.contiguous()
         dW = ops.wgrad(dy, ctx.A).reshape(ctx.wshape)
-        db = ops.colsum(dy)
+        db = _take_colsum(dy)
         ctx.A = None
         return None, dW, db, None, None
 
@@ -160,23 +176,26 @@ class EncoderBlockFn(Function):
         ctx.saved = None
         dx2 = dx2.contiguous()
         D = x.shape[1]
+        dev = x.device
         # ---- MLP branch
-        dhpre = ops.gemm(dx2, W2, trans_b=True, act=ACT_DGELU, aux_in=hpre)             # (dx2 W2) * gelu'(pre)
+        db2 = _take_colsum(dx2)                                                         # fc2 bias gradient
+        db1 = torch.empty((W1.shape[0],), dtype=torch.float32, device=dev)
+        dhpre = ops.gemm(dx2, W2, trans_b=True, act=ACT_DGELU, aux_in=hpre, colsum=db1)  # (dx2 W2) * gelu'(pre); db1 = colsum
         dW2 = ops.wgrad(dx2, hact)
-        db2 = ops.colsum(dx2)
         du2 = ops.gemm(dhpre, W1, trans_b=True)
         dW1 = ops.wgrad(dhpre, u2)
-        db1 = ops.colsum(dhpre)
-        dx1, dn2w, dn2b = ops.layernorm_bwd(du2, x1, n2w_, mean2, rstd2, dres=dx2)      # + residual gradient
+        dbp = torch.empty((D,), dtype=torch.float32, device=dev)
+        dx1, dn2w, dn2b = ops.layernorm_bwd(du2, x1, n2w_, mean2, rstd2, dres=dx2, dx_colsum=dbp)   # + residual gradient; dbp = colsum(dx1)
         # ---- attention branch
         d_o = ops.gemm(dx1, Wp, trans_b=True)
         dWp = ops.wgrad(dx1, o)
-        dbp = ops.colsum(dx1)
         dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale)
         du = ops.gemm(dqkv, Wqkv, trans_b=True)
         dWqkv = ops.wgrad(dqkv, u)
         dbqkv = ops.colsum(dqkv)
-        dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1)
+        dxs = torch.empty((D,), dtype=torch.float32, device=dev)
+        dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1, dx_colsum=dxs)
+        _publish_colsum(dx, dxs)
         return (dx, dn1w, dn1b, dWqkv, dbqkv[:D], dbqkv[2 * D:], dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None)
 
 
@@ -297,7 +316,9 @@ class AggBlockFn(Function):
             G[si]["to_k"], G[si]["to_v"] = dWkv[:inner], dWkv[inner:]
             dfeats_i, G[si]["ctx_w"], G[si]["ctx_b"] = ops.layernorm_bwd(dc, feats, LNW[si]["ctx_w"], mc, rc, dres=dfeats)
             dfeats = dfeats_i
-        dx, dnorm_w, dnorm_b = ops.layernorm_bwd(dfeats, x, norm_w, m0, r0)
+        dxs = torch.empty((x.shape[1],), dtype=torch.float32, device=dev)
+        dx, dnorm_w, dnorm_b = ops.layernorm_bwd(dfeats, x, norm_w, m0, r0, dx_colsum=dxs)
+        _publish_colsum(dx, dxs)
         flat = []
         for si in range(nset):
             flat += [G[si][k] for k in _LAYER_KEYS]

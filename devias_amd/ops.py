@@ -68,7 +68,8 @@ def auto_split_k(M: int, N: int, K: int, target_blocks: int = 768, bk: int = 64)
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux_in: Optional[torch.Tensor] = None,
          aux_out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, res_mod: int = 0,
-         out: Optional[torch.Tensor] = None, out_f32: bool = False, beta: float = 0.0, split_k: int = 1) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, out_f32: bool = False, beta: float = 0.0, split_k: int = 1,
+         colsum: Optional[torch.Tensor] = None, colsum_beta: float = 0.0) -> torch.Tensor:
     """C[M,N] = epilogue(op(A) @ op(B)); see devias_gemm in include/devias_amd.h.
     A: [M,K] (or [K,M] if trans_a); B: [N,K] nn.Linear layout (or [K,N] if trans_b)."""
     _chk(A, "gemm.A"); _chk(B, "gemm.B", A.dtype)
@@ -106,6 +107,16 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         assert res.shape[-1] == N and res.numel() // N == (res_mod if res_mod > 0 else M)
         a.res, a.ldr, a.res_mod = res.data_ptr(), N, res_mod
     a.beta = beta
+    if split_k == 1 and M <= 256 and K >= 512 and not trans_a:
+        # small-M (B*S-row slot MLP) GEMMs are latency bound on a handful of tiles: split K to fill the chip
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        split_k = max(1, min(K // 128, (256 + tiles - 1) // tiles))
+    if colsum is not None:            # bias gradient folded into the epilogue (needs the un-split kernel)
+        _chk(colsum, "gemm.colsum", torch.float32); assert colsum.numel() == N
+        split_k = 1
+        a.colsum, a.colsum_beta = colsum.data_ptr(), colsum_beta
+        nbytes = max(((M + 127) // 128) * N * 4, _lib.load().devias_colsum_workspace_bytes(M, N))
+        a.ws = workspace(nbytes, A.device).data_ptr()
     a.split_k = split_k
     if split_k > 1:
         nbytes = _lib.load().devias_gemm_workspace_bytes(M, N, split_k)
@@ -198,7 +209,7 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, beta_acc: float = 0.0):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, beta_acc: float = 0.0, dx_colsum=None):
     _chk(dy, "layernorm_bwd.dy"); _chk(x, "layernorm_bwd.x", dy.dtype)
     M, D = x.shape
     dx = torch.empty_like(x)
@@ -210,7 +221,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
         _chk(dres, "layernorm_bwd.dres", dy.dtype)
     ws = workspace(_lib.load().devias_layernorm_bwd_workspace_bytes(M, D), x.device)
     _lib.check(_lib.load().devias_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                _p(dres), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), beta_acc, M, D,
+                                                _p(dres), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), beta_acc, _p(dx_colsum), M, D,
                                                 dt_code(x.dtype), ws.data_ptr(), _stream()), "devias_layernorm_bwd")
     return dx, dgamma, dbeta
 

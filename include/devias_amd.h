@@ -54,8 +54,8 @@ int devias_device_info(int device, int64_t* out5);
  *   trans_b = 0: B is [N,K] row-major -- the nn.Linear weight layout;  1: B is stored [K,N]
  *   epilogue order: +bias[n] -> act (GELU stores the pre-activation to aux_out first) -> +res[(m % res_mod or m), n]
  *   c_f32 = 1 with T = bf16 writes C (and reads it under beta) as fp32: weight-gradient GEMMs.
- *   split_k > 1 (requires c_f32 or T=f32, no bias/act/res): partial sums go to `ws`
- *     (split_k * M * N floats) and a second kernel reduces them deterministically: C = beta*C + sum.
+ *   split_k > 1: partial sums go to `ws` (split_k * M * N floats) and a second kernel reduces them in a fixed order and
+ *     applies the same epilogue (used for the long-M weight-gradient reductions and the 64-row slot MLP GEMMs).
  * Replaces: F.linear / nn.Linear forward, its dgrad and wgrad ATen kernels (mm / addmm) at
  *   modeling_slot.py:60-67 (Mlp), :97-101 (qkv), :113 (proj), :167-177 (Conv3d patch embed as GEMM), :302/:393 (head),
  *   :199-204 (MaskPredictor), agg_block/attention.py:66-72 (FeedForward), :108-115,123-126,141 (to_q/to_k/to_v/to_out).
@@ -76,7 +76,10 @@ typedef struct {
     int32_t ldr, res_mod;     /* res_mod > 0: residual row = m % res_mod (positional table broadcast) */
     float beta;               /* C = acc + beta*C; only honoured for fp32 C */
     int32_t split_k;          /* >= 1 */
-    float* ws;                /* split-K workspace or NULL */
+    float* ws;                /* split-K workspace (or colsum partials: max(M/128 * N, colsum_workspace) floats) or NULL */
+    float* colsum;            /* optional fp32 [N]: colsum = colsum_beta*colsum + sum_m C[m, :] -- the bias gradient of the layer
+                                 whose output gradient this GEMM produces, folded into the epilogue (split_k must be 1, C of type T) */
+    float colsum_beta;
 } devias_gemm_args;
 int devias_gemm(const devias_gemm_args* args, void* stream);
 /* bytes of workspace devias_gemm needs for the given split_k (0 when split_k <= 1) */
@@ -113,11 +116,13 @@ int devias_add(const void* a, const void* b, void* y, int32_t dtype, int64_t n, 
  * agg_block/agg_block.py:105-107 eps 1e-5).  x,y: T [M,D]; gamma,beta fp32 [D]; mean,rstd fp32 [M] (saved for backward).
  * backward: dx = LN'(dy) (+ dres if dres != NULL, fusing the residual-branch gradient add);
  *           dgamma/dbeta (fp32 [D]) = beta_acc * old + column sums; ws >= devias_layernorm_bwd_workspace_bytes.
+ *           dx_colsum (optional fp32 [D]) = column sums of the stored dx: the bias gradient of the Linear layer that produced x's
+ *           residual branch input (proj / fc2 bias), obtained for free from the rows this kernel already holds.
  * ------------------------------------------------------------------------------------------------- */
 int devias_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                          int32_t M, int32_t D, float eps, int32_t dtype, void* stream);
 int devias_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                         const void* dres, void* dx, float* dgamma, float* dbeta, float beta_acc,
+                         const void* dres, void* dx, float* dgamma, float* dbeta, float beta_acc, float* dx_colsum,
                          int32_t M, int32_t D, int32_t dtype, float* ws, void* stream);
 int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
 

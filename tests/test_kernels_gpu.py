@@ -73,6 +73,10 @@ def test_gemm_epilogues(dtype, M, N, K):
     nb = A.float() @ W.float().t()
     assert rel(o.gemm(A, W, act=o.ACT_DGELU, aux_in=pre).float(), nb * xg.grad) < tol
     assert rel(o.gemm(A, W, act=o.ACT_DRELU, aux_in=pre).float(), nb * (pre.float() > 0)) < tol
+    # bias gradient (column sums of the stored output) folded into the epilogue, with accumulation
+    cs = torch.ones(N, device=DEV)
+    y = o.gemm(A, W, act=o.ACT_DGELU, aux_in=pre, colsum=cs, colsum_beta=1.0)
+    assert rel(cs, 1 + (nb * xg.grad).sum(0)) < (1e-4 if dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -93,6 +97,27 @@ def test_wgrad_splitk_and_beta(dtype, M, N, K):
 
 
 # ------------------------------------------------------------------------------------------ element-wise
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_m_splitk_with_epilogue(dtype):
+    """64-row GEMMs are split along K automatically; the reduce kernel applies the same fused epilogue"""
+    o = ops()
+    M, N, K = 64, 768, 3072
+    A, W = rnd(M, K, dtype=dtype, seed=70), rnd(N, K, dtype=dtype, scale=0.05, seed=71)
+    bias, res = rnd(N, seed=72), rnd(M, N, dtype=dtype, seed=73)
+    base = A.float() @ W.float().t() + bias
+    tol = TOL[dtype] * (4 if dtype == torch.bfloat16 else 2)
+    assert rel(o.gemm(A, W, bias=bias, res=res).float(), base + res.float()) < tol
+    aux = torch.empty(M, N, dtype=dtype, device=DEV)
+    y = o.gemm(A, W, bias=bias, act=o.ACT_GELU, aux_out=aux)
+    assert rel(aux.float(), base) < tol and rel(y.float(), F.gelu(base)) < tol
+    pre = rnd(M, N, dtype=dtype, seed=74)
+    xg = pre.float().clone().requires_grad_(True)
+    F.gelu(xg).backward(torch.ones_like(xg))
+    assert rel(o.gemm(A, W.clone(), act=o.ACT_DGELU, aux_in=pre).float(), (A.float() @ W.float().t()) * xg.grad) < tol
+    Wt = W.t().contiguous()          # [K, N]: dgrad layout
+    assert rel(o.gemm(A, Wt, trans_b=True, split_k=6).float(), A.float() @ Wt.float()) < tol
+
+
 def test_cast_im2col_colsum_rows():
     o = ops()
     x = rnd(1000003, seed=11)
@@ -143,8 +168,10 @@ def test_layernorm(dtype, M, D, eps):
     assert rel(dx.float(), xr.grad + dres.float()) < tol
     assert rel(dg, gr.grad) < (1e-4 if dtype == torch.float32 else 1e-3)
     assert rel(db, br.grad) < (1e-4 if dtype == torch.float32 else 1e-3)
-    dx2, dg2, db2 = o.layernorm_bwd(dy, x, g, mean, rstd, dgamma=dg.clone(), dbeta=db.clone(), beta_acc=1.0)
+    cs = torch.empty(D, device=DEV)
+    dx2, dg2, db2 = o.layernorm_bwd(dy, x, g, mean, rstd, dgamma=dg.clone(), dbeta=db.clone(), beta_acc=1.0, dx_colsum=cs)
     assert rel(dx2.float(), xr.grad) < tol and rel(dg2, 2 * gr.grad) < 1e-3
+    assert rel(cs, xr.grad.sum(0)) < (1e-4 if dtype == torch.float32 else 2e-2)        # fused bias-gradient column sums of dx
 
 
 # ---------------------------------------------------------------------------------------------- attention
