@@ -804,7 +804,8 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     if (use256 == 2 && big) ss = false;
     bool colsum_fused = false;
     if (a->colsum) {
-        DEVIAS_REQUIRE(split == 1 && a->ws && !p.c_f32, "devias_gemm: colsum needs split_k == 1, a workspace (M/128 * N floats) and a T-typed C");
+        DEVIAS_REQUIRE(split == 1 && a->ws && !(a->c_f32 && a->dtype == DEVIAS_BF16),
+                       "devias_gemm: colsum needs split_k == 1, a workspace (M/128 * N floats) and a T-typed C");
         if (ss || big) { p.colsum_part = a->ws; colsum_fused = true; }      // the full-tile kernels fold it into their epilogue
     }
     if (ss) {
