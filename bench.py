@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-full-step", action="store_true", help="skip the secondary full-step number (teacher fwd + AdamW)")
     return ap.parse_args()
 
 
@@ -166,6 +167,41 @@ def main():
             dist.destroy_process_group()
         return
 
+    full = None
+    if not args.no_full_step and world == 1:
+        # secondary number: the same step + frozen teacher forward (a15) + fused AdamW update (a18)
+        from devias_amd.modeling_finetune import vit_base_patch16_224
+        from devias_amd.optim import FusedAdamW
+        if args.model == "vit_base":
+            teacher = vit_base_patch16_224(num_classes=365, all_frames=args.frames, tubelet_size=2, use_mean_pooling=False,
+                                           init_scale=0.001, compute_dtype=args.dtype)
+            synth.fill_module_(teacher, seed=1)
+            teacher = teacher.to(device).eval()
+            opt = FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.05)
+
+            def full_step():
+                for p in model.parameters():
+                    p.grad = None
+                out = model(x)
+                _, tlog = teacher(x, return_attn=False)
+                total, logits, ld = crit(model, out, (None, tlog.float()), y, fg_mask=(fg196, fgN))
+                total.backward()
+                opt.step()
+                return total
+
+            for _ in range(2):
+                full_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nfs = max(3, args.steps // 2)
+            for _ in range(nfs):
+                fl = full_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / nfs
+            full = {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "steps": nfs,
+                    "includes": "student fwd+loss+bwd + frozen teacher fwd (1569 tokens) + fused AdamW (98.4M params)",
+                    "final_loss": float(fl.detach().float().sum())}
+
     clips_per_s = world * B * args.steps / wall
     gflop = TRAIN_GFLOP_PER_CLIP.get((args.model, args.frames, 224))
     ach = clips_per_s / world * gflop / 1e3 if gflop else None       # per-GPU TFLOP/s
@@ -187,6 +223,8 @@ def main():
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
                             "scope": f"whole step per GPU: {gflop} algorithmic GFLOP/clip x {B} clips / step time",
                             "dominant_kernel": dominant_kernel_probe(args, device)}
+    if full is not None:
+        line["full_step"] = full
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(line))

@@ -92,3 +92,48 @@ def test_surface_attributes_used_by_the_reference_driver():
         create_model("slot_vit_base_patch16_224", slot_matching_method="bogus")
     with pytest.raises(AssertionError):
         m.cuda()(torch.zeros(1, 3, 16, 112, 112, device="cuda"))
+
+
+def test_teacher_forward_matches_reference_golden():
+    """frozen cls-token scene teacher (model/modeling_finetune.py), N+1 = 785 tokens: fp32 within 1e-3, bf16 loosely"""
+    from devias_amd.modeling_finetune import vit_base_patch16_224
+    fx = dict(np.load(gu.GOLDEN_DIR + "/teacher_vitb_t8.npz"))
+    x = synth.video(2, 8, 224, seed=1000).cuda()
+    for mode, tol in (("fp32", 1e-3), ("bf16", 5e-2)):
+        m = vit_base_patch16_224(num_classes=365, all_frames=8, tubelet_size=2, use_mean_pooling=False, init_scale=1e-3,
+                                 compute_dtype=mode)
+        synth.fill_module_(m, seed=1)
+        m = m.cuda().eval()
+        names = sorted(n for n, _ in m.named_parameters())
+        assert names == sorted(ref_cpu.teacher_param_shapes(ref_cpu.SlotViTConfig(all_frames=8)).keys())
+        tok, logits = m(x, return_attn=False)
+        e1, e2 = gu.rel(tok.float().cpu(), fx["token"]), gu.rel(logits.float().cpu(), fx["logits"])
+        print(f"teacher {mode}: token {e1:.2e} logits {e2:.2e}")
+        assert e1 < tol and e2 < tol
+
+
+def test_train_class_batch_with_teacher_and_fused_adamw():
+    """engine.train_class_batch with a teacher MODULE + one FusedAdamW step == torch.optim.AdamW on the same gradients"""
+    from devias_amd.engine_for_slot import train_class_batch
+    from devias_amd.modeling_finetune import vit_base_patch16_224
+    from devias_amd.optim import FusedAdamW
+    from devias_amd.train_loss import TrainLoss
+    fx, cfg, B = gu.load("vitb_t8")
+    model = build(cfg, "fp32")
+    teacher = vit_base_patch16_224(num_classes=365, all_frames=8, use_mean_pooling=False, init_scale=1e-3, compute_dtype="fp32")
+    synth.fill_module_(teacher, seed=1)
+    teacher = teacher.cuda().eval()
+    x, y, tl, fg = gu.inputs(cfg, B)
+    crit = TrainLoss(scene_criterion="KL", num_action_classes=400, slot_matching_method="matching", scene_loss_weight=4000,
+                     mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0)
+    loss, out, ld = train_class_batch(model, teacher, x.cuda(), y.cuda(), crit, fg_mask=(fg[0].cuda(), fg[1].cuda()))
+    assert torch.isfinite(loss).all() and out.shape == (B, 765) and all(isinstance(v, float) for v in ld.values())
+    loss.backward()
+    ref = [p.detach().clone().requires_grad_(True) for p in model.parameters()]
+    for r, p in zip(ref, model.parameters()):
+        r.grad = p.grad.clone()
+    topt = torch.optim.AdamW(ref, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    fopt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    topt.step(); fopt.step()
+    worst = max(gu.rel(p.detach().cpu(), r.detach().cpu()) for p, r in zip(model.parameters(), ref))
+    assert worst < 1e-6, worst
