@@ -31,6 +31,7 @@ class GemmArgs(Structure):
         ("res", c_void_p), ("ldr", c_int32), ("res_mod", c_int32),
         ("beta", c_float), ("split_k", c_int32), ("ws", c_void_p),
         ("colsum", c_void_p), ("colsum_beta", c_float),
+        ("row_scale", c_void_p), ("rows_per_scale", c_int32),
     ]
 
 
@@ -54,6 +55,7 @@ PROTOTYPES = {
     "devias_rows_reduce_mod": (c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "devias_rows_broadcast": (c_int, [_P, _I, _I, _P, _I, _I, _P]),
     "devias_act_bwd": (c_int, [_P, _P, _P, _I, _I, _L, _P]),
+    "devias_row_scale": (c_int, [_P, _P, _I, _P, _I, _I, _I, _P]),
     "devias_add": (c_int, [_P, _P, _P, _I, _L, _P]),
     "devias_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "devias_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P, _P]),

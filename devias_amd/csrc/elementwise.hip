@@ -144,6 +144,15 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y
     }
 }
 
+template <typename T>
+__global__ void row_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale, int rps, T* __restrict__ y, int M, int N) {
+    const int64_t total4 = (int64_t)M * N / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i * 4 / N);
+        store4(y + i * 4, load4(x + i * 4) * scale[m / rps]);
+    }
+}
+
 // ---- AdamW ------------------------------------------------------------------------------------------
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
@@ -235,6 +244,18 @@ extern "C" int devias_rows_broadcast(const float* src, int32_t mod, int32_t N, v
     if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((rows_broadcast_kernel<bf16>), g, b, 0, st, src, mod, N, (bf16*)out, M);
     else hipLaunchKernelGGL((rows_broadcast_kernel<float>), g, b, 0, st, src, mod, N, (float*)out, M);
     DEVIAS_CHECK_LAUNCH("devias_rows_broadcast");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_row_scale(const void* x, const float* scale, int32_t rps, void* y, int32_t dtype, int32_t M, int32_t N, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(x && scale && y && rps > 0 && M > 0 && N > 0 && N % 4 == 0, "devias_row_scale: bad args (N must be a multiple of 4)");
+    DEVIAS_REQUIRE(aligned16(x) && aligned16(y), "devias_row_scale: unaligned pointer");
+    dim3 g(grid_for((int64_t)M * N / 4)), b(256);
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((row_scale_kernel<bf16>), g, b, 0, st, (const bf16*)x, scale, rps, (bf16*)y, M, N);
+    else if (dtype == DEVIAS_F32) hipLaunchKernelGGL((row_scale_kernel<float>), g, b, 0, st, (const float*)x, scale, rps, (float*)y, M, N);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_row_scale: bad dtype %d", dtype);
+    DEVIAS_CHECK_LAUNCH("devias_row_scale");
     return DEVIAS_OK;
 }
 

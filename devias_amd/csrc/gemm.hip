@@ -25,6 +25,7 @@ struct GemmP {
     float beta; int c_f32; int vec_c; int vec16;
     float* ws; int k_per_split; int split_k;
     int tiles_m, tiles_n;
+    const float* row_scale; int rows_per_scale;   // optional per-sample scale of (acc+bias, act) before the residual (stochastic depth)
     float* colsum_part;   // optional: per-(wave row-tile) partial column sums of the stored output, [M / (16*NI)][N]
     int group_m;          // tile rasterisation: GM row-tiles per group (m fastest inside a group); 1 = n fastest
     int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
@@ -210,6 +211,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
                     const float a = (float)a8[e];
                     v[e] = (p.act == DEVIAS_ACT_DGELU) ? v[e] * dgelu_fast(a) : (a > 0.f ? v[e] : 0.f);
                 }
+            }
+            if (p.row_scale) {
+                const float rs = p.row_scale[m / p.rows_per_scale];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= rs;
             }
             if (res) {
                 const int mr = p.res_mod > 0 ? m % p.res_mod : m;
@@ -399,6 +405,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmP p) {
                 for (int r = 0; r < 4; ++r)
                     v[r] = (p.act == DEVIAS_ACT_DGELU) ? v[r] * dgelu_t<T>(a[r]) : (a[r] > 0.f ? v[r] : 0.f);
             }
+            if (p.row_scale) v *= p.row_scale[m / p.rows_per_scale];
             if (res) {
                 if (full) { f32x4 rr = load4(res + (int64_t)mr * p.ldr + n); v += rr; }
                 else {
@@ -683,6 +690,7 @@ __global__ void splitk_reduce_kernel(GemmP p) {
         else if (p.act == DEVIAS_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
         else if (p.act == DEVIAS_ACT_DGELU) v *= dgelu_t<T>(to_f32(aux_in[(int64_t)m * p.ld_aux + n]));
         else if (p.act == DEVIAS_ACT_DRELU) v = to_f32(aux_in[(int64_t)m * p.ld_aux + n]) > 0.f ? v : 0.f;
+        if (p.row_scale) v *= p.row_scale[m / p.rows_per_scale];
         if (res) v += to_f32(res[(int64_t)(p.res_mod > 0 ? m % p.res_mod : m) * p.ldr + n]);
         if (p.c_f32) {
             float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
@@ -756,6 +764,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     }
     p.split_k = split; p.ws = a->ws;
     p.colsum_part = nullptr;
+    p.row_scale = a->row_scale; p.rows_per_scale = a->rows_per_scale > 0 ? a->rows_per_scale : 1;
     // vector (16-byte) staging needs aligned bases / leading dims and whole chunks along the contiguous dim
     bool vec = aligned16(a->A) && aligned16(a->B) && (a->lda % ch == 0) && (a->ldb % ch == 0);
     vec = vec && (a->trans_a ? (a->M % ch == 0) : (a->K % ch == 0));

@@ -150,7 +150,7 @@ class EncoderBlockFn(Function):
     """x -> x + proj(MHSA(LN1 x)) -> + fc2(GELU(fc1(LN2 .)))   (Block.forward, modeling_slot.py:142-152; no LayerScale, drop_path 0)"""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qb, vb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, meta):
+    def forward(ctx, x, n1w, n1b, qkvw, qb, vb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, meta, ds1=None, ds2=None):
         B, N, H, eps, cdt = meta
         scale = 64 ** -0.5
         n1w_, n1b_, n2w_, n2b_ = _f32(n1w), _f32(n1b), _f32(n2w), _f32(n2b)
@@ -159,12 +159,13 @@ class EncoderBlockFn(Function):
         qkv_bias = torch.cat((_f32(qb), torch.zeros_like(_f32(vb)), _f32(vb)))         # modeling_slot.py:97-99
         qkv = ops.gemm(u, Wqkv, bias=qkv_bias)                                          # [M, 3D] == [B,N,3,H,64]
         o, lse = ops.mhsa_fwd(qkv, B, N, H, scale)
-        x1 = ops.gemm(o, Wp, bias=_f32(pb), res=x)
+        x1 = ops.gemm(o, Wp, bias=_f32(pb), res=x, row_scale=ds1, rows_per_scale=N)       # x + drop_path(proj(.))
         u2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w_, n2b_, eps)
         hpre = torch.empty((x.shape[0], W1.shape[0]), dtype=cdt, device=x.device)
         hact = ops.gemm(u2, W1, bias=_f32(f1b), act=ACT_GELU, aux_out=hpre)
-        x2 = ops.gemm(hact, W2, bias=_f32(f2b), res=x1)
+        x2 = ops.gemm(hact, W2, bias=_f32(f2b), res=x1, row_scale=ds2, rows_per_scale=N)   # x1 + drop_path(mlp(.))
         ctx.meta = meta
+        ctx.ds = (ds1, ds2)
         ctx.saved = (x, u, mean1, rstd1, qkv, o, lse, x1, u2, mean2, rstd2, hpre, hact, n1w_, n2w_, Wqkv, Wp, W1, W2)
         return x2
 
@@ -177,18 +178,28 @@ class EncoderBlockFn(Function):
         dx2 = dx2.contiguous()
         D = x.shape[1]
         dev = x.device
-        # ---- MLP branch
-        db2 = _take_colsum(dx2)                                                         # fc2 bias gradient
+        ds1, ds2 = ctx.ds
+        # ---- MLP branch (g2 = gradient of the branch output: dx2 scaled by the per-sample stochastic-depth factor, if any)
+        if ds2 is None:
+            g2, db2 = dx2, _take_colsum(dx2)                                            # fc2 bias gradient
+        else:
+            g2 = ops.row_scale(dx2, ds2, N)
+            db2 = ops.colsum(g2)
         db1 = torch.empty((W1.shape[0],), dtype=torch.float32, device=dev)
-        dhpre = ops.gemm(dx2, W2, trans_b=True, act=ACT_DGELU, aux_in=hpre, colsum=db1)  # (dx2 W2) * gelu'(pre); db1 = colsum
-        dW2 = ops.wgrad(dx2, hact)
+        dhpre = ops.gemm(g2, W2, trans_b=True, act=ACT_DGELU, aux_in=hpre, colsum=db1)   # (g2 W2) * gelu'(pre); db1 = colsum
+        dW2 = ops.wgrad(g2, hact)
         du2 = ops.gemm(dhpre, W1, trans_b=True)
         dW1 = ops.wgrad(dhpre, u2)
         dbp = torch.empty((D,), dtype=torch.float32, device=dev)
         dx1, dn2w, dn2b = ops.layernorm_bwd(du2, x1, n2w_, mean2, rstd2, dres=dx2, dx_colsum=dbp)   # + residual gradient; dbp = colsum(dx1)
         # ---- attention branch
-        d_o = ops.gemm(dx1, Wp, trans_b=True)
-        dWp = ops.wgrad(dx1, o)
+        if ds1 is None:
+            g1 = dx1
+        else:
+            g1 = ops.row_scale(dx1, ds1, N)
+            dbp = ops.colsum(g1)
+        d_o = ops.gemm(g1, Wp, trans_b=True)
+        dWp = ops.wgrad(g1, o)
         dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale)
         du = ops.gemm(dqkv, Wqkv, trans_b=True)
         dWqkv = ops.wgrad(dqkv, u)
@@ -196,7 +207,7 @@ class EncoderBlockFn(Function):
         dxs = torch.empty((D,), dtype=torch.float32, device=dev)
         dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1, dx_colsum=dxs)
         _publish_colsum(dx, dxs)
-        return (dx, dn1w, dn1b, dWqkv, dbqkv[:D], dbqkv[2 * D:], dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None)
+        return (dx, dn1w, dn1b, dWqkv, dbqkv[:D], dbqkv[2 * D:], dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None)
 
 
 _LAYER_KEYS = ("to_q", "to_k", "to_v", "to_out_w", "to_out_b", "norm_w", "norm_b", "ctx_w", "ctx_b",
@@ -411,13 +422,18 @@ class Block(nn.Module):
         a = self.attn
         if a.q_bias is None:
             raise NotImplementedError("qkv_bias=False is not used by any DEVIAS entrypoint")
+        ds1 = ds2 = None
         if self.training and self.drop_path_rate > 0:
-            raise NotImplementedError("stochastic depth (drop_path > 0) is not implemented in the HIP path yet; "
-                                      "use drop_path_rate=0 (parity / benchmark setting)")
+            # timm 0.4.12 drop_path (modeling_slot.py:36-47): per-sample Bernoulli(keep) mask scaled by 1/keep, drawn independently
+            # for the attention and the MLP branch; applied inside the residual GEMM epilogues (row_scale)
+            keep = 1.0 - self.drop_path_rate
+            r = torch.rand((2, B), device=x.device, dtype=torch.float32)
+            ds = ((keep + r).floor() / keep).contiguous()
+            ds1, ds2 = ds[0], ds[1]
         meta = (B, N, a.num_heads, self.norm1.eps, cdt)
         return EncoderBlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight,
                                     a.proj.bias, self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
-                                    self.mlp.fc2.weight, self.mlp.fc2.bias, meta)
+                                    self.mlp.fc2.weight, self.mlp.fc2.bias, meta, ds1, ds2)
 
 
 class PatchEmbed(nn.Module):

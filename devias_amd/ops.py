@@ -69,7 +69,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, aux_in: Optional[torch.Tensor] = None,
          aux_out: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, res_mod: int = 0,
          out: Optional[torch.Tensor] = None, out_f32: bool = False, beta: float = 0.0, split_k: int = 1,
-         colsum: Optional[torch.Tensor] = None, colsum_beta: float = 0.0) -> torch.Tensor:
+         colsum: Optional[torch.Tensor] = None, colsum_beta: float = 0.0,
+         row_scale: Optional[torch.Tensor] = None, rows_per_scale: int = 0) -> torch.Tensor:
     """C[M,N] = epilogue(op(A) @ op(B)); see devias_gemm in include/devias_amd.h.
     A: [M,K] (or [K,M] if trans_a); B: [N,K] nn.Linear layout (or [K,N] if trans_b)."""
     _chk(A, "gemm.A"); _chk(B, "gemm.B", A.dtype)
@@ -107,6 +108,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         assert res.shape[-1] == N and res.numel() // N == (res_mod if res_mod > 0 else M)
         a.res, a.ldr, a.res_mod = res.data_ptr(), N, res_mod
     a.beta = beta
+    if row_scale is not None:
+        _chk(row_scale, "gemm.row_scale", torch.float32); assert rows_per_scale > 0 and row_scale.numel() * rows_per_scale >= M
+        a.row_scale, a.rows_per_scale = row_scale.data_ptr(), rows_per_scale
     if split_k == 1 and M <= 256 and K >= 512 and not trans_a:
         # small-M (B*S-row slot MLP) GEMMs are latency bound on a handful of tiles: split K to fill the chip
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
@@ -189,6 +193,15 @@ def act_bwd(dy: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
     _lib.check(_lib.load().devias_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), act, dt_code(dy.dtype), dy.numel(), _stream()),
                "devias_act_bwd")
     return dx
+
+
+def row_scale(x: torch.Tensor, scale: torch.Tensor, rows_per_scale: int) -> torch.Tensor:
+    _chk(x, "row_scale.x"); _chk(scale, "row_scale.scale", torch.float32)
+    M, N = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().devias_row_scale(x.data_ptr(), scale.data_ptr(), rows_per_scale, y.data_ptr(), dt_code(x.dtype), M, N, _stream()),
+               "devias_row_scale")
+    return y
 
 
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

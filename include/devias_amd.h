@@ -52,7 +52,7 @@ int devias_device_info(int device, int64_t* out5);
  * Generic fused GEMM:  C[M,N] = epilogue( op(A)[M,K] * op(B)[K,N] )
  *   trans_a = 0: A is [M,K] row-major (lda = row stride);  1: A is stored [K,M] (reduction-major)
  *   trans_b = 0: B is [N,K] row-major -- the nn.Linear weight layout;  1: B is stored [K,N]
- *   epilogue order: +bias[n] -> act (GELU stores the pre-activation to aux_out first) -> +res[(m % res_mod or m), n]
+ *   epilogue order: +bias[n] -> act (GELU stores the pre-activation to aux_out first) -> *row_scale[m / rows_per_scale] -> +res[(m % res_mod or m), n]
  *   c_f32 = 1 with T = bf16 writes C (and reads it under beta) as fp32: weight-gradient GEMMs.
  *   split_k > 1: partial sums go to `ws` (split_k * M * N floats) and a second kernel reduces them in a fixed order and
  *     applies the same epilogue (used for the long-M weight-gradient reductions and the 64-row slot MLP GEMMs).
@@ -80,6 +80,9 @@ typedef struct {
     float* colsum;            /* optional fp32 [N]: colsum = colsum_beta*colsum + sum_m C[m, :] -- the bias gradient of the layer
                                  whose output gradient this GEMM produces, folded into the epilogue (split_k must be 1, C of type T) */
     float colsum_beta;
+    const float* row_scale;   /* optional fp32 [ceil(M / rows_per_scale)]: (acc + bias, act) *= row_scale[m / rows_per_scale] BEFORE the residual
+                                 add -- timm drop_path (stochastic depth, modeling_slot.py:36-47,150-151): 0 or 1/keep per sample */
+    int32_t rows_per_scale;
 } devias_gemm_args;
 int devias_gemm(const devias_gemm_args* args, void* stream);
 /* bytes of workspace devias_gemm needs for the given split_k (0 when split_k <= 1) */
@@ -108,6 +111,8 @@ int devias_rows_broadcast(const float* src, int32_t mod, int32_t N, void* out, i
 /* dx = dy * f'(.) element-wise (T, n elements): act = DEVIAS_ACT_SIGMOID / DEVIAS_ACT_RELU take y = f(x) (the saved OUTPUT),
  * DEVIAS_ACT_GELU takes the saved pre-activation x. */
 int devias_act_bwd(const void* dy, const void* y_or_x, void* dx, int32_t act, int32_t dtype, int64_t n, void* stream);
+/* y[m, :] = x[m, :] * scale[m / rows_per_scale]  (T [M,N]); gradient of a stochastic-depth branch */
+int devias_row_scale(const void* x, const float* scale, int32_t rows_per_scale, void* y, int32_t dtype, int32_t M, int32_t N, void* stream);
 /* y = a + b (same dtype T, n elements); used for gradient fan-in of the residual stream */
 int devias_add(const void* a, const void* b, void* y, int32_t dtype, int64_t n, void* stream);
 

@@ -137,3 +137,51 @@ def test_train_class_batch_with_teacher_and_fused_adamw():
     topt.step(); fopt.step()
     worst = max(gu.rel(p.detach().cpu(), r.detach().cpu()) for p, r in zip(model.parameters(), ref))
     assert worst < 1e-6, worst
+
+
+def test_drop_path_matches_oracle_with_the_same_masks():
+    """stochastic depth (timm drop_path): with the SAME per-sample masks the fused row-scale epilogue path must equal the oracle
+    block evaluated with those masks, forward and backward (fp32)"""
+    from devias_amd.modeling_slot import EncoderBlockFn, _f32
+    cfg = ref_cpu.SlotViTConfig(all_frames=2, embed_dim=384, num_heads=6, depth=1)
+    B, N, D = 3, cfg.num_patches, cfg.embed_dim
+    shapes = {k: v for k, v in ref_cpu.param_shapes(cfg).items() if k.startswith("blocks.0.")}
+    P = synth.fill_params(shapes, seed=5)
+    x = synth.param_values("dp.x", (B, N, D), seed=6) * 20
+    ds = torch.tensor([[0.0, 1 / 0.8, 1 / 0.8], [1 / 0.8, 0.0, 1 / 0.8]])
+    # oracle with masks
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xg = x.clone().requires_grad_(True)
+    p = "blocks.0."
+    import torch.nn.functional as F
+    u = F.layer_norm(xg, (D,), Pg[p + "norm1.weight"], Pg[p + "norm1.bias"], 1e-6)
+    bias = torch.cat([Pg[p + "attn.q_bias"], torch.zeros(D), Pg[p + "attn.v_bias"]])
+    qkv = F.linear(u, Pg[p + "attn.qkv.weight"], bias).reshape(B, N, 3, 6, 64).permute(2, 0, 3, 1, 4)
+    att = ((qkv[0] * 0.125) @ qkv[1].transpose(-2, -1)).softmax(-1)
+    o = (att @ qkv[2]).transpose(1, 2).reshape(B, N, D)
+    x1 = xg + ds[0].view(B, 1, 1) * F.linear(o, Pg[p + "attn.proj.weight"], Pg[p + "attn.proj.bias"])
+    h = F.gelu(F.linear(F.layer_norm(x1, (D,), Pg[p + "norm2.weight"], Pg[p + "norm2.bias"], 1e-6), Pg[p + "mlp.fc1.weight"], Pg[p + "mlp.fc1.bias"]))
+    x2 = x1 + ds[1].view(B, 1, 1) * F.linear(h, Pg[p + "mlp.fc2.weight"], Pg[p + "mlp.fc2.bias"])
+    w = synth.param_values("dp.w", (B, N, D), seed=7)
+    (x2 * w).sum().backward()
+    # HIP path
+    order = ["norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.q_bias", "attn.v_bias", "attn.proj.weight", "attn.proj.bias",
+             "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"]
+    Pc = [P[p + k].cuda().requires_grad_(True) for k in order]
+    xc = x.reshape(B * N, D).cuda().requires_grad_(True)
+    dsc = ds.cuda().contiguous()
+    y = EncoderBlockFn.apply(xc, *Pc, (B, N, 6, 1e-6, torch.float32), dsc[0], dsc[1])
+    (y * w.reshape(B * N, D).cuda()).sum().backward()
+    assert gu.rel(y.detach().cpu().view(B, N, D), x2.detach()) < 1e-5
+    assert gu.rel(xc.grad.cpu().view(B, N, D), xg.grad) < 1e-4
+    for k, t_ in zip(order, Pc):
+        assert gu.rel(t_.grad.cpu(), Pg[p + k].grad) < 2e-4, k
+    # and the module-level switch draws masks only in training mode
+    from devias_amd.modeling_slot import VisionTransformer
+    m = VisionTransformer(embed_dim=384, num_heads=6, depth=2, qkv_bias=True, num_classes=400, all_frames=2, num_latents=2,
+                          agg_weights_tie=True, agg_depth=2, slot_matching_method="matching", drop_path_rate=0.5, compute_dtype="fp32").cuda()
+    xin = synth.video(2, 2, 224).cuda()
+    m.eval(); a = m(xin)[2][0]; b_ = m(xin)[2][0]
+    assert torch.equal(a, b_)
+    m.train(); torch.manual_seed(0); c = m(xin)[2][0]; d = m(xin)[2][0]
+    assert not torch.equal(c, d)
