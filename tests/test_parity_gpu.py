@@ -181,7 +181,7 @@ def test_drop_path_matches_oracle_with_the_same_masks():
     m = VisionTransformer(embed_dim=384, num_heads=6, depth=2, qkv_bias=True, num_classes=400, all_frames=2, num_latents=2,
                           agg_weights_tie=True, agg_depth=2, slot_matching_method="matching", drop_path_rate=0.5, compute_dtype="fp32").cuda()
     xin = synth.video(2, 2, 224).cuda()
-    m.eval(); a = m(xin)[2][0]; b_ = m(xin)[2][0]
+    m.eval(); a = m(xin)[2][1]; b_ = m(xin)[2][1]          # slots (the head is zero-initialised with init_scale=0)
     assert torch.equal(a, b_)
-    m.train(); torch.manual_seed(0); c = m(xin)[2][0]; d = m(xin)[2][0]
+    m.train(); torch.manual_seed(0); c = m(xin)[2][1]; d = m(xin)[2][1]
     assert not torch.equal(c, d)
