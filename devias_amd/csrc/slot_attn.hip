@@ -13,7 +13,7 @@
 
 namespace {
 
-enum { MAXS = 8, EPL = 8, DH = 512, TCH = 64 };   // tokens per workgroup chunk
+enum { MAXS_LIMIT = 8, EPL = 8, DH = 512, TCH = 64 };   // tokens per workgroup chunk
 
 template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
 template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8]) {
@@ -38,7 +38,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
 // ---------------------------------------------------------------------------------------------------------
 // forward pass over K/V: writes A, and per-chunk partials  ws_r[bh][chunk][S], ws_o[bh][chunk][S][DH]
 // ---------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int MAXS>
 __global__ __launch_bounds__(256) void slot_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                        float* __restrict__ attn, float* __restrict__ ws_r,
                                                        float* __restrict__ ws_o, int S, int N, int h, float scale) {
@@ -56,35 +56,46 @@ __global__ __launch_bounds__(256) void slot_fwd_kernel(const T* __restrict__ q, 
         rs[i] = 0.f;
     }
     const int j0 = chunk * TCH, j1 = min(N, j0 + TCH);
-    for (int j = j0 + wave; j < j1; j += 4) {
-        const T* krow = kv + ((int64_t)b * N + j) * 2 * inner + hh * DH + lane * 8;
-        float k8[8], v8[8];
-        load8<T>(krow, k8);
-        load8<T>(krow + inner, v8);
-        float sim[MAXS];
-        float mx = -INFINITY;
+    // two tokens per wave iteration (4 independent 16-byte loads in flight per lane)
+    for (int jj = j0 + wave * 2; jj < j1; jj += 8) {
+        const int ntok = min(2, j1 - jj);
+        float k8[2][8], v8[2][8];
 #pragma unroll
-        for (int i = 0; i < MAXS; ++i) {
-            if (i < S) {
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d += qv[i][e] * k8[e];
-                sim[i] = wave_sum(d) * scale;
-                mx = fmaxf(mx, sim[i]);
-            }
+        for (int u = 0; u < 2; ++u) {
+            const int j = min(jj + u, j1 - 1);
+            const T* krow = kv + ((int64_t)b * N + j) * 2 * inner + hh * DH + lane * 8;
+            load8<T>(krow, k8[u]);
+            load8<T>(krow + inner, v8[u]);
         }
-        float den = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXS; ++i) if (i < S) { sim[i] = expf(sim[i] - mx); den += sim[i]; }
-        const float inv = 1.0f / den;
+        for (int u = 0; u < 2; ++u) {
+            if (u >= ntok) break;
+            const int j = jj + u;
+            float sim[MAXS];
+            float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < MAXS; ++i) {
-            if (i < S) {
-                const float a = sim[i] * inv;
-                if (lane == 0) attn[((int64_t)bh * S + i) * N + j] = a;
-                rs[i] += a;
+            for (int i = 0; i < MAXS; ++i) {
+                if (i < S) {
+                    float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) oacc[i][e] += a * v8[e];
+                    for (int e = 0; e < 8; ++e) d += qv[i][e] * k8[u][e];
+                    sim[i] = wave_sum(d) * scale;
+                    mx = fmaxf(mx, sim[i]);
+                }
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) if (i < S) { sim[i] = expf(sim[i] - mx); den += sim[i]; }
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) {
+                if (i < S) {
+                    const float a = sim[i] * inv;
+                    if (lane == 0) attn[((int64_t)bh * S + i) * N + j] = a;
+                    rs[i] += a;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) oacc[i][e] += a * v8[u][e];
+                }
             }
         }
     }
@@ -132,7 +143,7 @@ __global__ void slot_fwd_finish_kernel(const float* __restrict__ ws_r, const flo
 // ---------------------------------------------------------------------------------------------------------
 // backward pass over K/V of one layer: ds[bh,i,j] and per-chunk dq partials ws_q[bh][chunk][S][DH]
 // ---------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int MAXS>
 __global__ __launch_bounds__(256) void slot_bwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                        const float* __restrict__ attn, const float* __restrict__ rsum,
                                                        const T* __restrict__ o, const T* __restrict__ d_o,
@@ -161,33 +172,43 @@ __global__ __launch_bounds__(256) void slot_bwd_kernel(const T* __restrict__ q, 
         for (int e = 0; e < 8; ++e) { if (i >= S) dov[i][e] = 0.f; dq[i][e] = 0.f; }
     }
     const int j0 = chunk * TCH, j1 = min(N, j0 + TCH);
-    for (int j = j0 + wave; j < j1; j += 4) {
-        const T* krow = kv + ((int64_t)b * N + j) * 2 * inner + hh * DH + lane * 8;
-        float k8[8], v8[8];
-        load8<T>(krow, k8);
-        load8<T>(krow + inner, v8);
-        float a[MAXS], dA[MAXS];
-        float tsum = 0.f;
+    for (int jj = j0 + wave * 2; jj < j1; jj += 8) {
+        const int ntok = min(2, j1 - jj);
+        float k8[2][8], v8[2][8];
 #pragma unroll
-        for (int i = 0; i < MAXS; ++i) {
-            if (i < S) {
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d += dov[i][e] * v8[e];
-                const float dAbar = wave_sum(d);
-                a[i] = attn[((int64_t)bh * S + i) * N + j];
-                dA[i] = (dAbar - dl[i]) * rinv[i] + (dA_ext ? dA_ext[((int64_t)bh * S + i) * N + j] : 0.f);
-                tsum += a[i] * dA[i];
-            }
+        for (int u = 0; u < 2; ++u) {
+            const int j = min(jj + u, j1 - 1);
+            const T* krow = kv + ((int64_t)b * N + j) * 2 * inner + hh * DH + lane * 8;
+            load8<T>(krow, k8[u]);
+            load8<T>(krow + inner, v8[u]);
         }
 #pragma unroll
-        for (int i = 0; i < MAXS; ++i) {
-            if (i < S) {
-                const float ds = a[i] * (dA[i] - tsum);
-                if (lane == 0) ds_out[((int64_t)bh * S + i) * N + j] = ds;
-                const float w = ds * scale;
+        for (int u = 0; u < 2; ++u) {
+            if (u >= ntok) break;
+            const int j = jj + u;
+            float a[MAXS], dA[MAXS];
+            float tsum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dq[i][e] += w * k8[e];
+            for (int i = 0; i < MAXS; ++i) {
+                if (i < S) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d += dov[i][e] * v8[u][e];
+                    const float dAbar = wave_sum(d);
+                    a[i] = attn[((int64_t)bh * S + i) * N + j];
+                    dA[i] = (dAbar - dl[i]) * rinv[i] + (dA_ext ? dA_ext[((int64_t)bh * S + i) * N + j] : 0.f);
+                    tsum += a[i] * dA[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) {
+                if (i < S) {
+                    const float ds = a[i] * (dA[i] - tsum);
+                    if (lane == 0) ds_out[((int64_t)bh * S + i) * N + j] = ds;
+                    const float w = ds * scale;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dq[i][e] += w * k8[u][e];
+                }
             }
         }
     }
@@ -235,6 +256,7 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const T* __restrict__
     __shared__ __attribute__((aligned(16))) float sm_q[KVG_PAIRS][DH];
     __shared__ __attribute__((aligned(16))) float sm_do[KVG_PAIRS][DH];
     __shared__ float sm_rinv[KVG_PAIRS];
+    __shared__ float sm_cds[KVG_PAIRS][TCH], sm_cab[KVG_PAIRS][TCH];   // per-token coefficients of this chunk (coalesced once)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bh = blockIdx.y, b = bh / h, hh = bh % h;
     const int inner = h * DH;
@@ -261,6 +283,18 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const T* __restrict__
             sm_rinv[threadIdx.x] = 1.0f / rsum_stack[((int64_t)l * B * h + bh) * S + i];
         }
         __syncthreads();
+        for (int idx = threadIdx.x; idx < np * TCH; idx += 256) {
+            const int pp = idx / TCH, jl = idx % TCH, j = j0 + jl;
+            const int l = (p0 + pp) / S, i = (p0 + pp) % S;
+            float cds = 0.f, cab = 0.f;
+            if (j < j1) {
+                const int64_t ci = (int64_t)l * BhSN + ((int64_t)bh * S + i) * N + j;
+                cds = ds_stack[ci] * scale;
+                cab = attn_stack[ci] * sm_rinv[pp];
+            }
+            sm_cds[pp][jl] = cds; sm_cab[pp][jl] = cab;
+        }
+        __syncthreads();
         for (int j = j0 + wave; j < j1; j += 4) {
             T* krow = dkv + ((int64_t)b * N + j) * 2 * inner + hh * DH + lane * 8;
             float dk[8], dv[8];
@@ -270,10 +304,8 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const T* __restrict__
                 for (int e = 0; e < 8; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
             }
             for (int pp = 0; pp < np; ++pp) {
-                const int l = (p0 + pp) / S, i = (p0 + pp) % S;
-                const int64_t ci = (int64_t)l * BhSN + ((int64_t)bh * S + i) * N + j;
-                const float cds = ds_stack[ci] * scale;
-                const float cab = attn_stack[ci] * sm_rinv[pp];
+                const float cds = sm_cds[pp][j - j0];
+                const float cab = sm_cab[pp][j - j0];
                 const f32x4 q0 = *reinterpret_cast<const f32x4*>(&sm_q[pp][lane * 8]);
                 const f32x4 q1 = *reinterpret_cast<const f32x4*>(&sm_q[pp][lane * 8 + 4]);
                 const f32x4 o0 = *reinterpret_cast<const f32x4*>(&sm_do[pp][lane * 8]);
@@ -299,7 +331,7 @@ extern "C" int64_t devias_slot_attn_workspace_bytes(int32_t B, int32_t S, int32_
 
 #define SLOT_COMMON_CHECKS(name)                                                                              \
     DEVIAS_REQUIRE(dh == DH, name ": only dim_head == 512 is built (agg_block/agg_block.py:83), got %d", dh); \
-    DEVIAS_REQUIRE(S >= 1 && S <= MAXS, name ": 1 <= num_latents <= 8 supported, got %d", S);                \
+    DEVIAS_REQUIRE(S >= 1 && S <= MAXS_LIMIT, name ": 1 <= num_latents <= 8 supported, got %d", S);                \
     DEVIAS_REQUIRE(B > 0 && N > 0 && h > 0 && (int64_t)B * h <= 65535, name ": bad B/N/h");                  \
     DEVIAS_REQUIRE(dtype == DEVIAS_BF16 || dtype == DEVIAS_F32, name ": bad dtype %d", dtype)
 
@@ -314,11 +346,15 @@ extern "C" int devias_slot_attn_fwd(const void* q, const void* kv, float* attn, 
     float* ws_o = ws + (((int64_t)B * h * nchunks * S + 3) & ~(int64_t)3);
     dim3 grid(nchunks, B * h), block(256);
     if (dtype == DEVIAS_BF16) {
-        hipLaunchKernelGGL((slot_fwd_kernel<bf16>), grid, block, 0, st, (const bf16*)q, (const bf16*)kv, attn, ws_r, ws_o, S, N, h, scale);
+        if (S <= 2) hipLaunchKernelGGL((slot_fwd_kernel<bf16, 2>), grid, block, 0, st, (const bf16*)q, (const bf16*)kv, attn, ws_r, ws_o, S, N, h, scale);
+        else if (S <= 4) hipLaunchKernelGGL((slot_fwd_kernel<bf16, 4>), grid, block, 0, st, (const bf16*)q, (const bf16*)kv, attn, ws_r, ws_o, S, N, h, scale);
+        else hipLaunchKernelGGL((slot_fwd_kernel<bf16, 8>), grid, block, 0, st, (const bf16*)q, (const bf16*)kv, attn, ws_r, ws_o, S, N, h, scale);
         DEVIAS_CHECK_LAUNCH("devias_slot_attn_fwd");
         hipLaunchKernelGGL((slot_fwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws_r, ws_o, rsum, (bf16*)o, S, h, nchunks);
     } else {
-        hipLaunchKernelGGL((slot_fwd_kernel<float>), grid, block, 0, st, (const float*)q, (const float*)kv, attn, ws_r, ws_o, S, N, h, scale);
+        if (S <= 2) hipLaunchKernelGGL((slot_fwd_kernel<float, 2>), grid, block, 0, st, (const float*)q, (const float*)kv, attn, ws_r, ws_o, S, N, h, scale);
+        else if (S <= 4) hipLaunchKernelGGL((slot_fwd_kernel<float, 4>), grid, block, 0, st, (const float*)q, (const float*)kv, attn, ws_r, ws_o, S, N, h, scale);
+        else hipLaunchKernelGGL((slot_fwd_kernel<float, 8>), grid, block, 0, st, (const float*)q, (const float*)kv, attn, ws_r, ws_o, S, N, h, scale);
         DEVIAS_CHECK_LAUNCH("devias_slot_attn_fwd");
         hipLaunchKernelGGL((slot_fwd_finish_kernel<float>), dim3(B * h * S), dim3(256), 0, st, ws_r, ws_o, rsum, (float*)o, S, h, nchunks);
     }
@@ -337,13 +373,19 @@ extern "C" int devias_slot_attn_bwd(const void* q, const void* kv, const float* 
     const int nchunks = cdiv(N, TCH);
     dim3 grid(nchunks, B * h), block(256);
     if (dtype == DEVIAS_BF16) {
-        hipLaunchKernelGGL((slot_bwd_kernel<bf16>), grid, block, 0, st, (const bf16*)q, (const bf16*)kv, attn, rsum, (const bf16*)o,
-                           (const bf16*)d_o, d_attn_ext, ds, ws, S, N, h, scale);
+#define SB_ARGS (const bf16*)q, (const bf16*)kv, attn, rsum, (const bf16*)o, (const bf16*)d_o, d_attn_ext, ds, ws, S, N, h, scale
+        if (S <= 2) hipLaunchKernelGGL((slot_bwd_kernel<bf16, 2>), grid, block, 0, st, SB_ARGS);
+        else if (S <= 4) hipLaunchKernelGGL((slot_bwd_kernel<bf16, 4>), grid, block, 0, st, SB_ARGS);
+        else hipLaunchKernelGGL((slot_bwd_kernel<bf16, 8>), grid, block, 0, st, SB_ARGS);
+#undef SB_ARGS
         DEVIAS_CHECK_LAUNCH("devias_slot_attn_bwd");
         hipLaunchKernelGGL((slot_bwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws, (bf16*)dq, S, h, nchunks);
     } else {
-        hipLaunchKernelGGL((slot_bwd_kernel<float>), grid, block, 0, st, (const float*)q, (const float*)kv, attn, rsum, (const float*)o,
-                           (const float*)d_o, d_attn_ext, ds, ws, S, N, h, scale);
+#define SB_ARGS (const float*)q, (const float*)kv, attn, rsum, (const float*)o, (const float*)d_o, d_attn_ext, ds, ws, S, N, h, scale
+        if (S <= 2) hipLaunchKernelGGL((slot_bwd_kernel<float, 2>), grid, block, 0, st, SB_ARGS);
+        else if (S <= 4) hipLaunchKernelGGL((slot_bwd_kernel<float, 4>), grid, block, 0, st, SB_ARGS);
+        else hipLaunchKernelGGL((slot_bwd_kernel<float, 8>), grid, block, 0, st, SB_ARGS);
+#undef SB_ARGS
         DEVIAS_CHECK_LAUNCH("devias_slot_attn_bwd");
         hipLaunchKernelGGL((slot_bwd_finish_kernel<float>), dim3(B * h * S), dim3(256), 0, st, ws, (float*)dq, S, h, nchunks);
     }
