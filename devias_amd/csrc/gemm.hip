@@ -670,6 +670,7 @@ __global__ __launch_bounds__(SS_NT, OCC) void gemm_ss_kernel(GemmP p) {
 }
 
 
+
 // C[i] = epilogue(sum_s ws[s][i])   (fixed summation order -> bitwise reproducible); the full fused epilogue is available
 // here too so that small-M, long-K GEMMs (the B*S = 64-row slot MLPs) can be split along K to fill the chip
 template <typename T>

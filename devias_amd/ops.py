@@ -56,13 +56,16 @@ def device_info(device: int = 0):
     return {"cus": out[0], "clock_khz": out[1], "lds_per_block": out[2], "wave": out[3], "gfx": out[4]}
 
 
-def auto_split_k(M: int, N: int, K: int, target_blocks: int = 768, bk: int = 64) -> int:
-    """Split the reduction of a weight-gradient GEMM so that tiles x splits fills the chip (256 CUs x ~3 workgroups)."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= target_blocks or K < 8 * bk:
+def auto_split_k(M: int, N: int, K: int, bk: int = 64) -> int:
+    """Split the long reduction of a weight-gradient GEMM so that (tiles x splits) is just under ONE full round of the kernel
+    that will run it: 512 slots for the bf16 256x128 kernel (256 CUs x 2 workgroups), 768 for the 128x128 kernel."""
+    if bk == 64 and M % 256 == 0 and N % 128 == 0:
+        tiles, slots = (M // 256) * (N // 128), 512
+    else:
+        tiles, slots = ((M + 127) // 128) * ((N + 127) // 128), 768
+    if tiles >= slots or K < 8 * bk:
         return 1
-    s = min((target_blocks + tiles - 1) // tiles, K // (4 * bk), 64)
-    return max(1, s)
+    return max(1, min(slots // tiles, K // (4 * bk), 64))
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
@@ -133,7 +136,7 @@ def wgrad(dY: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None,
     """dW[N,K] (fp32) = dY[M,N]^T @ X[M,K]   (weight gradient of Y = X W^T); split-K over the long M reduction."""
     M, N = dY.shape
     K = X.shape[1]
-    sk = auto_split_k(N, K, M, bk=64 if dY.dtype == torch.bfloat16 else 16)
+    sk = auto_split_k(N, K, M, bk=64 if dY.dtype == torch.bfloat16 else 16)     # C is [N, K], the reduction runs over M
     return gemm(dY, X, trans_a=True, trans_b=True, out=out, out_f32=True, beta=beta, split_k=sk)
 
 

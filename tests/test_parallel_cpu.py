@@ -83,3 +83,46 @@ def test_gradsync_single_process_is_identity():
     # bucket order is reverse registration order (head first, first layer last): SURVEY.md §3.4
     first = sync.buckets[0][0]
     assert first is list(model.parameters())[-1]
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from devias_amd.parallel import GradSync, init_distributed_from_env
+    init_distributed_from_env(backend="nccl")
+    dev = torch.device("cuda", rank)
+    model = _make_model().to(dev)
+    sync = GradSync(model, bucket_bytes=512)
+    g = torch.Generator().manual_seed(100 + rank)
+    model(torch.randn(8, 16, generator=g).to(dev)).pow(2).mean().backward()
+    sync.finish()
+    torch.cuda.synchronize()
+    q.put((rank, [p.grad.detach().cpu().numpy().copy() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(180)
+def test_gradsync_two_ranks_rccl():
+    """same equivalence over RCCL (side-stream all-reduce); needs >= 2 GPUs, skipped on the 1-GPU box"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+    model = _make_model()
+    loss = 0
+    for rank in range(world):
+        g = torch.Generator().manual_seed(100 + rank)
+        loss = loss + model(torch.randn(8, 16, generator=g)).pow(2).mean() / world
+    loss.backward()
+    for pi, p in enumerate(model.parameters()):
+        for rank in range(world):
+            assert torch.allclose(torch.from_numpy(res[rank][pi]), p.grad, rtol=1e-4, atol=1e-6)
