@@ -118,6 +118,47 @@ def _take_colsum(dy: torch.Tensor) -> torch.Tensor:
     return cs
 
 
+# ---- weight-gradient side stream ------------------------------------------------------------------------------------
+# dX (needed by the next backward region) and dW (needed only by the optimizer) of a layer are independent: the dW GEMMs and the
+# bias column sums run on a second HIP stream so their workgroups fill the tail rounds / HBM-write-bound epilogues of the dX chain
+# (and vice versa).  Joined before the region returns its gradients to autograd.
+import os as _os
+_OVERLAP = _os.environ.get("DEVIAS_OVERLAP", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(dev: torch.device):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+class _WgradLane:
+    """`with lane.after_main():` runs the enclosed launches on the side stream once everything issued so far on the main
+    stream is done; `lane.join(*outs)` makes the main stream wait and registers the outputs with it."""
+
+    def __init__(self, dev: torch.device):
+        self.on = _OVERLAP
+        self.main = torch.cuda.current_stream(dev)
+        self.side = _side_stream(dev) if self.on else None
+
+    def after_main(self):
+        if not self.on:
+            import contextlib
+            return contextlib.nullcontext()
+        self.side.wait_event(self.main.record_event())
+        return torch.cuda.stream(self.side)
+
+    def join(self, *outs):
+        if self.on:
+            self.main.wait_stream(self.side)
+            for t in outs:
+                if t is not None:
+                    t.record_stream(self.main)
+
+
 def _f32(p: torch.Tensor) -> torch.Tensor:
     d = p.detach()
     return d if d.dtype == torch.float32 and d.is_contiguous() else d.float().contiguous()
@@ -179,17 +220,20 @@ class EncoderBlockFn(Function):
         D = x.shape[1]
         dev = x.device
         ds1, ds2 = ctx.ds
+        lane = _WgradLane(dev)
         # ---- MLP branch (g2 = gradient of the branch output: dx2 scaled by the per-sample stochastic-depth factor, if any)
         if ds2 is None:
             g2, db2 = dx2, _take_colsum(dx2)                                            # fc2 bias gradient
         else:
             g2 = ops.row_scale(dx2, ds2, N)
             db2 = ops.colsum(g2)
+        with lane.after_main():
+            dW2 = ops.wgrad(g2, hact)
         db1 = torch.empty((W1.shape[0],), dtype=torch.float32, device=dev)
         dhpre = ops.gemm(g2, W2, trans_b=True, act=ACT_DGELU, aux_in=hpre, colsum=db1)   # (g2 W2) * gelu'(pre); db1 = colsum
-        dW2 = ops.wgrad(g2, hact)
+        with lane.after_main():
+            dW1 = ops.wgrad(dhpre, u2)
         du2 = ops.gemm(dhpre, W1, trans_b=True)
-        dW1 = ops.wgrad(dhpre, u2)
         dbp = torch.empty((D,), dtype=torch.float32, device=dev)
         dx1, dn2w, dn2b = ops.layernorm_bwd(du2, x1, n2w_, mean2, rstd2, dres=dx2, dx_colsum=dbp)   # + residual gradient; dbp = colsum(dx1)
         # ---- attention branch
@@ -198,15 +242,18 @@ class EncoderBlockFn(Function):
         else:
             g1 = ops.row_scale(dx1, ds1, N)
             dbp = ops.colsum(g1)
+        with lane.after_main():
+            dWp = ops.wgrad(g1, o)
         d_o = ops.gemm(g1, Wp, trans_b=True)
-        dWp = ops.wgrad(g1, o)
         dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale)
+        with lane.after_main():
+            dWqkv = ops.wgrad(dqkv, u)
+            dbqkv = ops.colsum(dqkv)
         du = ops.gemm(dqkv, Wqkv, trans_b=True)
-        dWqkv = ops.wgrad(dqkv, u)
-        dbqkv = ops.colsum(dqkv)
         dxs = torch.empty((D,), dtype=torch.float32, device=dev)
         dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1, dx_colsum=dxs)
         _publish_colsum(dx, dxs)
+        lane.join(dW2, dW1, dWp, dWqkv, dbqkv)
         return (dx, dn1w, dn1b, dWqkv, dbqkv[:D], dbqkv[2 * D:], dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None)
 
 

@@ -40,8 +40,9 @@ def _chk(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only fp32 scratch buffer per device; safe because all kernels of a step are ordered on one stream."""
-    key = (torch.device(device).index or 0)
+    """Grow-only fp32 scratch buffer per (device, stream): kernels of one stream are ordered, so a buffer is never shared by
+    two launches in flight (the weight-gradient side stream gets its own)."""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
     n = (int(nbytes) + 3) // 4
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < n:
