@@ -262,6 +262,24 @@ def generate_teacher(ref):
     print(f"[teacher_vitb_t8] wrote {path}")
 
 
+def generate_state_dict_keys(ref):
+    """state_dict key -> shape of the REAL reference modules (data only): pins checkpoint compatibility (tests/test_checkpoint_cpu.py)."""
+    import json
+    reg = ref[0]
+    out = {}
+    m = reg["slot_vit_base_patch16_224"](num_classes=400, all_frames=16, tubelet_size=2, drop_path_rate=0.1, init_scale=1e-3, num_latents=2,
+                                         head_type="linear", slot_matching_method="matching", agg_weights_tie=True, agg_depth=8,
+                                         num_scene_classes=365)
+    out["slot_vit_base_patch16_224.tied_s2_d8"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    m = reg["slot_vit_base_patch16_224"](num_classes=174, all_frames=16, num_latents=4, slot_matching_method="matching",
+                                         agg_weights_tie=False, agg_depth=4)
+    out["slot_vit_base_patch16_224.untied_s4_d4_nb174"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    t = reg["vit_base_patch16_224"](num_classes=365, all_frames=16, tubelet_size=2, use_mean_pooling=False)
+    out["vit_base_patch16_224.cls_365"] = {k: list(v.shape) for k, v in t.state_dict().items()}
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "reference_state_dict_keys.json"), "w"))
+    print("[state_dict_keys]", {k: len(v) for k, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -273,6 +291,8 @@ def main():
             generate(name, ref)
     if args.only in (None, "teacher"):
         generate_teacher(ref)
+    if args.only in (None, "keys"):
+        generate_state_dict_keys(ref)
 
 
 if __name__ == "__main__":
