@@ -87,14 +87,33 @@ struct TileRegs {
     }
 };
 
+// LDS-DMA staging of a [64 rows][64 cols] bf16 tile (8 x 1 KiB global_load_lds, shared by NW waves) straight into the row image
+// (TR = false) or the transposed-read image (TR = true); the images' XOR swizzles are applied on the per-lane SOURCE address.
+// Rows past `nrows` re-read row nrows-1 (finite data; their scores are masked / their probabilities are zero).
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+template <int NW, bool TR>
+__device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t row_stride, int row0, int nrows, char* img, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+        const int r8 = (wave * (8 / NW) + i) * 8;
+        const int row = r8 + (lane >> 3), slot = lane & 7;
+        const int chunk = TR ? ((((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1)) : (slot ^ (row & 7));
+        const int grow = min(row0 + row, nrows - 1);
+        const bf16* src = base + (int64_t)grow * row_stride + chunk * 8;
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(img + r8 * 128), 16, 0, 0);
+    }
+}
+
 // ======================================= forward (bf16) ===================================================
-template <int QT, int NW>
+template <int QT, int NW, bool DMA>
 __global__ __launch_bounds__(NW * 64) void mhsa_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                             float* __restrict__ lse, int N, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[16384];
+    __shared__ __attribute__((aligned(16))) char smem[DMA ? 32768 : 16384];   // DMA: two stages of (K row image | V transposed-read image)
     char* imgK = smem;            // row image of K tile  [key][d]
     char* imgV = smem + 8192;     // transposed-read image of V tile [key][d]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.y, b = blockIdx.z;
     const int D = H * 64;
     const int64_t RS = 3 * (int64_t)D;
@@ -121,15 +140,33 @@ __global__ __launch_bounds__(NW * 64) void mhsa_fwd_bf16_kernel(const bf16* __re
 
     const int nkv = (N + 63) / 64;
     TileRegs<NW * 64> rk, rv;
-    rk.load(base + D, RS, 0, N, tid);
-    rv.load(base + 2 * D, RS, 0, N, tid);
+    if constexpr (DMA) {
+        dma_tile<NW, false>(base + D, RS, 0, N, smem, wave, lane);
+        dma_tile<NW, true>(base + 2 * D, RS, 0, N, smem + 8192, wave, lane);
+    } else {
+        rk.load(base + D, RS, 0, N, tid);
+        rv.load(base + 2 * D, RS, 0, N, tid);
+    }
     for (int t = 0; t < nkv; ++t) {
-        rk.store_rows(imgK, tid);
-        rv.store_tr(imgV, tid);
-        __syncthreads();
-        if (t + 1 < nkv) {
-            rk.load(base + D, RS, (t + 1) * 64, N, tid);
-            rv.load(base + 2 * D, RS, (t + 1) * 64, N, tid);
+        if constexpr (DMA) {
+            // one barrier per tile: tile t has landed for every wave, and everyone is done reading tile t-1's stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            imgK = smem + (t & 1) * 16384;
+            imgV = imgK + 8192;
+            if (t + 1 < nkv) {
+                char* nxt = smem + ((t + 1) & 1) * 16384;
+                dma_tile<NW, false>(base + D, RS, (t + 1) * 64, N, nxt, wave, lane);
+                dma_tile<NW, true>(base + 2 * D, RS, (t + 1) * 64, N, nxt + 8192, wave, lane);
+            }
+        } else {
+            rk.store_rows(imgK, tid);
+            rv.store_tr(imgV, tid);
+            __syncthreads();
+            if (t + 1 < nkv) {
+                rk.load(base + D, RS, (t + 1) * 64, N, tid);
+                rv.load(base + 2 * D, RS, (t + 1) * 64, N, tid);
+            }
         }
         // S^T tile: acc_s[kt][qt] holds keys 16kt + 4g + r (rows) x query c (col)
         f32x4 acc_s[4][QT];
@@ -198,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_fwd_bf16_kernel(const bf16* __re
                 for (int qt = 0; qt < QT; ++qt) acc_o[dt][qt] = mfma(vf, pf[qt], acc_o[dt][qt]);
             }
         }
-        __syncthreads();
+        if constexpr (!DMA) __syncthreads();
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -639,10 +676,11 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
     if (dtype == DEVIAS_BF16)
         {
         static const int cfg = [] { const char* e = getenv("DEVIAS_ATTN_CFG"); return e ? atoi(e) : 0; }();
-        if (cfg == 1) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 2>), dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-        else if (cfg == 2) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 4>), dim3(cdiv(N, 256), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-        else if (cfg == 3) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 2>), dim3(cdiv(N, 64), H, B), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-        else hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        if (cfg == 1) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 2, false>), dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        else if (cfg == 2) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 4, false>), dim3(cdiv(N, 256), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        else if (cfg == 3) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 2, false>), dim3(cdiv(N, 64), H, B), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        else if (cfg == 4) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, false>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        else hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
     }
     else if (dtype == DEVIAS_F32)
         hipLaunchKernelGGL(mhsa_fwd_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (float*)o, lse, N, H, scale);

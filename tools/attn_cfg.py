@@ -9,8 +9,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     out, lse = o.mhsa_fwd(qkv, B, N, H, 0.125)
     do = torch.randn_like(out)
     fl = 4.0 * B * H * N * N * 64 / 1e9
-    t = timeit(lambda: o.mhsa_fwd(qkv, B, N, H, 0.125), iters=20)
-    t2 = timeit(lambda: o.mhsa_bwd(qkv, out, do, lse, B, N, H, 0.125), iters=20)
+    t = timeit(lambda: o.mhsa_fwd(qkv, B, N, H, 0.125), iters=60, warmup=40)
+    t2 = timeit(lambda: o.mhsa_bwd(qkv, out, do, lse, B, N, H, 0.125), iters=30, warmup=10)
     # correctness spot check vs cfg-independent torch reference on a small case
     q2 = torch.randn(2 * 200, 3 * 2 * 64, device="cuda").bfloat16()
     o2, l2 = o.mhsa_fwd(q2, 2, 200, 2, 0.125)
