@@ -25,7 +25,7 @@ import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2516.6          # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU (dense; MI355X_MICROARCH.md chip table)
 TRAIN_GFLOP_PER_CLIP = {           # algorithmic (tied K/V once), BASELINE.md §3
-    ("vit_base", 16, 224): 1109.3, ("vit_small", 8, 224): 143.7, ("vit_large", 16, 224): 3617.4,
+    ("vit_base", 16, 224): 1109.3, ("vit_small", 8, 224): 143.7, ("vit_large", 16, 224): 3617.4, ("vit_base", 32, 320): 7945.6,
 }
 
 
@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--model", default="vit_base", choices=["vit_base", "vit_small", "vit_large"])
     ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--img-size", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -48,7 +49,7 @@ def build_model(args, device):
     from devias_amd import create_model, synth
     name = {"vit_base": "slot_vit_base_patch16_224", "vit_small": "slot_vit_small_patch16_224",
             "vit_large": "slot_vit_large_patch16_224"}[args.model]
-    model = create_model(name, num_classes=400, all_frames=args.frames, tubelet_size=2, drop_path_rate=0.0, init_scale=0.001,
+    model = create_model(name, img_size=args.img_size, num_classes=400, all_frames=args.frames, tubelet_size=2, drop_path_rate=0.0, init_scale=0.001,
                          num_latents=2, head_type="linear", slot_matching="matching", agg_weights_tie=True, agg_depth=8,
                          num_scene_classes=365, compute_dtype=args.dtype)
     synth.fill_module_(model, seed=0)        # formula weights: identical on every rank, no broadcast needed
@@ -61,7 +62,7 @@ def cpu_baseline(args):
     from devias_amd import synth
     from oracle import ref_cpu
     kw = {"vit_base": {}, "vit_small": dict(embed_dim=384, num_heads=6), "vit_large": dict(embed_dim=1024, num_heads=16, depth=24)}[args.model]
-    cfg = ref_cpu.SlotViTConfig(all_frames=args.frames, **kw)
+    cfg = ref_cpu.SlotViTConfig(all_frames=args.frames, img_size=args.img_size, **kw)
     # PyTorch CPU kernels stop scaling (and thrash) far below the 100+ hardware threads of the GPU hosts; 16 threads is what
     # the reference's CPU path is timed on here -- the count actually used is what `cores` reports
     cores = min(os.cpu_count() or 1, 16)
@@ -85,7 +86,7 @@ def dominant_kernel_probe(args, device):
     class, the 128x128 MFMA GEMM, on the fc1 shape of this workload."""
     from devias_amd import ops
     D = {"vit_base": 768, "vit_small": 384, "vit_large": 1024}[args.model]
-    M = args.batch * (args.frames // 2) * 196
+    M = args.batch * (args.frames // 2) * (args.img_size // 16) ** 2
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     a = torch.randn(M, D, device=device).to(dt)
     w = (torch.randn(4 * D, D, device=device) * 0.02).to(dt)
@@ -130,10 +131,10 @@ def main():
     B = args.batch
     N = model.patch_embed.num_patches
     first = rank * B                                   # rank r owns clips [B r, B r + B) of the global batch (weak scaling)
-    x = synth.video(B, args.frames, 224, seed=1000, first=first).to(device)
+    x = synth.video(B, args.frames, args.img_size, seed=1000, first=first).to(device)
     y = synth.targets(B, 400, seed=1000, first=first).to(device)
     tl = synth.teacher_logits(B, 365, seed=1000, first=first).to(device)
-    fg196, fgN = (t.to(device) for t in synth.fg_masks(B, N, 196, seed=1000, first=first))
+    fg196, fgN = (t.to(device) for t in synth.fg_masks(B, N, (args.img_size // 16) ** 2, seed=1000, first=first))
     crit = TrainLoss(scene_criterion="KL", num_action_classes=400, slot_matching_method="matching", scene_loss_weight=4000,
                      mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0, sync_loss_dict=False)
     sync = GradSync(model) if world > 1 else None
@@ -179,7 +180,7 @@ def main():
         # secondary number: the same step + frozen teacher forward (a15) + fused AdamW update (a18)
         from devias_amd.modeling_finetune import vit_base_patch16_224
         from devias_amd.optim import FusedAdamW
-        if args.model == "vit_base":
+        if args.model == "vit_base" and args.img_size == 224:
             teacher = vit_base_patch16_224(num_classes=365, all_frames=args.frames, tubelet_size=2, use_mean_pooling=False,
                                            init_scale=0.001, compute_dtype=args.dtype)
             synth.fill_module_(teacher, seed=1)
@@ -210,16 +211,16 @@ def main():
                     "final_loss": float(fl.detach().float().sum())}
 
     clips_per_s = world * B * args.steps / wall
-    gflop = TRAIN_GFLOP_PER_CLIP.get((args.model, args.frames, 224))
+    gflop = TRAIN_GFLOP_PER_CLIP.get((args.model, args.frames, args.img_size))
     ach = clips_per_s / world * gflop / 1e3 if gflop else None       # per-GPU TFLOP/s
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
     line = {
         "metric": "clips/sec fwd+bwd, ViT-B/16 16x224^2 slot head, bs=32/GPU" if args.model == "vit_base" and args.frames == 16
-                  else f"clips/sec fwd+bwd, {args.model} {args.frames}x224^2 slot head, bs={B}/GPU",
+                  else f"clips/sec fwd+bwd, {args.model} {args.frames}x{args.img_size}^2 slot head, bs={B}/GPU",
         "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"slot-{args.model} 16-patch {args.frames}x224^2 ({N} tokens), S=2 slots, tied agg depth 8, "
+        "config": {"workload": f"slot-{args.model} 16-patch {args.frames}x{args.img_size}^2 ({N} tokens), S=2 slots, tied agg depth 8, "
                                f"B={B} clips/GPU, student fwd + matching loss + bwd" + (" + RCCL grad all-reduce (fp32, 64 MiB buckets)" if world > 1 else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False},

@@ -185,3 +185,39 @@ def test_drop_path_matches_oracle_with_the_same_masks():
     assert torch.equal(a, b_)
     m.train(); torch.manual_seed(0); c = m(xin)[2][1]; d = m(xin)[2][1]
     assert not torch.equal(c, d)
+
+
+@pytest.mark.parametrize("kw", [dict(embed_dim=1024, num_heads=16, depth=2, all_frames=4),            # ViT-L width (BASELINE config 4)
+                                dict(embed_dim=768, num_heads=12, depth=1, all_frames=4, img_size=320),   # 320^2 frames (config 5 geometry)
+                                dict(embed_dim=384, num_heads=6, depth=2, all_frames=2, num_latents=3, agg_depth=3)])
+def test_fp32_step_matches_oracle_other_geometries(kw):
+    """geometries the goldens do not cover (ViT-L width, 320x320 frames -> 400-cell mask grid, 3 slots): HIP fp32 vs the CPU oracle
+    on the same formula weights/inputs, outputs + loss + every gradient"""
+    from functools import partial
+    from devias_amd.modeling_slot import VisionTransformer
+    from devias_amd.train_loss import TrainLoss
+    cfg = ref_cpu.SlotViTConfig(**kw)
+    B = 2
+    m = VisionTransformer(img_size=cfg.img_size, patch_size=16, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+                          mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_classes=400,
+                          all_frames=cfg.all_frames, init_scale=1e-3, num_latents=cfg.num_latents, slot_matching_method="matching",
+                          agg_weights_tie=cfg.agg_weights_tie, agg_depth=cfg.agg_depth, compute_dtype="fp32")
+    synth.fill_module_(m, seed=0)
+    m = m.cuda().train()
+    x, y, tl, fg = gu.inputs(cfg, B)
+    crit = TrainLoss(scene_criterion="KL", num_action_classes=400, slot_matching_method="matching", scene_loss_weight=4000,
+                     mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0)
+    out = m(x.cuda())
+    total, logits, ld = crit(m, out, (None, tl.cuda()), y.cuda(), fg_mask=(fg[0].cuda(), fg[1].cuda()))
+    total.backward()
+    P = synth.fill_params(ref_cpu.param_shapes(cfg), seed=0)
+    ototal, ologits, old, ograds, oout, oidx = ref_cpu.train_step(P, cfg, x, y, tl, fg)
+    assert gu.rel(out[2][0].detach().cpu(), oout[2][0].detach()) < 1e-3
+    assert gu.rel(out[2][2].detach().cpu(), oout[2][2].detach()) < 1e-3 and out[2][2].shape[1] == cfg.grid ** 2
+    assert gu.rel(out[1][2].detach().cpu(), oout[1][2].detach()) < 1e-3
+    assert abs(float(total) - float(ototal)) / abs(float(ototal)) < 1e-3
+    assert crit.last_match.cpu().tolist() == [[int(a), int(b)] for a, b in zip(oidx[0], oidx[1])]
+    gmax = max(float(g.abs().max()) for g in ograds.values())
+    for n, p in m.named_parameters():
+        e = float((p.grad.cpu().double() - ograds[n].double()).abs().max() / max(float(ograds[n].abs().max()), 1e-6 * gmax))
+        assert e < 5e-3, (n, e)
