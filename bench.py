@@ -78,7 +78,7 @@ def cpu_baseline(args):
     dt = (time.perf_counter() - t0) / args.cpu_steps
     return {"value": B / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle/ref_cpu.py student fwd+loss+bwd, B={B} clips x {args.cpu_steps} timed steps (+1 warm-up), fp32, "
-                      f"{args.model} {args.frames}x224^2"}
+                      f"{args.model} {args.frames}x{args.img_size}^2"}
 
 
 def dominant_kernel_probe(args, device):
@@ -215,7 +215,7 @@ def main():
     ach = clips_per_s / world * gflop / 1e3 if gflop else None       # per-GPU TFLOP/s
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
     line = {
-        "metric": "clips/sec fwd+bwd, ViT-B/16 16x224^2 slot head, bs=32/GPU" if args.model == "vit_base" and args.frames == 16
+        "metric": "clips/sec fwd+bwd, ViT-B/16 16x224^2 slot head, bs=32/GPU" if args.model == "vit_base" and args.frames == 16 and args.img_size == 224
                   else f"clips/sec fwd+bwd, {args.model} {args.frames}x{args.img_size}^2 slot head, bs={B}/GPU",
         "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
