@@ -53,6 +53,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef f32x4 type; };
+template <> struct Raw4<bf16> { typedef bf16x4 type; };
+__device__ __forceinline__ f32x4 raw_to_f32(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 raw_to_f32(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+
 // backward: workgroup = 4 waves, each wave walks LNB_ROWS/4 rows; lane-owned columns are fixed so the
 // dgamma/dbeta partial sums live in registers and are combined across the 4 waves through LDS at the end.
 template <typename T, int NIT>
@@ -72,20 +78,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         dc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int r0 = blockIdx.x * LNB_ROWS;
+    // software pipeline over rows: the (packed) loads of row r+4 are issued before the reductions of row r, so each wave keeps
+    // two rows of dy / x / dres in flight (the kernel is latency-bound otherwise: one dependent HBM round trip per row)
+    typedef typename Raw4<T>::type raw4;
+    raw4 nd[NIT], nx[NIT], nr[NIT];
+    float nmu = 0.f, nrs = 0.f;
+    auto issue = [&](int row) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = (it * 64 + lane) * 4;
+            if (c < D) {
+                nd[it] = *reinterpret_cast<const raw4*>(dy + (int64_t)row * D + c);
+                nx[it] = *reinterpret_cast<const raw4*>(x + (int64_t)row * D + c);
+                if (dres) nr[it] = *reinterpret_cast<const raw4*>(dres + (int64_t)row * D + c);
+            }
+        }
+        nmu = mean[row]; nrs = rstd[row];
+    };
+    if (r0 + wave < M) issue(r0 + wave);
     for (int rr = wave; rr < LNB_ROWS; rr += LN_WAVES) {
         const int row = r0 + rr;
         if (row >= M) break;
-        const float mu = mean[row], rs = rstd[row];
-        const T* dyr = dy + (int64_t)row * D;
-        const T* xr = x + (int64_t)row * D;
+        raw4 cd[NIT], cx[NIT], cr[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) { cd[it] = nd[it]; cx[it] = nx[it]; cr[it] = nr[it]; }
+        const float mu = nmu, rs = nrs;
+        if (rr + LN_WAVES < LNB_ROWS && row + LN_WAVES < M) issue(row + LN_WAVES);
         f32x4 a[NIT], xh[NIT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int c = (it * 64 + lane) * 4;
             if (c < D) {
-                f32x4 d = load4(dyr + c);
-                f32x4 xv = load4(xr + c);
+                const f32x4 d = raw_to_f32(cd[it]);
+                const f32x4 xv = raw_to_f32(cx[it]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float h = (xv[j] - mu) * rs;
@@ -107,7 +133,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rs * (a[it][j] - m1 - xh[it][j] * m2);
-                if (dres) o += load4(dres + (int64_t)row * D + c);
+                if (dres) o += raw_to_f32(cr[it]);
                 dc[it] += o;
                 store4(dxr + c, o);
             }
