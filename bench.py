@@ -124,7 +124,7 @@ def main():
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())     # (ranks > GPUs only happens in the gloo plumbing test)
     torch.cuda.set_device(device)
 
     model = build_model(args, device)
@@ -215,7 +215,7 @@ def main():
     ach = clips_per_s / world * gflop / 1e3 if gflop else None       # per-GPU TFLOP/s
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
     line = {
-        "metric": "clips/sec fwd+bwd, ViT-B/16 16x224^2 slot head, bs=32/GPU" if args.model == "vit_base" and args.frames == 16 and args.img_size == 224
+        "metric": "clips/sec fwd+bwd, ViT-B/16 16x224^2 slot head, bs=32/GPU" if args.model == "vit_base" and args.frames == 16 and args.img_size == 224 and B == 32
                   else f"clips/sec fwd+bwd, {args.model} {args.frames}x{args.img_size}^2 slot head, bs={B}/GPU",
         "value": clips_per_s, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
