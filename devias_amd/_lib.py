@@ -71,7 +71,12 @@ PROTOTYPES = {
     "devias_head_match_loss_bwd": (c_int, [POINTER(LossDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devias_head_match_loss_workspace_bytes": (c_int64, [_I]),
     "devias_adamw_step": (c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "devias_grad_sumsq_multi": (c_int, [_P, _P, _P, _I, _P, _P]),
+    "devias_clip_coef": (c_int, [_P, _I, _F, _P, _P]),
+    "devias_adamw_multi": (c_int, [_P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
 }
+OPT_CHUNK = 16384          # DEVIAS_OPT_CHUNK
+OPT_TENSOR_BYTES = 64      # sizeof(devias_opt_tensor)
 
 _lib = None
 

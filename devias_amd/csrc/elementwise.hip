@@ -168,6 +168,83 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// ---- multi-tensor optimizer: one workgroup per DEVIAS_OPT_CHUNK-element piece of some tensor -------------------------
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(const devias_opt_tensor* __restrict__ table, const int32_t* __restrict__ ct,
+                                                          const int32_t* __restrict__ ci, float* __restrict__ partials) {
+    __shared__ float red[4];
+    const devias_opt_tensor t = table[ct[blockIdx.x]];
+    const int64_t lo = (int64_t)ci[blockIdx.x] * DEVIAS_OPT_CHUNK;
+    const int64_t hi = lo + DEVIAS_OPT_CHUNK < t.n ? lo + DEVIAS_OPT_CHUNK : t.n;
+    const float* g = t.grad + lo;
+    const int len = (int)(hi - lo);
+    float s = 0.f;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        const int n4 = len >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            float4 v = reinterpret_cast<const float4*>(g)[i];
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < len; i += 256) s += g[i] * g[i];
+    } else {
+        for (int i = threadIdx.x; i < len; i += 256) s += g[i] * g[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partials, int n, float max_norm, float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;                                               // fixed order: thread t owns partials t, t+256, ...
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float norm = sqrtf(red[0]);
+        out[0] = norm;
+        float c = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.f;
+        out[1] = c < 1.f ? c : 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const devias_opt_tensor* __restrict__ table, const int32_t* __restrict__ ct,
+                                                          const int32_t* __restrict__ ci, float b1, float b2, float eps, float gscale,
+                                                          const float* __restrict__ gscale_dev) {
+    const devias_opt_tensor t = table[ct[blockIdx.x]];
+    const int64_t lo = (int64_t)ci[blockIdx.x] * DEVIAS_OPT_CHUNK;
+    const int64_t hi = lo + DEVIAS_OPT_CHUNK < t.n ? lo + DEVIAS_OPT_CHUNK : t.n;
+    const int len = (int)(hi - lo);
+    if (gscale_dev) gscale *= *gscale_dev;
+    float* p = t.param + lo; const float* g = t.grad + lo; float* m = t.exp_avg + lo; float* v = t.exp_avg_sq + lo;
+    const float decay = 1.0f - t.lr * t.weight_decay, step = t.lr / t.bc1, ib2 = 1.0f / t.bc2_sqrt;
+    auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+        gi *= gscale;
+        pi *= decay;                                              // decoupled weight decay (torch.optim.AdamW)
+        mi = mi + (1.0f - b1) * (gi - mi);                        // exp_avg.lerp_(grad, 1-beta1)
+        vi = b2 * vi + (1.0f - b2) * gi * gi;
+        pi = pi - step * (mi / (sqrtf(vi) * ib2 + eps));
+    };
+    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                      reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    int done = 0;
+    if (al) {
+        const int n4 = len >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            float4 pv = reinterpret_cast<float4*>(p)[i], gv = reinterpret_cast<const float4*>(g)[i];
+            float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+            upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
+            reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+        }
+        done = n4 << 2;
+    }
+    for (int i = done + threadIdx.x; i < len; i += 256) upd(p[i], g[i], m[i], v[i]);
+}
+
 inline int grid_for(int64_t n, int per_thread = 1) {
     int64_t b = (n / per_thread + 255) / 256;
     if (b < 1) b = 1;
@@ -295,5 +372,32 @@ extern "C" int devias_adamw_step(float* param, const float* grad, float* exp_avg
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                        beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
     DEVIAS_CHECK_LAUNCH("devias_adamw_step");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_grad_sumsq_multi(const devias_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index,
+                                       int32_t n_chunks, float* partials, void* stream) {
+    DEVIAS_REQUIRE(table && chunk_tensor && chunk_index && partials && n_chunks >= 0, "devias_grad_sumsq_multi: bad args");
+    if (n_chunks == 0) return DEVIAS_OK;
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor, chunk_index, partials);
+    DEVIAS_CHECK_LAUNCH("devias_grad_sumsq_multi");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_clip_coef(const float* partials, int32_t n_chunks, float max_norm, float* out, void* stream) {
+    DEVIAS_REQUIRE(out && n_chunks >= 0 && (partials || n_chunks == 0), "devias_clip_coef: bad args");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_chunks, max_norm, out);
+    DEVIAS_CHECK_LAUNCH("devias_clip_coef");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_adamw_multi(const devias_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index,
+                                  int32_t n_chunks, float beta1, float beta2, float eps, float grad_scale,
+                                  const float* grad_scale_dev, void* stream) {
+    DEVIAS_REQUIRE(table && chunk_tensor && chunk_index && n_chunks >= 0, "devias_adamw_multi: bad args");
+    if (n_chunks == 0) return DEVIAS_OK;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor, chunk_index, beta1, beta2,
+                       eps, grad_scale, grad_scale_dev);
+    DEVIAS_CHECK_LAUNCH("devias_adamw_multi");
     return DEVIAS_OK;
 }

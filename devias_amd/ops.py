@@ -361,3 +361,25 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
         _chk(t, "adamw_step." + n, torch.float32)
     _lib.check(_lib.load().devias_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(),
                                              lr, beta1, beta2, eps, weight_decay, step, grad_scale, _stream()), "devias_adamw_step")
+
+
+def grad_sumsq_multi(table, chunk_tensor, chunk_index, partials):
+    """devias_grad_sumsq_multi: table uint8 [n_tensors, 64] (devias_opt_tensor records), chunk lists int32, partials fp32."""
+    _chk(table, "grad_sumsq_multi.table", torch.uint8); _chk(partials, "grad_sumsq_multi.partials", torch.float32)
+    _chk(chunk_tensor, "grad_sumsq_multi.chunk_tensor", torch.int32); _chk(chunk_index, "grad_sumsq_multi.chunk_index", torch.int32)
+    _lib.check(_lib.load().devias_grad_sumsq_multi(table.data_ptr(), chunk_tensor.data_ptr(), chunk_index.data_ptr(), chunk_tensor.numel(),
+                                                   partials.data_ptr(), _stream()), "devias_grad_sumsq_multi")
+
+
+def clip_coef(partials, n_chunks, max_norm, out):
+    _chk(partials, "clip_coef.partials", torch.float32); _chk(out, "clip_coef.out", torch.float32)
+    _lib.check(_lib.load().devias_clip_coef(partials.data_ptr(), n_chunks, float(max_norm), out.data_ptr(), _stream()), "devias_clip_coef")
+
+
+def adamw_multi(table, chunk_tensor, chunk_index, beta1, beta2, eps, grad_scale=1.0, grad_scale_dev=None):
+    _chk(table, "adamw_multi.table", torch.uint8)
+    _chk(chunk_tensor, "adamw_multi.chunk_tensor", torch.int32); _chk(chunk_index, "adamw_multi.chunk_index", torch.int32)
+    if grad_scale_dev is not None:
+        _chk(grad_scale_dev, "adamw_multi.grad_scale_dev", torch.float32)
+    _lib.check(_lib.load().devias_adamw_multi(table.data_ptr(), chunk_tensor.data_ptr(), chunk_index.data_ptr(), chunk_tensor.numel(),
+                                              beta1, beta2, eps, grad_scale, _p(grad_scale_dev), _stream()), "devias_adamw_multi")

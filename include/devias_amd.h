@@ -209,6 +209,38 @@ int devias_adamw_step(float* param, const float* grad, float* exp_avg, float* ex
                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                       float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Multi-tensor optimizer step: the whole parameter list in ONE launch per operation.
+ * Replaces the per-group / per-tensor Python loops of torch.optim.AdamW as created by utils/optim_factory.py:132-133 over
+ * the layer-decay groups of get_parameter_groups (:49-93), the gradient norm of utils/utils.py:409-421 (get_grad_norm_:
+ * 2-norm of the per-tensor 2-norms) and torch.nn.utils.clip_grad_norm_ as called at utils/utils.py:391.
+ *
+ * `table` is a DEVICE array of n_tensors descriptors (per tensor: pointers, length and that tensor's group
+ * hyper-parameters lr = schedule·lr_scale, weight_decay, bias corrections of its step).  `chunk_tensor[c]`,
+ * `chunk_index[c]` (device int32 [n_chunks]) enumerate fixed DEVIAS_OPT_CHUNK-element pieces of the tensors, one workgroup each.
+ *   devias_grad_sumsq_multi: partials[c] = sum of squares of chunk c (fp32, fixed order inside the chunk)
+ *   devias_clip_coef:        out[0] = sqrt(sum_c partials[c]) (fixed order), out[1] = max_norm > 0 ?
+ *                            min(1, max_norm / (out[0] + 1e-6)) : 1   (clip_grad_norm_ semantics)
+ *   devias_adamw_multi:      g' = g * grad_scale * (grad_scale_dev ? *grad_scale_dev : 1); AdamW update as devias_adamw_step
+ * No host synchronisation anywhere: the clip coefficient stays on the device.
+ * ------------------------------------------------------------------------------------------------- */
+#define DEVIAS_OPT_CHUNK 16384
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    float lr, weight_decay, bc1, bc2_sqrt;   /* bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step) */
+    int64_t reserved;                         /* pads the descriptor to 64 bytes */
+} devias_opt_tensor;
+int devias_grad_sumsq_multi(const devias_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index,
+                            int32_t n_chunks, float* partials, void* stream);
+int devias_clip_coef(const float* partials, int32_t n_chunks, float max_norm, float* out, void* stream);
+int devias_adamw_multi(const devias_opt_tensor* table, const int32_t* chunk_tensor, const int32_t* chunk_index,
+                       int32_t n_chunks, float beta1, float beta2, float eps, float grad_scale,
+                       const float* grad_scale_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -321,3 +321,62 @@ def test_adamw_matches_torch():
         opt.step()
         o.adamw_step(p, g * step, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, step)
     assert rel(p, ref.detach()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ multi-tensor optimizer
+def _opt_setup(seed=70):
+    shapes = [(3,), (16385,), (257, 129), (1, 1), (40000,), (765, 768), (5, 7, 11), (16384,), (32768,)]
+    ps = [rnd(*s, seed=seed + i) for i, s in enumerate(shapes)]
+    groups = lambda tensors: [  # noqa: E731
+        {"params": tensors[0:3], "weight_decay": 0.05, "lr_scale": 0.1}, {"params": tensors[3:6], "weight_decay": 0.0, "lr_scale": 1.0},
+        {"params": tensors[6:], "weight_decay": 0.01, "lr_scale": 0.5}]
+    return shapes, ps, groups
+
+
+@pytest.mark.parametrize("max_norm", [None, 0.0, 0.5, 1e9])
+def test_fused_adamw_multi_tensor_matches_torch(max_norm):
+    """whole parameter list in one launch, per-group lr (schedule x lr_scale) and weight decay, fused global-norm clipping ==
+    torch.optim.AdamW + torch.nn.utils.clip_grad_norm_ (utils/optim_factory.py:132-133, utils/utils.py:388-394)"""
+    from devias_amd.optim import FusedAdamW
+    shapes, ps, groups = _opt_setup()
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [p.clone().requires_grad_(True) for p in ps]
+    topt = torch.optim.AdamW(groups(ref), lr=1e-3, betas=(0.9, 0.95), eps=1e-8)
+    fopt = FusedAdamW(groups(mine), lr=1e-3, betas=(0.9, 0.95), eps=1e-8)
+    for step in range(1, 6):
+        lr = 1e-3 * (1.0 - 0.1 * step)
+        for opt in (topt, fopt):
+            for g in opt.param_groups:
+                g["lr"] = lr * g["lr_scale"]
+        grads = [rnd(*s, seed=100 * step + i, scale=0.3 * step) for i, s in enumerate(shapes)]
+        skip = 4 if step == 3 else -1                      # a parameter without a gradient in one step (plan is rebuilt)
+        for i, (r, m) in enumerate(zip(ref, mine)):
+            r.grad = None if i == skip else grads[i].clone()
+            m.grad = None if i == skip else grads[i].clone()
+        if max_norm is not None:
+            with_grad = [r for r in ref if r.grad is not None]
+            tn = torch.nn.utils.clip_grad_norm_(with_grad, max_norm) if max_norm > 0 else \
+                torch.norm(torch.stack([torch.norm(r.grad, 2.0) for r in with_grad]), 2.0)          # get_grad_norm_, utils/utils.py:409-421
+        topt.step()
+        fopt.step(max_norm=max_norm)
+        if max_norm is not None:
+            assert abs(float(fopt.last_grad_norm) - float(tn)) <= 2e-6 * float(tn)
+        worst = max(rel(m.detach(), r.detach()) for m, r in zip(mine, ref))
+        assert worst < 2e-6, (step, worst)
+    for m, r in zip(mine, ref):
+        assert rel(fopt.state[m]["exp_avg_sq"], topt.state[r]["exp_avg_sq"]) < 2e-6
+
+
+def test_fused_adamw_multi_equals_per_tensor_path_bitwise():
+    from devias_amd.optim import FusedAdamW
+    shapes, ps, groups = _opt_setup(seed=80)
+    a = [p.clone().requires_grad_(True) for p in ps]
+    b = [p.clone().requires_grad_(True) for p in ps]
+    oa = FusedAdamW(groups(a), lr=2e-3, multi_tensor=True)
+    ob = FusedAdamW(groups(b), lr=2e-3, multi_tensor=False)
+    for step in range(3):
+        for i, (x, y) in enumerate(zip(a, b)):
+            g = rnd(*shapes[i], seed=300 + 10 * step + i)
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    assert max(rel(x.detach(), y.detach()) for x, y in zip(a, b)) < 1e-6

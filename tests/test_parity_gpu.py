@@ -221,3 +221,29 @@ def test_fp32_step_matches_oracle_other_geometries(kw):
     for n, p in m.named_parameters():
         e = float((p.grad.cpu().double() - ograds[n].double()).abs().max() / max(float(ograds[n].abs().max()), 1e-6 * gmax))
         assert e < 5e-3, (n, e)
+
+
+def test_validation_one_epoch_and_final_test(tmp_path):
+    """engine/engine_for_slot.py:215-303: eval forward, CE on the selected action logits, top-1/5; compared with the same
+    metrics computed from the ORACLE's forward of the same clips (fp32)"""
+    from devias_amd.engine_for_slot import final_test, validation_one_epoch
+    fx, cfg, B = gu.load("vits_t8")
+    model = build(cfg, "fp32")
+    x, y, tl, fg = gu.inputs(cfg, B)
+    P = synth.fill_params(ref_cpu.param_shapes(cfg), seed=0)
+    with torch.no_grad():
+        out = ref_cpu.student_forward(P, cfg, x)
+    logits = out[1][0].float()
+    ce = float(torch.nn.functional.cross_entropy(logits, y, reduction="mean"))
+    top = logits.topk(5, dim=1).indices
+    acc1 = 100.0 * float((top[:, :1] == y[:, None]).any(1).float().mean())
+    acc5 = 100.0 * float((top == y[:, None]).any(1).float().mean())
+    loader = [(x, y), (x, y)]
+    st = validation_one_epoch(loader, model, "cuda")
+    assert abs(st["loss"] - ce) < 1e-4 * abs(ce) and st["acc1"] == acc1 and st["acc5"] == acc5
+    f = tmp_path / "final.txt"
+    ids = ["vid%d" % i for i in range(B)]
+    st2 = final_test([(x, y, ids, torch.zeros(B, dtype=torch.int64), torch.ones(B, dtype=torch.int64))], model, "cuda", str(f))
+    lines = f.read_text().splitlines()
+    assert len(lines) == 1 + B and lines[1].startswith("vid0 [") and lines[1].endswith(" %d 0 1" % int(y[0]))
+    assert abs(st2["loss"] - ce) < 1e-4 * abs(ce)

@@ -280,6 +280,55 @@ def generate_state_dict_keys(ref):
     print("[state_dict_keys]", {k: len(v) for k, v in out.items()})
 
 
+def generate_optim(ref):
+    """Parameter groups (utils/optim_factory.py), cosine schedules and get_grad_norm_ (utils/utils.py) of the REAL reference ->
+    tests/golden/optim_factory.json (names, scales and schedule values only)."""
+    import contextlib
+    import io
+    import json
+    for mod, names in (("adafactor", ["Adafactor"]), ("adahessian", ["Adahessian"]), ("adamp", ["AdamP"]), ("lookahead", ["Lookahead"]),
+                       ("nadam", ["Nadam"]), ("nvnovograd", ["NvNovoGrad"]), ("radam", ["RAdam"]), ("rmsprop_tf", ["RMSpropTF"]),
+                       ("sgdp", ["SGDP"])):
+        m = types.ModuleType("timm.optim." + mod)
+        for n in names:
+            setattr(m, n, object)
+        sys.modules["timm.optim." + mod] = m
+    sys.modules.setdefault("timm.optim", types.ModuleType("timm.optim"))
+    import utils.optim_factory as rof
+    import utils.utils as ru
+    reg = ref[0]
+    out = {"groups": {}, "schedules": []}
+    models = {
+        "tied_s2_d8": reg["slot_vit_base_patch16_224"](num_classes=400, all_frames=8, num_latents=2, slot_matching_method="matching",
+                                                       agg_weights_tie=True, agg_depth=8, num_scene_classes=365),
+        "untied_s4_d4": reg["slot_vit_base_patch16_224"](num_classes=400, all_frames=8, num_latents=4, slot_matching_method="matching",
+                                                         agg_weights_tie=False, agg_depth=4, num_scene_classes=365),
+    }
+    for mname, m in models.items():
+        nl = m.get_num_layers()
+        for tag, decay, agg_scale in (("ld0.75", 0.75, 0.1), ("ld0.9_agg0.5", 0.9, 0.5), ("flat", 1.0, 0.1)):
+            assigner = rof.LayerDecayValueAssigner([decay ** (nl + 1 - i) for i in range(nl + 2)]) if decay < 1.0 else None
+            with contextlib.redirect_stdout(io.StringIO()) as buf:
+                rof.get_parameter_groups(m, 0.05, m.no_weight_decay(), assigner.get_layer_id if assigner else None,
+                                         assigner.get_scale if assigner else None, agg_block_scale=agg_scale)
+            txt = buf.getvalue()
+            names = json.loads(txt[txt.index("{"):])
+            out["groups"][f"{mname}.{tag}"] = {"num_layers": nl, "layer_decay": decay, "agg_block_scale": agg_scale, "weight_decay": 0.05,
+                                               "groups": [[k, v["weight_decay"], v["lr_scale"], v["params"]] for k, v in names.items()]}
+    for kw in (dict(base_value=1e-3, final_value=1e-6, epochs=5, niter_per_ep=7, warmup_epochs=2, start_warmup_value=1e-6),
+               dict(base_value=0.05, final_value=0.05, epochs=3, niter_per_ep=4),
+               dict(base_value=2e-3, final_value=1e-5, epochs=4, niter_per_ep=10, warmup_epochs=1, start_warmup_value=0.0, warmup_steps=13),
+               dict(base_value=2e-3, final_value=1e-5, epochs=4, niter_per_ep=10, warmup_epochs=0, warmup_steps=5)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            try:
+                sched = [float.hex(float(v)) for v in ru.cosine_scheduler(**kw)]
+            except AssertionError:
+                sched = "AssertionError"
+        out["schedules"].append({"kwargs": kw, "values": sched})
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "optim_factory.json"), "w"))
+    print("[optim]", {k: len(v["groups"]) for k, v in out["groups"].items()}, [len(s["values"]) for s in out["schedules"]])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -293,6 +342,8 @@ def main():
         generate_teacher(ref)
     if args.only in (None, "keys"):
         generate_state_dict_keys(ref)
+    if args.only in (None, "optim"):
+        generate_optim(ref)
 
 
 if __name__ == "__main__":
