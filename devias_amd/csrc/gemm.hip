@@ -197,7 +197,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
                     *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 y = gelu_fast2(f32x2{v[e], v[e + 1]});
+                    v[e] = y[0]; v[e + 1] = y[1];
+                }
             } else if (p.act == DEVIAS_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -206,10 +209,15 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
                 for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
             } else if (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) {
                 const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)m * p.ld_aux + ncol);
+                if (p.act == DEVIAS_ACT_DGELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float a = (float)a8[e];
-                    v[e] = (p.act == DEVIAS_ACT_DGELU) ? v[e] * dgelu_fast(a) : (a > 0.f ? v[e] : 0.f);
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 d = dgelu_fast2(f32x2{(float)a8[e], (float)a8[e + 1]});
+                        v[e] *= d[0]; v[e + 1] *= d[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)a8[e] > 0.f ? v[e] : 0.f;
                 }
             }
             if (p.row_scale) {
@@ -671,6 +679,295 @@ __global__ __launch_bounds__(SS_NT, OCC) void gemm_ss_kernel(GemmP p) {
 
 
 
+// =====================================================================================================================
+// Persistent 256 x 128 x 64 kernel: ONE workgroup of 4 waves per CU (one wave per SIMD, 512-register budget) walks a list of
+// output tiles.  What it removes is the per-tile prologue and the HBM-write-bound epilogue burst of the kernels above:
+//   * the operand ring (3 stages x 48 KiB, LDS-DMA, prefetch distance 2) runs CONTINUOUSLY across tile boundaries: the first
+//     K-tiles of tile i+1 are in flight while tile i finishes;
+//   * at the end of a tile the accumulators go through a private 4 KiB LDS region per wave (16 rows at a time), get their
+//     epilogue (bias, GELU / dGELU, row scale, residual; residual / aux_in rows were prefetched during the last K-tile), and
+//     are PARKED in registers as row-contiguous bf16 pieces (16 B per lane, whole 128-B lines);
+//   * the parked pieces are stored two per K-iteration during the NEXT tile's K loop, so the output leaves at the average
+//     rate of the GEMM (~1-2 TB/s), under the MFMAs, instead of in bursts while the matrix cores idle.
+// vmcnt is counted exactly (stores count on gfx950): at the top of K-iteration g only the operations issued after the loads
+// of K-tile g may be outstanding.  EPI is a compile-time epilogue shape (1 = aux_in, 2 = residual, 4 = aux_out) so that only the
+// register arrays a GEMM needs exist.
+// =====================================================================================================================
+enum { PK_BM = 256, PK_BN = 128, PK_NT = 256, PK_STAGE = 49152, PK_NSTAGE = 3, PK_SCRATCH = 4096, PK_LPW = 12 };
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// n is wave-uniform; only the counts this kernel produces exist as exact cases, anything else waits for everything
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+    switch (n) {
+        case 12: wait_vm<12>(); break;
+        case 14: wait_vm<14>(); break;
+        case 16: wait_vm<16>(); break;
+        case 2: wait_vm<2>(); break;
+        case 4: wait_vm<4>(); break;
+        default: wait_vm<0>(); break;
+    }
+}
+
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(PK_NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pk_kernel(GemmP p) {
+    constexpr bool HAS_AUXIN = (EPI & 1) != 0, HAS_RES = (EPI & 2) != 0, HAS_AUXOUT = (EPI & 4) != 0;
+    __shared__ __attribute__((aligned(16))) char smem[PK_NSTAGE * PK_STAGE + 4 * PK_SCRATCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x;
+    const int nk = p.K / 64;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    bf16* Cb = reinterpret_cast<bf16*>(p.C);
+    bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
+    const bf16* aux_in = reinterpret_cast<const bf16*>(p.aux_in);
+    const bf16* res = reinterpret_cast<const bf16*>(p.res);
+    char* scratch = smem + PK_NSTAGE * PK_STAGE + wave * PK_SCRATCH;
+
+    auto coords = [&](int v, int& m0, int& n0) {
+        int tm, tn;
+        tile_coords(xcd_remap(v, ntiles), p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        m0 = tm * PK_BM; n0 = tn * PK_BN;
+    };
+    // LDS-DMA addressing: per-lane byte offsets are constants of the kernel; everything that changes (tile origin, K-tile,
+    // instruction index) is wave-uniform and lives in the scalar base -> no vector ALU work per DMA instruction
+    const uint32_t vo_a = (uint32_t)(((lane >> 3) * p.lda + (((lane & 7) ^ ((lane >> 3) & 7)) * 8)) * 2);          // A: k contiguous
+    uint32_t vo_b[2];
+    if constexpr (!TB) {
+        vo_b[0] = vo_b[1] = (uint32_t)(((lane >> 3) * p.ldb + (((lane & 7) ^ ((lane >> 3) & 7)) * 8)) * 2);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                      // k-strided rows: 4 k-rows x 16 slots of 16 B per instruction
+            const int slot = lane & 15, f = (lane >> 4) | (h << 2);
+            vo_b[h] = (uint32_t)(((lane >> 4) * p.ldb + ((((slot >> 1) ^ f)) << 4) + (slot & 1) * 8) * 2);
+        }
+    }
+    // one LDS-DMA instruction (1 KiB) of the 12 this wave owns per K-tile: n < 8 -> A rows, else B
+    auto issue_one = [&](int n, int m0, int n0, int kt, int stage) {
+        char* s = smem + stage * PK_STAGE;
+        if (n < 8) {
+            const int r8 = (wave * 8 + n) * 8;
+            const char* ub = reinterpret_cast<const char*>(A + (int64_t)(m0 + r8) * p.lda + kt * 64);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo_a), (lds_void_ptr)(s + r8 * 128), 16, 0, 0);
+        } else if constexpr (!TB) {
+            const int r8 = (wave * 4 + (n - 8)) * 8;
+            const char* ub = reinterpret_cast<const char*>(B + (int64_t)(n0 + r8) * p.ldb + kt * 64);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo_b[0]), (lds_void_ptr)(s + 32768 + r8 * 128), 16, 0, 0);
+        } else {
+            const int kb = (wave * 4 + (n - 8)) * 4;
+            const char* ub = reinterpret_cast<const char*>(B + (int64_t)(kt * 64 + kb) * p.ldb + n0);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo_b[((n - 8) >> 1) & 1]), (lds_void_ptr)(s + 32768 + kb * 256), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int m0, int n0, int kt, int stage) {
+#pragma unroll
+        for (int n = 0; n < PK_LPW; ++n) issue_one(n, m0, n0, kt, stage);
+    };
+
+    int v = blockIdx.x;
+    int m0, n0, m0n = 0, n0n = 0;
+    coords(v, m0, n0);
+    bool has_next = v + G < ntiles;
+    if (has_next) coords(v + G, m0n, n0n);
+    issue(m0, n0, 0, 0);
+    issue(m0, n0, 1, 1);                                   // nk >= 2 (host)
+    int st = 0;                                            // ring stage of the current K-tile
+    int pend = PK_LPW;                                     // operations issued after the loads of the current K-tile
+    bool parked = false;
+    int pm = 0, pn = 0;                                    // origin of this wave's parked 128 x 64 block
+    u32x4 park[16], park2[HAS_AUXOUT ? 16 : 1];
+    const int rr = lane >> 3, cl = (lane & 7) * 8;         // piece geometry: row inside an 8-row group, first of 8 columns
+
+#define PK_STORE(q)                                                                                                      \
+    {                                                                                                                    \
+        const int row_ = ((q) >> 1) * 16 + ((q) & 1) * 8 + rr;                                                           \
+        *reinterpret_cast<u32x4*>(Cb + (int64_t)(pm + row_) * p.ldc + pn + cl) = park[q];                                \
+        if constexpr (HAS_AUXOUT) *reinterpret_cast<u32x4*>(aux_out + (int64_t)(pm + row_) * p.ld_aux + pn + cl) = park2[q]; \
+    }
+#define PK_STORE_STEP(i) case i: PK_STORE(2 * i) PK_STORE(2 * i + 1) break;
+#define PK_STORE_SWITCH(i) switch (i) { PK_STORE_STEP(0) PK_STORE_STEP(1) PK_STORE_STEP(2) PK_STORE_STEP(3) PK_STORE_STEP(4) PK_STORE_STEP(5) PK_STORE_STEP(6) PK_STORE_STEP(7) default: break; }
+    constexpr int NS_STEP = HAS_AUXOUT ? 4 : 2;            // store instructions per store step
+
+    for (;;) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 pre_aux[HAS_AUXIN ? 16 : 1], pre_res[HAS_RES ? 16 : 1];
+        f32x4 bias4[4];
+        const int mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vm_dyn(pend);                             // this wave's LDS-DMA for the current K-tile has landed
+            __builtin_amdgcn_s_barrier();                  // ... everyone's has, and stage (st + 2) % 3 is free again
+            int ns = 0;
+            if (parked && kt < 8) { PK_STORE_SWITCH(kt) ns = NS_STEP; }
+            // K-tile g + 2 of the continuous stream: this tile's, or the next tile's first ones; when nothing is left the (free)
+            // stage is filled with a harmless re-read so that the loop body stays one basic block for the scheduler
+            const int k2 = kt + 2;
+            int s2 = st + 2; if (s2 >= PK_NSTAGE) s2 -= PK_NSTAGE;
+            const bool same = k2 < nk;
+            const int lm0 = (same || !has_next) ? m0 : m0n, ln0 = (same || !has_next) ? n0 : n0n;
+            const int lk = same ? k2 : (has_next ? k2 - nk : 0);
+            pend = ns + PK_LPW;
+            if (kt == nk - 1) {                            // what the epilogue will read: fetch it under the last MFMAs
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 16 + (lane >> 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias) pend = 99;
+                if constexpr (HAS_AUXIN) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        pre_aux[q] = *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)(mrow0 + (q >> 1) * 16 + (q & 1) * 8 + rr) * p.ld_aux + ncol0 + cl);
+                    pend = 99;
+                }
+                if constexpr (HAS_RES) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int m = mrow0 + (q >> 1) * 16 + (q & 1) * 8 + rr;
+                        const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+                        pre_res[q] = *reinterpret_cast<const bf16x8*>(res + (int64_t)mr * p.ldr + ncol0 + cl);
+                    }
+                    pend = 99;
+                }
+            }
+            const char* sA = smem + st * PK_STAGE;
+            const char* sB = sA + 32768;
+            // 64 MFMAs in 16 steps of 4 (one A row-tile x 4 B column-tiles); each step also issues one of the 12 LDS-DMA
+            // instructions of K-tile g + 2 and the LDS reads of fragments needed two phases later.  The order is pinned step
+            // by step: with one wave per SIMD nothing else hides DMA issue or LDS latency.
+            bf16x8 fb0[4], fb1[4], fa0[4], fa1[4], fa2[4], fa3[4];
+#define PK_RA(ks, ih, i) read_frag_ss<TA, PK_BM>(sA, wm * 128 + ((ih) * 4 + (i)) * 16, ks, lane)
+#define PK_RB(ks, j) read_frag_ss<TB, PK_BN>(sB, wn * 64 + (j) * 16, ks, lane)
+#define PK_MM4(ih, i, fb, fa) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[(ih) * 4 + (i)][j] = mfma16(fb[j], fa[i], acc[(ih) * 4 + (i)][j]);
+#define PK_SB __builtin_amdgcn_sched_barrier(0);
+#define PK_DMA(n) issue_one(n, lm0, ln0, lk, s2);
+            PK_SB
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb0[j] = PK_RB(0, j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa0[i] = PK_RA(0, 0, i);
+            PK_SB
+            PK_MM4(0, 0, fb0, fa0) PK_DMA(0) fa1[0] = PK_RA(0, 1, 0); fb1[0] = PK_RB(1, 0); PK_SB
+            PK_MM4(0, 1, fb0, fa0) PK_DMA(1) fa1[1] = PK_RA(0, 1, 1); fb1[1] = PK_RB(1, 1); PK_SB
+            PK_MM4(0, 2, fb0, fa0) PK_DMA(2) fa1[2] = PK_RA(0, 1, 2); fb1[2] = PK_RB(1, 2); PK_SB
+            PK_MM4(0, 3, fb0, fa0) PK_DMA(3) fa1[3] = PK_RA(0, 1, 3); fb1[3] = PK_RB(1, 3); PK_SB
+            PK_MM4(1, 0, fb0, fa1) PK_DMA(4) fa2[0] = PK_RA(1, 0, 0); PK_SB
+            PK_MM4(1, 1, fb0, fa1) PK_DMA(5) fa2[1] = PK_RA(1, 0, 1); PK_SB
+            PK_MM4(1, 2, fb0, fa1) PK_DMA(6) fa2[2] = PK_RA(1, 0, 2); PK_SB
+            PK_MM4(1, 3, fb0, fa1) PK_DMA(7) fa2[3] = PK_RA(1, 0, 3); PK_SB
+            PK_MM4(0, 0, fb1, fa2) PK_DMA(8) fa3[0] = PK_RA(1, 1, 0); PK_SB
+            PK_MM4(0, 1, fb1, fa2) PK_DMA(9) fa3[1] = PK_RA(1, 1, 1); PK_SB
+            PK_MM4(0, 2, fb1, fa2) PK_DMA(10) fa3[2] = PK_RA(1, 1, 2); PK_SB
+            PK_MM4(0, 3, fb1, fa2) PK_DMA(11) fa3[3] = PK_RA(1, 1, 3); PK_SB
+            PK_MM4(1, 0, fb1, fa3) PK_SB
+            PK_MM4(1, 1, fb1, fa3) PK_SB
+            PK_MM4(1, 2, fb1, fa3) PK_SB
+            PK_MM4(1, 3, fb1, fa3) PK_SB
+#undef PK_RA
+#undef PK_RB
+#undef PK_MM4
+#undef PK_SB
+#undef PK_DMA
+            if (++st == PK_NSTAGE) st = 0;
+        }
+
+        // ---- tile end: pieces the K loop was too short to store, then epilogue + park ---------------------------------
+        if (parked && nk < 8) {
+            for (int i = nk; i < 8; ++i) { PK_STORE_SWITCH(i) }
+            pend = 99;
+        }
+        if (!(p.debug & 32) || acc[0][0][0] == 12345.678f) {
+            const int lm = lane & 15, g = lane >> 4;
+            float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const int c0 = (lane & 7) * 2;
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f32x4*>(scratch + lm * 256 + (((4 * j + g) ^ lm) << 4)) = acc[pass][j] + bias4[j];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int q = pass * 2 + it;
+                    const int row = it * 8 + rr;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((c0 ^ (row & 15)) << 4));
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(scratch + row * 256 + (((c0 + 1) ^ (row & 15)) << 4));
+                    float vv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const int m = mrow0 + pass * 16 + row;
+                    if constexpr (HAS_AUXOUT) {
+                        const bf16x8 pre = {(bf16)vv[0], (bf16)vv[1], (bf16)vv[2], (bf16)vv[3], (bf16)vv[4], (bf16)vv[5], (bf16)vv[6], (bf16)vv[7]};
+                        park2[q] = *reinterpret_cast<const u32x4*>(&pre);
+                    }
+                    if (p.act == DEVIAS_ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 y = gelu_fast2(f32x2{vv[e], vv[e + 1]});
+                            vv[e] = y[0]; vv[e + 1] = y[1];
+                        }
+                    }
+                    if constexpr (HAS_AUXIN) {
+                        const bf16x8 a8 = pre_aux[q];
+                        if (p.act == DEVIAS_ACT_DGELU) {
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2) {
+                                const f32x2 d = dgelu_fast2(f32x2{(float)a8[e], (float)a8[e + 1]});
+                                vv[e] *= d[0]; vv[e + 1] *= d[1];
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) vv[e] = (float)a8[e] > 0.f ? vv[e] : 0.f;
+                        }
+                    }
+                    if (p.row_scale) {
+                        const float rs = p.row_scale[m / p.rows_per_scale];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vv[e] *= rs;
+                        pend = 99;
+                    }
+                    if constexpr (HAS_RES) {
+                        const bf16x8 r8 = pre_res[q];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vv[e] += (float)r8[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs[e] += vv[e];
+                    const bf16x8 o = {(bf16)vv[0], (bf16)vv[1], (bf16)vv[2], (bf16)vv[3], (bf16)vv[4], (bf16)vv[5], (bf16)vv[6], (bf16)vv[7]};
+                    park[q] = *reinterpret_cast<const u32x4*>(&o);
+                }
+            }
+            if (p.colsum_part) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    cs[e] += __shfl_xor(cs[e], 8, 64);
+                    cs[e] += __shfl_xor(cs[e], 16, 64);
+                    cs[e] += __shfl_xor(cs[e], 32, 64);
+                }
+                if (lane < 8) {
+                    float* dst = p.colsum_part + (int64_t)(mrow0 / 128) * p.N + ncol0 + cl;
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+                }
+                pend = 99;
+            }
+        }
+        parked = true; pm = mrow0; pn = ncol0;
+        if (!has_next) break;
+        v += G; m0 = m0n; n0 = n0n;
+        has_next = v + G < ntiles;
+        if (has_next) coords(v + G, m0n, n0n);
+    }
+    wait_vm<0>();                                          // the trailing (unused) LDS-DMA must land before the LDS is released
+#pragma unroll
+    for (int q = 0; q < 16; ++q) PK_STORE(q)
+#undef PK_STORE
+#undef PK_STORE_STEP
+#undef PK_STORE_SWITCH
+}
+
+
 // C[i] = epilogue(sum_s ws[s][i])   (fixed summation order -> bitwise reproducible); the full fused epilogue is available
 // here too so that small-M, long-K GEMMs (the B*S = 64-row slot MLPs) can be split along K to fill the chip
 template <typename T>
@@ -818,7 +1115,32 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
                        "devias_gemm: colsum needs split_k == 1, a workspace (M/128 * N floats) and a T-typed C");
         if (ss || big) { p.colsum_part = a->ws; colsum_fused = true; }      // the full-tile kernels fold it into their epilogue
     }
-    if (ss) {
+    // persistent 256x128 kernel (continuous 3-stage operand ring, deferred stores).  Measured (tools/gemm_block_shapes.py, M = 50176):
+    // it wins where the operand stream is HBM-latency bound and the K loop is long -- NT, K >= 2048, narrow N (fc2 forward:
+    // 288 vs 317 us) -- and loses elsewhere (one wave per SIMD cannot hide LDS-DMA issue and LDS latency behind a second wave:
+    // qkv 273 vs 232 us, every k-strided-B shape).  DEVIAS_GEMM_PK: unset = that measured policy, 0 = never, 1 = wherever the
+    // single-stage kernel would run, 2 = also where the 256^2 kernel would run.
+    const int use_pk = [] { const char* e = getenv("DEVIAS_GEMM_PK"); return e ? atoi(e) : -1; }();   // read per call: tests toggle it
+    int epi = (a->aux_in ? 1 : 0) | (a->res ? 2 : 0) | (a->aux_out ? 4 : 0);
+    bool pk = use_pk != 0 && (ss || (use_pk >= 2 && big)) && !a->trans_a && split == 1 && !p.c_f32 && a->beta == 0.f && a->K >= 128 &&
+              (a->M % PK_BM == 0) && (a->N % PK_BN == 0) && (epi == 0 || epi == 1 || epi == 2 || epi == 4) &&
+              (a->act == DEVIAS_ACT_NONE || (a->act == DEVIAS_ACT_GELU && epi == 4) || ((a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU) && epi == 1)) &&
+              (int64_t)(a->M / PK_BM) * (a->N / PK_BN) >= 256;
+    if (use_pk < 0) pk = pk && !a->trans_b && a->K >= 2048 && a->N <= 1024;
+    if (pk) {
+        if (a->colsum) { p.colsum_part = a->ws; colsum_fused = true; }
+        p.tiles_m = a->M / PK_BM; p.tiles_n = a->N / PK_BN;
+        static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        int nt = p.tiles_m * p.tiles_n;
+        int g = nt < ncu ? nt : ncu;
+        g &= ~7; if (g < 8) g = nt < 8 ? nt : 8;            // the XCD remap wants a multiple of 8 workgroups
+        dim3 grid(g), block(PK_NT);
+        const int tb = a->trans_b;
+#define PK_LAUNCH(TB_, E_) hipLaunchKernelGGL((gemm_pk_kernel<false, TB_, E_>), grid, block, 0, st, p)
+        if (!tb) { if (epi == 0) PK_LAUNCH(false, 0); else if (epi == 2) PK_LAUNCH(false, 2); else if (epi == 4) PK_LAUNCH(false, 4); else PK_LAUNCH(false, 1); }
+        else { if (epi == 0) PK_LAUNCH(true, 0); else if (epi == 2) PK_LAUNCH(true, 2); else if (epi == 4) PK_LAUNCH(true, 4); else PK_LAUNCH(true, 1); }
+#undef PK_LAUNCH
+    } else if (ss) {
         p.tiles_m = a->M / SS_BM; p.tiles_n = a->N / SS_BN;
         dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(SS_NT);
         const int ta = a->trans_a, tb = a->trans_b;

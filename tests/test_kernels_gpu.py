@@ -380,3 +380,53 @@ def test_fused_adamw_multi_equals_per_tensor_path_bitwise():
             x.grad, y.grad = g.clone(), g.clone()
         oa.step(); ob.step()
     assert max(rel(x.detach(), y.detach()) for x, y in zip(a, b)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ persistent GEMM
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("epi", ["bias", "res", "gelu_aux", "dgelu_colsum", "plain", "res_rowscale"])
+@pytest.mark.parametrize("M,N,K", [(256 * 40, 1024, 128), (256 * 33, 2048, 320), (256 * 70, 512, 768)])
+def test_gemm_persistent_kernel(tb, epi, M, N, K, monkeypatch):
+    """gemm_pk_kernel (deferred stores, continuous operand ring) against the fp32 op on the bf16-rounded inputs; the same
+    call through the non-persistent kernels must agree with it to bf16 rounding of identical fp32 values (bitwise)"""
+    o = ops()
+    from devias_amd._lib import ACT_DGELU, ACT_GELU
+    A = rnd(M, K, dtype=torch.bfloat16, seed=1)
+    B = rnd(*((K, N) if tb else (N, K)), dtype=torch.bfloat16, scale=0.1, seed=2)
+    bias = rnd(N, seed=3)
+    res = rnd(M, N, dtype=torch.bfloat16, seed=4)
+    pre = rnd(M, N, dtype=torch.bfloat16, seed=5)
+    rs = (torch.arange(M // 256, device=DEV) % 3).float() * 0.5
+    ref = A.float() @ (B.float() if tb else B.float().t())
+    kw = {}
+    if epi == "bias":
+        kw = dict(bias=bias); ref = ref + bias
+    elif epi == "res":
+        kw = dict(bias=bias, res=res); ref = ref + bias + res.float()
+    elif epi == "res_rowscale":
+        kw = dict(bias=bias, res=res, row_scale=rs, rows_per_scale=256); ref = (ref + bias) * rs.repeat_interleave(256)[:, None] + res.float()
+    elif epi == "gelu_aux":
+        kw = dict(bias=bias, act=ACT_GELU); ref_pre = ref + bias; ref = F.gelu(ref_pre)
+    elif epi == "dgelu_colsum":
+        x = pre.float()
+        dg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+        kw = dict(act=ACT_DGELU, aux_in=pre); ref = ref * dg
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("DEVIAS_GEMM_PK", mode)
+        kw2 = dict(kw)
+        if epi == "gelu_aux":
+            kw2["aux_out"] = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        if epi == "dgelu_colsum":
+            kw2["colsum"] = torch.zeros(N, device=DEV)
+        c = o.gemm(A, B, trans_b=tb, **kw2)
+        torch.cuda.synchronize()
+        outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
+    c, aux, cs = outs["2"]
+    assert rel(c.float(), ref) < TOL[torch.bfloat16]
+    assert torch.equal(c, outs["0"][0])
+    if aux is not None:
+        assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16] and torch.equal(aux, outs["0"][1])
+    if cs is not None:
+        assert rel(cs, c.float().sum(0)) < 1e-2                 # sums the fp32 values before bf16 rounding
+        assert rel(cs, outs["0"][2]) < 1e-5
