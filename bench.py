@@ -185,16 +185,20 @@ def main():
                                            init_scale=0.001, compute_dtype=args.dtype)
             synth.fill_module_(teacher, seed=1)
             teacher = teacher.to(device).eval()
+            from devias_amd.fame import FAME
             opt = FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.05)
+            fame = FAME(beta=0.5, prob_aug=0.5)
+            x32 = x.float()                                   # FAME takes the fp32 clips the data loader delivers
 
             def full_step():
                 for p in model.parameters():
                     p.grad = None
-                out = model(x)
-                _, tlog = teacher(x, return_attn=False)
-                total, logits, ld = crit(model, out, (None, tlog.float()), y, fg_mask=(fg196, fgN))
+                xs, ys, masks = fame(x32, y)                  # device FAME: masks + fg/bg mixing (engine_for_slot.py:106-108)
+                out = model(xs)
+                _, tlog = teacher(xs, return_attn=False)
+                total, logits, ld = crit(model, out, (None, tlog.float()), ys, fg_mask=masks)
                 total.backward()
-                opt.step()
+                opt.step(max_norm=1.0)                        # fused global-norm clip + AdamW, 3 launches
                 return total
 
             for _ in range(2):
@@ -207,7 +211,7 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / nfs
             full = {"value": B / dt, "unit": "clips/s", "ms_per_step": dt * 1e3, "steps": nfs,
-                    "includes": "student fwd+loss+bwd + frozen teacher fwd (1569 tokens) + fused AdamW (98.4M params)",
+                    "includes": "FAME masks + clip mixing on device, student fwd+loss+bwd, frozen teacher fwd (1569 tokens), grad-norm clip + fused AdamW (98.4M params)",
                     "final_loss": float(fl.detach().float().sum())}
 
     clips_per_s = world * B * args.steps / wall

@@ -74,6 +74,11 @@ PROTOTYPES = {
     "devias_grad_sumsq_multi": (c_int, [_P, _P, _P, _I, _P, _P]),
     "devias_clip_coef": (c_int, [_P, _I, _F, _P, _P]),
     "devias_adamw_multi": (c_int, [_P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
+    "devias_fame_diff_color": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "devias_fame_blur": (c_int, [_P, _P, _I, _I, _I, _I, _F, _P]),
+    "devias_fame_seg_refine": (c_int, [_P, _P, _I, _I, _I, _F, _P, _P]),
+    "devias_fame_binarize_pool": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "devias_fame_mix": (c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 OPT_CHUNK = 16384          # DEVIAS_OPT_CHUNK
 OPT_TENSOR_BYTES = 64      # sizeof(devias_opt_tensor)

@@ -123,3 +123,28 @@ def fg_masks(batch: int, tokens: int, grid: int = 196, seed: int = 1000, first: 
         m[b] = (np.floor(uniform24(seed, f"fg196.{first + b}", grid) * 257.0) / 256.0).astype(np.float32)
         mn[b] = (np.floor(uniform24(seed, f"fgN.{first + b}", tokens) * 257.0) / 256.0).astype(np.float32)
     return _t(m, (batch, grid)), _t(mn, (batch, tokens))
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def scene_video(batch: int, frames: int, size: int, seed: int = 2000, first: int = 0) -> torch.Tensor:
+    """Structured clips for the FAME path, x[B,3,T,H,W] fp32, ImageNet-normalised: a static colour ramp background, a 60-pixel
+    square moving 6 px/frame right and 4 px/frame down, 3 bits of hashed noise.  Integer arithmetic up to the final
+    (v/256 - mean)/std in IEEE fp32, so every machine produces the same bits."""
+    out = np.empty((batch, 3, frames, size, size), dtype=np.float32)
+    yy, xx = np.meshgrid(np.arange(size), np.arange(size), indexing="ij")
+    obj = (200, 40, 90)
+    for b in range(batch):
+        gb = first + b
+        noise = (hash_u64(seed, f"scene.{gb}", 3 * frames * size * size) >> np.uint64(61)).astype(np.int64).reshape(3, frames, size, size)
+        for c in range(3):
+            base = (xx * (3 + c) + yy * (2 + (gb % 5) + c)) % 256
+            for t in range(frames):
+                x0, y0 = 20 + 10 * (gb % 7) + 6 * t, 30 + 4 * t
+                inside = (xx >= x0) & (xx < x0 + 60) & (yy >= y0) & (yy < y0 + 60)
+                v = np.where(inside, obj[(c + gb) % 3], base) + noise[c, t]
+                v = np.minimum(v, 255).astype(np.float32) / np.float32(256.0)
+                out[b, c, t] = (v - np.float32(IMAGENET_MEAN[c])) / np.float32(IMAGENET_STD[c])
+    return torch.from_numpy(out)

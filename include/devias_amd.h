@@ -241,6 +241,33 @@ int devias_adamw_multi(const devias_opt_tensor* table, const int32_t* chunk_tens
                        int32_t n_chunks, float beta1, float beta2, float eps, float grad_scale,
                        const float* grad_scale_dev, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * FAME foreground masks and clip mixing (utils/transform/fame.py of the reference; CPU tensors + kornia there, called from
+ * engine/engine_for_slot.py:106-108).  All buffers are device memory; images are fp32 [n, H, W].
+ *   devias_fame_diff_color   video [B,3,T,H,W] (ImageNet-normalised; denormalised inside, fame.py:118) ->
+ *                            diffs [B, 1 + T/2, H, W]: slot 0 = mean over the T-1 consecutive frame differences of sum_c |.|
+ *                            (fame.py:93), slot 1+i = sum_c |frame 2i - frame 2i+1| (fame.py:107);
+ *                            cmap  [B, H*W] int16: HSV colour bin of the temporal mean image (fame.py:47-64)
+ *   devias_fame_blur         separable Gaussian, 'reflect' border, taps exp(-x^2/(2 sigma^2)) normalised (kornia GaussianBlur2d,
+ *                            fame.py:20-22); in != out
+ *   devias_fame_seg_refine   per image: the HW/2 largest / HW/10 smallest pixels vote into 1000-bin foreground / background
+ *                            colour histograms of their clip (image i belongs to clip i / imgs_per_clip), refine =
+ *                            pr_fg / (pr_bg + pr_fg) (fame.py:50-76).  Min-max normalisation (fame.py:30-36) is monotonic and
+ *                            only feeds top-k selections, so it is not materialised.
+ *   devias_fame_binarize_pool  per image: the num_fg largest pixels -> 1 (binmask uint8 [n,H,W], may be NULL), pooled[n, (H/pool)*(W/pool)]
+ *                            = pool x pool average of the binary mask (fame.py:78-87, 142-148)
+ *   devias_fame_mix          out[j] = aug[j] ? (mask[src[j]] ? video[src[j]] : video[partner[j]]) : video[src[j]]   (fame.py:124-138)
+ * Top-k selections take the exact k-th value (radix select on the float bits); equal values are taken in index order.
+ * ------------------------------------------------------------------------------------------------- */
+int devias_fame_diff_color(const float* video, int32_t B, int32_t T, int32_t H, int32_t W, float* diffs, int16_t* cmap, void* stream);
+int devias_fame_blur(const float* in, float* out, int32_t n_img, int32_t H, int32_t W, int32_t ksize, float sigma, void* stream);
+int devias_fame_seg_refine(const float* blurred, const int16_t* cmap, int32_t n_img, int32_t imgs_per_clip, int32_t HW, float eps,
+                           float* refine, void* stream);
+int devias_fame_binarize_pool(const float* blurred, int32_t n_img, int32_t H, int32_t W, int32_t num_fg, int32_t pool,
+                              uint8_t* binmask, float* pooled, void* stream);
+int devias_fame_mix(const float* video, const uint8_t* binmask, int32_t mask_stride, const int32_t* src, const int32_t* partner,
+                    const int32_t* aug, float* out, int32_t B, int32_t CT, int32_t HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -329,6 +329,61 @@ def generate_optim(ref):
     print("[optim]", {k: len(v["groups"]) for k, v in out["groups"].items()}, [len(s["values"]) for s in out["schedules"]])
 
 
+def generate_fame(ref):
+    """FAME (utils/transform/fame.py): run the reference's own class -- with oracle/fame_cpu.py's restatements of the two kornia
+    functions injected as the `kornia` module (kornia is absent here) and its two random draws replaced by fixed tensors --
+    check oracle/fame_cpu.FameOracle against it, and commit the outputs (tests/golden/fame_*.npz)."""
+    from oracle import fame_cpu
+
+    class _Blur(nn.Module):
+        def __init__(self, ks, sg):
+            super().__init__()
+            self.ks, self.sg = ks, sg
+
+        def forward(self, x):
+            return fame_cpu.gaussian_blur2d(x, self.ks[0], self.sg[0])
+
+    def _mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    _mod("kornia", filters=_mod("kornia.filters", GaussianBlur2d=_Blur), color=_mod("kornia.color", rgb_to_hsv=fame_cpu.rgb_to_hsv))
+    _mod("kornia.augmentation"); _mod("kornia.augmentation.container", VideoSequential=object)
+    _mod("torchvision", transforms=_mod("torchvision.transforms")); _mod("torchvision.datasets")
+    _mod("torchvision.datasets.video_utils", VideoClips=object)
+    import utils.transform.fame as rf
+    for name, (B, T, size, beta, prob, rand, perm) in {
+        "fame_t8": (3, 8, 224, 0.5, 0.5, [0.2, 0.9, 0.4], [2, 0, 1]),
+        "fame_t16_all": (2, 16, 224, 0.3, 1.0, [0.0, 0.0], [1, 0]),
+    }.items():
+        x = synth.scene_video(B, T, size)
+        label = torch.arange(B) * 7 + 1
+        perm_t, rand_t = torch.tensor(perm), torch.tensor(rand)
+        model = rf.FAME(beta=beta, prob_aug=prob)
+        orig = (torch.randperm, torch.rand)
+        torch.randperm = lambda n, device=None: perm_t
+        torch.rand = lambda n: rand_t
+        try:
+            with torch.no_grad():
+                vids, lab, (m, mpf) = model(x.clone(), label)
+        finally:
+            torch.randperm, torch.rand = orig
+        orc = fame_cpu.FameOracle(beta=beta, prob_aug=prob)
+        ov, ol, (om, ompf), (binmask, soft, soft_pf) = orc.forward(x, label, perm_t, rand_t)
+        assert torch.equal(ol, lab) and torch.equal(om, m) and torch.equal(ompf, mpf), name
+        assert torch.equal(ov, vids), name
+        idx = (synth.hash_u64(11, "fame.sample." + name, 4096) % np.uint64(vids.numel())).astype(np.int64)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + ".npz"),
+                            B=B, T=T, size=size, beta=beta, prob_aug=prob, rand=np.array(rand, np.float32), perm=np.array(perm, np.int64),
+                            label=label.numpy(), out_label=lab.numpy(), mask=m.numpy(), masks_per_frame=mpf.numpy(),
+                            binmask=np.packbits(binmask.numpy().astype(np.uint8)), soft=soft.numpy().astype(np.float16),
+                            video_sample_idx=idx, video_sample=vids.flatten()[idx].numpy(),
+                            video_sum=np.array([float(vids.double().sum()), float(vids.double().abs().sum())]))
+        print(f"[{name}] reference == oracle (bitwise); mask mean {float(m.mean()):.4f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -344,6 +399,8 @@ def main():
         generate_state_dict_keys(ref)
     if args.only in (None, "optim"):
         generate_optim(ref)
+    if args.only in (None, "fame"):
+        generate_fame(ref)
 
 
 if __name__ == "__main__":
