@@ -1,6 +1,7 @@
 """End-to-end parity of the HIP path (through the C ABI) against the golden fixtures produced by the real reference
 and against the CPU oracle, on the same formula weights / inputs.  fp32 kernel mode carries the 1e-3 gate of
 BASELINE.json's north_star; bf16 mode deviation is measured and bounded loosely."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -247,3 +248,19 @@ def test_validation_one_epoch_and_final_test(tmp_path):
     lines = f.read_text().splitlines()
     assert len(lines) == 1 + B and lines[1].startswith("vid0 [") and lines[1].endswith(" %d 0 1" % int(y[0]))
     assert abs(st2["loss"] - ce) < 1e-4 * abs(ce)
+
+
+def test_knn_classifier_matches_reference():
+    """utils/eval/run_knn.py:123-163 on formula features: top-1/top-5 of the reference function (tests/golden/knn.json)"""
+    import json
+    from devias_amd.eval_knn import knn_classifier
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "knn.json")))
+    n_train, n_test, D, C = g["n_train"], g["n_test"], g["D"], g["C"]
+    lab_tr = torch.from_numpy((synth.hash_u64(5, "knn.lab.train", n_train) % np.uint64(C)).astype(np.int64))
+    lab_te = torch.from_numpy((synth.hash_u64(5, "knn.lab.test", n_test) % np.uint64(C)).astype(np.int64))
+    cent = synth.param_values("knn.centroids.weight", (C, D), seed=5) * 20
+    f_tr = torch.nn.functional.normalize(cent[lab_tr] + synth.param_values("knn.noise.train.weight", (n_train, D), seed=5) * 110, dim=1)
+    f_te = torch.nn.functional.normalize(cent[lab_te] + synth.param_values("knn.noise.test.weight", (n_test, D), seed=5) * 110, dim=1)
+    for case in g["cases"]:
+        t1, t5 = knn_classifier(f_tr.cuda(), lab_tr.cuda(), f_te.cuda(), lab_te.cuda(), case["k"], case["T"], num_classes=C)
+        assert abs(t1 - case["top1"]) <= 0.9 and abs(t5 - case["top5"]) <= 0.9, (case, t1, t5)     # <= 2 of 230 borderline votes (fp32 summation order)

@@ -384,6 +384,28 @@ def generate_fame(ref):
         print(f"[{name}] reference == oracle (bitwise); mask mean {float(m.mean()):.4f}")
 
 
+def generate_knn(ref):
+    """knn_classifier of the reference (utils/eval/run_knn.py:123-163) on formula features -> tests/golden/knn.json."""
+    import json
+    for m in ("dataset", "dataset.datasets", "dataset.kinetics"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["dataset.datasets"].knn_build_dataset = None
+    sys.modules["dataset.kinetics"].VideoClsDataset = object
+    import utils.eval.run_knn as rk
+    n_train, n_test, D, C = 600, 230, 64, 7
+    lab_tr = torch.from_numpy((synth.hash_u64(5, "knn.lab.train", n_train) % np.uint64(C)).astype(np.int64))
+    lab_te = torch.from_numpy((synth.hash_u64(5, "knn.lab.test", n_test) % np.uint64(C)).astype(np.int64))
+    cent = synth.param_values("knn.centroids.weight", (C, D), seed=5) * 20
+    f_tr = torch.nn.functional.normalize(cent[lab_tr] + synth.param_values("knn.noise.train.weight", (n_train, D), seed=5) * 110, dim=1)
+    f_te = torch.nn.functional.normalize(cent[lab_te] + synth.param_values("knn.noise.test.weight", (n_test, D), seed=5) * 110, dim=1)
+    out = {"n_train": n_train, "n_test": n_test, "D": D, "C": C, "cases": []}
+    for k, T in ((20, 0.07), (3, 0.07), (10, 1.0)):
+        t1, t5 = rk.knn_classifier(f_tr, lab_tr, f_te, lab_te, k, T, num_classes=C)
+        out["cases"].append({"k": k, "T": T, "top1": t1, "top5": t5})
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "knn.json"), "w"))
+    print("[knn]", out["cases"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -401,6 +423,8 @@ def main():
         generate_optim(ref)
     if args.only in (None, "fame"):
         generate_fame(ref)
+    if args.only in (None, "knn"):
+        generate_knn(ref)
 
 
 if __name__ == "__main__":
