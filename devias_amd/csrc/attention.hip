@@ -106,8 +106,8 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
 }
 
 // ======================================= forward (bf16) ===================================================
-template <int QT, int NW, bool DMA>
-__global__ __launch_bounds__(NW * 64) void mhsa_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+template <int QT, int NW, bool DMA, int OCC = 1>
+__global__ __launch_bounds__(NW * 64, OCC) void mhsa_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                             float* __restrict__ lse, int N, int H, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[DMA ? 32768 : 16384];   // DMA: two stages of (K row image | V transposed-read image)
     char* imgK = smem;            // row image of K tile  [key][d]
@@ -196,10 +196,15 @@ __global__ __launch_bounds__(NW * 64) void mhsa_fwd_bf16_kernel(const bf16* __re
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             // running max is kept in RAW score units; scale*log2(e) is folded into the exponent's FMA
-            float mx = fmaxf(fmaxf(acc_s[0][qt][0], acc_s[0][qt][1]), fmaxf(acc_s[0][qt][2], acc_s[0][qt][3]));
-#pragma unroll
-            for (int kt = 1; kt < 4; ++kt)
-                mx = fmaxf(mx, fmaxf(fmaxf(acc_s[kt][qt][0], acc_s[kt][qt][1]), fmaxf(acc_s[kt][qt][2], acc_s[kt][qt][3])));
+            // chains of max(max(m, a), b): each pair folds into one v_max3_f32
+            float mx = fmaxf(fmaxf(acc_s[0][qt][0], acc_s[0][qt][1]), acc_s[0][qt][2]);
+            mx = fmaxf(fmaxf(mx, acc_s[0][qt][3]), acc_s[1][qt][0]);
+            mx = fmaxf(fmaxf(mx, acc_s[1][qt][1]), acc_s[1][qt][2]);
+            float mx2 = fmaxf(fmaxf(acc_s[1][qt][3], acc_s[2][qt][0]), acc_s[2][qt][1]);
+            mx2 = fmaxf(fmaxf(mx2, acc_s[2][qt][2]), acc_s[2][qt][3]);
+            mx2 = fmaxf(fmaxf(mx2, acc_s[3][qt][0]), acc_s[3][qt][1]);
+            mx = fmaxf(fmaxf(mx, acc_s[3][qt][2]), acc_s[3][qt][3]);
+            mx = fmaxf(mx, mx2);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             if (__any(mx > mrow[qt])) {       // some row's max grew: rescale (rare after the first tiles)
@@ -211,16 +216,18 @@ __global__ __launch_bounds__(NW * 64) void mhsa_fwd_bf16_kernel(const bf16* __re
                 for (int dt = 0; dt < 4; ++dt) acc_o[dt][qt] *= alpha;
             }
             const float nb = -mrow[qt] * sl2;
-            float ps = 0.f;
+            const f32x2 sl2v = {sl2, sl2}, nbv = {nb, nb};
+            f32x2 ps2 = {0.f, 0.f};                       // packed fp32: one v_pk_fma_f32 / v_pk_add_f32 per two scores
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(fmaf(acc_s[kt][qt][r], sl2, nb));
-                    acc_s[kt][qt][r] = p;
-                    ps += p;
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 e = f32x2{acc_s[kt][qt][r], acc_s[kt][qt][r + 1]} * sl2v + nbv;
+                    const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
+                    acc_s[kt][qt][r] = p[0]; acc_s[kt][qt][r + 1] = p[1];
+                    ps2 += p;
                 }
-            lrow[qt] += ps;
+            lrow[qt] += ps2[0] + ps2[1];
         }
         // O^T += V^T P^T
 #pragma unroll
@@ -341,14 +348,18 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
                     }
         }
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
+        for (int qt = 0; qt < QT; ++qt) {
+            const f32x2 sl2v = {sl2, sl2}, nl = {-lse2[qt], -lse2[qt]}, dlv = {dl[qt], dl[qt]};   // packed fp32: two scores per VALU op
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(fmaf(acc_s[kt][qt][r], sl2, -lse2[qt]));
-                    acc_s[kt][qt][r] = p * (acc_dp[kt][qt][r] - dl[qt]);       // dS^T / scale (scale applied once at the end)
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 e = f32x2{acc_s[kt][qt][r], acc_s[kt][qt][r + 1]} * sl2v + nl;
+                    const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
+                    const f32x2 ds = p * (f32x2{acc_dp[kt][qt][r], acc_dp[kt][qt][r + 1]} - dlv);   // dS^T / scale (scale applied once at the end)
+                    acc_s[kt][qt][r] = ds[0]; acc_s[kt][qt][r + 1] = ds[1];
                 }
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 dsf[QT];
@@ -455,13 +466,16 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
         for (int qt = 0; qt < 4; ++qt) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dl + 16 * qt + 4 * g);
+            const f32x2 sl2v = {sl2, sl2};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(fmaf(acc_s[qt][kt][r], sl2, -l4[r]));
-                    acc_s[qt][kt][r] = p;
-                    acc_dp[qt][kt][r] = p * (acc_dp[qt][kt][r] - d4[r]);            // dS / scale (scale applied once at the end)
+                for (int r = 0; r < 4; r += 2) {                                    // packed fp32: two scores per VALU op
+                    const f32x2 e = f32x2{acc_s[qt][kt][r], acc_s[qt][kt][r + 1]} * sl2v - f32x2{l4[r], l4[r + 1]};
+                    const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
+                    const f32x2 ds = p * (f32x2{acc_dp[qt][kt][r], acc_dp[qt][kt][r + 1]} - f32x2{d4[r], d4[r + 1]});   // dS / scale
+                    acc_s[qt][kt][r] = p[0]; acc_s[qt][kt][r + 1] = p[1];
+                    acc_dp[qt][kt][r] = ds[0]; acc_dp[qt][kt][r + 1] = ds[1];
                 }
         }
 #pragma unroll
@@ -680,6 +694,7 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
         else if (cfg == 2) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 4, false>), dim3(cdiv(N, 256), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
         else if (cfg == 3) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 2, false>), dim3(cdiv(N, 64), H, B), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
         else if (cfg == 4) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, false>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        else if (cfg == 5) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true, 4>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
         else hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
     }
     else if (dtype == DEVIAS_F32)
