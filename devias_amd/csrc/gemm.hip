@@ -29,6 +29,7 @@ struct GemmP {
     float* colsum_part;   // optional: per-(wave row-tile) partial column sums of the stored output, [M / (16*NI)][N]
     int group_m;          // tile rasterisation: GM row-tiles per group (m fastest inside a group); 1 = n fastest
     int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
+    int stagger;          // experiment: first-round workgroups start (blockIdx/8 % 4) * stagger ticks (10 ns) late, to spread the store bursts
     int debug;            // timing ablations only (DEVIAS_GEMM_DEBUG): 1 = one K-tile, 2 = no epilogue stores, 4 = no LDS-DMA after tile 0
 };
 
@@ -518,6 +519,10 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
 
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(((blockIdx.x >> 3) & 3) * p.stagger);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
     if (p.debug & 8) st0 = __builtin_amdgcn_s_memrealtime();
     f32x4 acc[8][4];
@@ -1077,6 +1082,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
                       (!a->aux_out || aligned16(a->aux_out)) && aligned16(a->C);
     p.vec_c = vc ? 1 : 0;
     { const char* e = getenv("DEVIAS_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
+    { const char* e = getenv("DEVIAS_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
     {   // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
         // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
         static const int gm = [] { const char* e = getenv("DEVIAS_GEMM_GROUPM"); return e ? atoi(e) : 0; }();

@@ -7,7 +7,7 @@ Mirrors the surface `run_slot_finetuning.py:529-560` drives:
   create_optimizer           utils/optim_factory.py:96-133  (opt='adamw' -> devias_amd.optim.FusedAdamW; the reference's other
                                                              optimizers are timm/apex classes outside the hot path)
   cosine_scheduler           utils/utils.py:424-441
-Pure host logic; pinned against the reference by tests/golden/optim_factory.json (tools/make_goldens.py)."""
+Pure host logic; pinned against the reference by tests/golden/optim_factory.json (tests/golden/make_goldens.py)."""
 from __future__ import annotations
 
 import json

@@ -1,11 +1,11 @@
-"""CPU oracle of the FAME foreground-mask / clip-mixing step (TEST INFRASTRUCTURE ONLY: imported by tests/, tools/make_goldens.py
+"""CPU oracle of the FAME foreground-mask / clip-mixing step (TEST INFRASTRUCTURE ONLY: imported by tests/, tests/golden/make_goldens.py
 and nothing on the product path).
 
 Restates utils/transform/fame.py of the reference (functions cite file:line).  Two of its operations live in a third-party
 dependency that is neither vendored nor version-pinned by the reference (`kornia`, docs/INSTALL.md:32, absent from this
 image): `kornia.filters.GaussianBlur2d` and `kornia.color.rgb_to_hsv`.  They are restated here from kornia's published
 algorithm (0.6/0.7 line: separable normalised Gaussian taps exp(-x^2/(2 sigma^2)), 'reflect' border; HSV with hue in
-[0, 2 pi]) -- PARITY UNPINNED for those two functions.  Everything else is pinned: tools/make_goldens.py runs the reference's
+[0, 2 pi]) -- PARITY UNPINNED for those two functions.  Everything else is pinned: tests/golden/make_goldens.py runs the reference's
 own FAME class with these two restatements injected as the `kornia` module and checks this file against it; the outputs are
 committed as tests/golden/fame_*.npz."""
 from __future__ import annotations

@@ -5,7 +5,7 @@ training step.  Only tests/, __graft_entry__.smoke() and bench.py's
 `cpu_baseline` leg may import this file; the product path (devias_amd/) never
 does and fails loudly when the HIP library is missing.
 
-Pinned: tools/make_goldens.py imports the real reference (in the build
+Pinned: tests/golden/make_goldens.py imports the real reference (in the build
 container only), feeds it the formula weights/inputs of devias_amd/synth.py and
 (a) asserts this restatement reproduces the reference's outputs, losses and
 gradients, (b) commits those reference outputs as fixtures under tests/golden/.

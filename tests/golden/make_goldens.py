@@ -12,7 +12,7 @@ per parameter, and a few intermediate slices for bisecting.
 While generating, the CPU oracle (oracle/ref_cpu.py) is checked against the
 reference on the same data; a mismatch aborts.  The fixtures are data only.
 
-Usage (in the build container):  python tools/make_goldens.py [--only NAME]
+Usage (in the build container):  python tests/golden/make_goldens.py [--only NAME]
 This script never runs on the GPU box and nothing under tests/ imports it.
 """
 from __future__ import annotations
@@ -27,7 +27,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 REF = "/root/reference"

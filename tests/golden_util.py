@@ -1,4 +1,4 @@
-"""Shared helpers for the golden-fixture tests (fixtures are made by tools/make_goldens.py from the real reference)."""
+"""Shared helpers for the golden-fixture tests (fixtures are made by tests/golden/make_goldens.py from the real reference)."""
 import ast
 import os
 

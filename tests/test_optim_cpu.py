@@ -1,5 +1,5 @@
 """Host logic of the optimizer surface against values produced by the REAL reference (tests/golden/optim_factory.json,
-written by tools/make_goldens.py --only optim): parameter groups with layer decay, cosine schedules."""
+written by tests/golden/make_goldens.py --only optim): parameter groups with layer decay, cosine schedules."""
 import json
 import os
 import types

@@ -1,4 +1,4 @@
-"""The CPU oracle against the fixtures produced by the REAL reference (tools/make_goldens.py)."""
+"""The CPU oracle against the fixtures produced by the REAL reference (tests/golden/make_goldens.py)."""
 import numpy as np
 import pytest
 import torch
