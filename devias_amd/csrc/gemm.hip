@@ -29,6 +29,7 @@ struct GemmP {
     float* colsum_part;   // optional: per-(wave row-tile) partial column sums of the stored output, [M / (16*NI)][N]
     int group_m;          // tile rasterisation: GM row-tiles per group (m fastest inside a group); 1 = n fastest
     int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
+    int epi_swap;         // 1 = register-transposed epilogue (epilogue_swap), 0 = LDS-staged (epilogue_staged)
     int stagger;          // experiment: first-round workgroups start (blockIdx/8 % 4) * stagger ticks (10 ns) late, to spread the store bursts
     int debug;            // timing ablations only (DEVIAS_GEMM_DEBUG): 1 = one K-tile, 2 = no epilogue stores, 4 = no LDS-DMA after tile 0
 };
@@ -232,8 +233,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
             }
+            if (p.colsum_part) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) cs[e] += v[e];
+                for (int e = 0; e < 8; ++e) cs[e] += v[e];
+            }
             if (p.c_f32) {
                 float* C = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + ncol;
                 f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
@@ -245,7 +248,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
                 *reinterpret_cast<f32x4*>(C + 4) = o1;
             } else {
                 bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
+                if (!(p.debug & 64) || v[0] == 12345.678f)       // ablation: staging + math without the global stores
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
             }
         }
     }
@@ -261,6 +265,127 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
             float* dst = p.colsum_part + (int64_t)(mrow0 / (16 * NI)) * p.N + ncol;
             *reinterpret_cast<f32x4*>(dst) = f32x4{cs[0], cs[1], cs[2], cs[3]};
             *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+        }
+    }
+}
+
+
+// ---- register-transposed epilogue (bf16 activations, full tiles, 16-byte aligned rows) ---------------------------------------
+// Same contract as epilogue_staged, without LDS: gfx950's v_permlane16_swap exchanges the accumulator quads of lane groups g and
+// g ^ 1, after which lane (row lm, group g) owns 8 CONSECUTIVE columns of one row -- column tile 2*pr + (g & 1), half g >> 1 -- i.e.
+// a 16-byte bf16 piece; one store instruction then writes 16 rows x 64 contiguous bytes.  Measured (tools/exp/store_bw.hip) that
+// pattern stores at 24.8 GB/s per CU vs 26.0 for whole 128-B lines, and the LDS round trip it removes cost more than the stores
+// (qkv shape: staging + arithmetic 35 us, stores 23 us of a 58 us epilogue).
+template <int NI>
+__device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4], int mrow0, int ncol0, int z, int lane) {
+    const int lm = lane & 15, g = lane >> 4;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16* res = reinterpret_cast<const bf16*>(p.res);
+    const bf16* aux_in = reinterpret_cast<const bf16*>(p.aux_in);
+    bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
+    float cs[2][8];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[pr][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int m = mrow0 + i * 16 + lm;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const f32x4 A = acc[i][2 * pr] + bias4[2 * pr], B = acc[i][2 * pr + 1] + bias4[2 * pr + 1];
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(A[r]), __float_as_uint(B[r]), false, false);
+                v[r] = __uint_as_float(sw[0]);
+                v[4 + r] = __uint_as_float(sw[1]);
+            }
+            const int ncol = ncol0 + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1);
+            if (p.split_k > 1) {
+                float* w = p.ws + ((int64_t)z * p.M + m) * p.N + ncol;
+                *reinterpret_cast<f32x4*>(w) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(w + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                continue;
+            }
+            if (p.act == DEVIAS_ACT_GELU) {
+                if (aux_out) {
+                    bf16x8 pre = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+                    *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 y = gelu_fast2(f32x2{v[e], v[e + 1]});
+                    v[e] = y[0]; v[e + 1] = y[1];
+                }
+            } else if (p.act == DEVIAS_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.act == DEVIAS_ACT_SIGMOID) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+            } else if (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) {
+                const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)m * p.ld_aux + ncol);
+                if (p.act == DEVIAS_ACT_DGELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 d = dgelu_fast2(f32x2{(float)a8[e], (float)a8[e + 1]});
+                        v[e] *= d[0]; v[e + 1] *= d[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)a8[e] > 0.f ? v[e] : 0.f;
+                }
+            }
+            if (p.row_scale) {
+                const float rs = p.row_scale[m / p.rows_per_scale];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= rs;
+            }
+            if (res) {
+                const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+                const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + (int64_t)mr * p.ldr + ncol);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+            }
+            if (p.colsum_part) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[pr][e] += v[e];
+            }
+            if (p.c_f32) {
+                float* C = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + ncol;
+                f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                if (p.beta != 0.f) {
+                    o0 += p.beta * *reinterpret_cast<const f32x4*>(C);
+                    o1 += p.beta * *reinterpret_cast<const f32x4*>(C + 4);
+                }
+                *reinterpret_cast<f32x4*>(C) = o0;
+                *reinterpret_cast<f32x4*>(C + 4) = o1;
+            } else {
+                bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+                if (!(p.debug & 64) || v[0] == 12345.678f)
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
+            }
+        }
+    }
+    if (p.colsum_part && p.split_k == 1) {
+        // the 16 lanes of a group (same g, rows lm = 0..15) own the same columns: fold them in a fixed order
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = cs[pr][e];
+                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                cs[pr][e] = t;
+            }
+            if (lm == 0) {
+                float* dst = p.colsum_part + (int64_t)(mrow0 / (16 * NI)) * p.N + ncol0 + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1);
+                *reinterpret_cast<f32x4*>(dst) = f32x4{cs[pr][0], cs[pr][1], cs[pr][2], cs[pr][3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs[pr][4], cs[pr][5], cs[pr][6], cs[pr][7]};
+            }
         }
     }
 }
@@ -575,6 +700,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
         }
     }
     if ((p.debug & 2) && acc[0][0][0] != 12345.678f) return;
+    if (p.epi_swap) { epilogue_swap<8>(p, acc, m0 + wm * 128, n0 + wn * 64, z, lane); return; }
     __syncthreads();                                   // every wave is done reading the operand stages
     epilogue_staged<8, 4>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, z, lane);
 }
@@ -678,6 +804,7 @@ __global__ __launch_bounds__(SS_NT, OCC) void gemm_ss_kernel(GemmP p) {
             }
         }
     }
+    if (p.epi_swap) { epilogue_swap<8>(p, acc, m0 + wm * 128, n0 + wn * 64, z, lane); return; }
     __syncthreads();
     epilogue_staged<8, 2>(p, acc, smem + wave * 12288, m0 + wm * 128, n0 + wn * 64, z, lane);
 }
@@ -1083,6 +1210,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     p.vec_c = vc ? 1 : 0;
     { const char* e = getenv("DEVIAS_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
     { const char* e = getenv("DEVIAS_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+    { const char* e = getenv("DEVIAS_GEMM_EPI"); p.epi_swap = e ? atoi(e) : 1; }       // read per call: tests compare both epilogues
     {   // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
         // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
         static const int gm = [] { const char* e = getenv("DEVIAS_GEMM_GROUPM"); return e ? atoi(e) : 0; }();

@@ -412,8 +412,9 @@ def test_gemm_persistent_kernel(tb, epi, M, N, K, monkeypatch):
         dg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
         kw = dict(act=ACT_DGELU, aux_in=pre); ref = ref * dg
     outs = {}
-    for mode in ("2", "0"):
-        monkeypatch.setenv("DEVIAS_GEMM_PK", mode)
+    for mode in ("2", "0", "0s"):                          # persistent kernel; other kernels with the register-transposed epilogue; with the LDS-staged one
+        monkeypatch.setenv("DEVIAS_GEMM_PK", mode[0])
+        monkeypatch.setenv("DEVIAS_GEMM_EPI", "0" if mode.endswith("s") else "1")
         kw2 = dict(kw)
         if epi == "gelu_aux":
             kw2["aux_out"] = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
@@ -424,9 +425,10 @@ def test_gemm_persistent_kernel(tb, epi, M, N, K, monkeypatch):
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
     c, aux, cs = outs["2"]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]
-    assert torch.equal(c, outs["0"][0])
+    assert torch.equal(c, outs["0"][0]) and torch.equal(c, outs["0s"][0])
     if aux is not None:
+        assert torch.equal(aux, outs["0s"][1])
         assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16] and torch.equal(aux, outs["0"][1])
     if cs is not None:
         assert rel(cs, c.float().sum(0)) < 1e-2                 # sums the fp32 values before bf16 rounding
-        assert rel(cs, outs["0"][2]) < 1e-5
+        assert rel(cs, outs["0"][2]) < 1e-5 and rel(cs, outs["0s"][2]) < 1e-5
