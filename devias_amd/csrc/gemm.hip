@@ -707,6 +707,79 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
 
 
 // =====================================================================================================================
+// Experiment (DEVIAS_GEMM256=3): the 256 x 256 x 64 kernel with REGISTER-staged operands (global_load_dwordx4 -> VGPR ->
+// ds_write_b128 into the same swizzled images) instead of LDS-DMA, k-contiguous operands only.  Question it answers: is the
+// per-instruction issue cost of LDS-DMA (60-185 cycles per 1-KiB piece, MI355X_MICROARCH.md) what holds the K loop at 1.38 PFLOP/s?
+// =====================================================================================================================
+__global__ __launch_bounds__(NT2) void gemm256r_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    int tm, tn;
+    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * T2, n0 = tn * T2;
+    const int nk = p.K / 64;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    // thread -> 4 A pieces + 4 B pieces of 16 B per K-tile: row = (tid >> 3) + 64 * i, chunk = tid & 7
+    const int prow = tid >> 3, pch = tid & 7;
+    const bf16* ap = A + (int64_t)(m0 + prow) * p.lda + pch * 8;
+    const bf16* bp = B + (int64_t)(n0 + prow) * p.ldb + pch * 8;
+    const int64_t astep = (int64_t)64 * p.lda, bstep = (int64_t)64 * p.ldb;
+    u32x4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const u32x4*>(ap + i * astep + kt * 64);
+            rb[i] = *reinterpret_cast<const u32x4*>(bp + i * bstep + kt * 64);
+        }
+    };
+    auto lstore = [&](char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = prow + 64 * i;
+            *reinterpret_cast<u32x4*>(st + off_kc2(row, pch)) = ra[i];
+            *reinterpret_cast<u32x4*>(st + 32768 + off_kc2(row, pch)) = rb[i];
+        }
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gload(0);
+    lstore(smem);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * STAGE2;
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag2<false>(cur + 32768, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                bf16x8 fa[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = read_frag2<false>(cur, wm * 128 + (ih * 4 + i) * 16, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ih * 4 + i][j] = mfma16(fb[j], fa[i], acc[ih * 4 + i][j]);
+            }
+        }
+        if (kt + 1 < nk) lstore(smem + ((kt + 1) & 1) * STAGE2);      // stage (kt+1)&1 was last read in iteration kt-1 (barrier below)
+        __syncthreads();
+    }
+    epilogue_swap<8>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane);
+}
+
+
+// =====================================================================================================================
 // 256 x 128 x 64 tile, 256 threads (4 waves as 2(M) x 2(N), 128 x 64 per wave), ONE 48 KiB LDS stage filled by LDS-DMA,
 // three workgroups per CU: load/compute overlap and -- the point -- epilogue/compute overlap come from the co-resident
 // workgroups (independent waves, independent vmcnt), not from an in-kernel software pipeline.
@@ -1240,9 +1313,9 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
               (p.k_per_split % 64 == 0);
     if (ss && use_ss < 0 && use256 != 2) {
         const bool nt = !a->trans_a && !a->trans_b;
-        if (nt && big && (int64_t)(a->M / T2) * (a->N / T2) * split >= 1000) ss = false;     // 256^2 wins the big NT grids
+        if (nt && big) ss = false;     // 256^2 wins every NT shape it can tile since the epilogue left LDS (proj 80 vs 99 us, fc2 271 vs 289-317 us)
     }
-    if (use256 == 2 && big) ss = false;
+    if (use256 >= 2 && big) ss = false;
     bool colsum_fused = false;
     if (a->colsum) {
         DEVIAS_REQUIRE(split == 1 && a->ws && !(a->c_f32 && a->dtype == DEVIAS_BF16),
@@ -1260,7 +1333,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
               (a->M % PK_BM == 0) && (a->N % PK_BN == 0) && (epi == 0 || epi == 1 || epi == 2 || epi == 4) &&
               (a->act == DEVIAS_ACT_NONE || (a->act == DEVIAS_ACT_GELU && epi == 4) || ((a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU) && epi == 1)) &&
               (int64_t)(a->M / PK_BM) * (a->N / PK_BN) >= 256;
-    if (use_pk < 0) pk = pk && !a->trans_b && a->K >= 2048 && a->N <= 1024;
+    if (use_pk < 0) pk = false;    // measured policy: never by default (see the note above; the 256^2 kernel with the register-transposed epilogue took its one win)
     if (pk) {
         if (a->colsum) { p.colsum_part = a->ws; colsum_fused = true; }
         p.tiles_m = a->M / PK_BM; p.tiles_n = a->N / PK_BN;
@@ -1289,7 +1362,8 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;
         dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(NT2);
         const int ta = a->trans_a, tb = a->trans_b;
-        if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, block, 0, st, p);
+        if (!ta && !tb && use256 == 3 && split == 1) hipLaunchKernelGGL(gemm256r_kernel, grid, block, 0, st, p);
+        else if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, block, 0, st, p);
         else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, block, 0, st, p);
         else if (ta && tb) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, block, 0, st, p);
