@@ -291,11 +291,29 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
     for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs[pr][e] = 0.f;
+    // the rows the epilogue reads (residual, or the saved pre-activation of dGELU / dReLU) are fetched PF pieces ahead of their use
+    constexpr int PF = 4;
+    const bf16* side = res ? res : aux_in;
+    const int side_ld = res ? p.ldr : p.ld_aux;
+    const bool side_on = side != nullptr && p.split_k == 1;
+    bf16x8 sbuf[PF];
+    auto side_load = [&](int n) -> bf16x8 {
+        const int i = n >> 1, pr = n & 1;
+        int m = mrow0 + i * 16 + lm;
+        if (res && p.res_mod > 0) m %= p.res_mod;
+        return *reinterpret_cast<const bf16x8*>(side + (int64_t)m * side_ld + ncol0 + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1));
+    };
+    if (side_on) {
+#pragma unroll
+        for (int n = 0; n < PF; ++n) sbuf[n] = side_load(n);
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int m = mrow0 + i * 16 + lm;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
+            bf16x8 side8 = sbuf[(i * 2 + pr) % PF];
+            if (side_on && i * 2 + pr + PF < 2 * NI) sbuf[(i * 2 + pr) % PF] = side_load(i * 2 + pr + PF);
             const f32x4 A = acc[i][2 * pr] + bias4[2 * pr], B = acc[i][2 * pr + 1] + bias4[2 * pr + 1];
             float v[8];
 #pragma unroll
@@ -328,7 +346,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
             } else if (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) {
-                const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)m * p.ld_aux + ncol);
+                const bf16x8 a8 = res ? *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)m * p.ld_aux + ncol) : side8;
                 if (p.act == DEVIAS_ACT_DGELU) {
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
@@ -346,8 +364,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                 for (int e = 0; e < 8; ++e) v[e] *= rs;
             }
             if (res) {
-                const int mr = p.res_mod > 0 ? m % p.res_mod : m;
-                const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + (int64_t)mr * p.ldr + ncol);
+                const bf16x8 r8 = side8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
             }
