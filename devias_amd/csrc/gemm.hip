@@ -642,7 +642,7 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* lds, int base16, int ks
     }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int PIN = 0>
 __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -683,6 +683,69 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
         __syncthreads();
         if ((p.debug & 8) && kt == 0) st2 = __builtin_amdgcn_s_memrealtime();
         char* cur = smem + (kt & 1) * STAGE2;
+        if constexpr (!TA && !TB && PIN != 0) {
+            {
+                // experiment (DEVIAS_GEMM_DEBUG=128): the 8 LDS-DMA instructions of tile kt+1 spread over the first 8 of 16 four-MFMA
+                // steps, fragment reads two steps ahead of their use, order pinned step by step
+                char* nxt = smem + ((kt + 1) & 1) * STAGE2;
+                const int kn = kbeg + (kt + 1 < nk ? kt + 1 : kt) * 64;       // last tile: harmless re-read into the free stage
+                const char* sA = cur; const char* sB = cur + 32768;
+                bf16x8 fb0[4], fb1[4], fa0[4], fa1[4];
+#define G_RA(ks, ih, i) read_frag2<false>(sA, wm * 128 + ((ih) * 4 + (i)) * 16, ks, lane)
+#define G_RB(ks, j) read_frag2<false>(sB, wn * 64 + (j) * 16, ks, lane)
+#define G_MM4(ih, i, fb, fa) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[(ih) * 4 + (i)][j] = mfma16(fb[j], fa[i], acc[(ih) * 4 + (i)][j]);
+#define G_SB __builtin_amdgcn_sched_barrier(0);
+#define G_DMA(n) { const int r8 = wave * 32 + ((n) & 3) * 8; const int row = r8 + (lane >> 3); const int chunk = (lane & 7) ^ (row & 7); \
+                   const bf16* src = ((n) < 4 ? A + (int64_t)(m0 + row) * p.lda : B + (int64_t)(n0 + row) * p.ldb) + kn + chunk * 8; \
+                   __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(nxt + ((n) < 4 ? 0 : 32768) + r8 * 128), 16, 0, 0); }
+                G_SB
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb0[j] = G_RB(0, j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa0[i] = G_RA(0, 0, i);
+                G_SB
+                if constexpr (PIN == 1) {
+                G_MM4(0, 0, fb0, fa0) G_DMA(0) fa1[0] = G_RA(0, 1, 0); fb1[0] = G_RB(1, 0); G_SB
+                G_MM4(0, 1, fb0, fa0) G_DMA(1) fa1[1] = G_RA(0, 1, 1); fb1[1] = G_RB(1, 1); G_SB
+                G_MM4(0, 2, fb0, fa0) G_DMA(2) fa1[2] = G_RA(0, 1, 2); fb1[2] = G_RB(1, 2); G_SB
+                G_MM4(0, 3, fb0, fa0) G_DMA(3) fa1[3] = G_RA(0, 1, 3); fb1[3] = G_RB(1, 3); G_SB
+                G_MM4(1, 0, fb0, fa1) G_DMA(4) fa0[0] = G_RA(1, 0, 0); G_SB
+                G_MM4(1, 1, fb0, fa1) G_DMA(5) fa0[1] = G_RA(1, 0, 1); G_SB
+                G_MM4(1, 2, fb0, fa1) G_DMA(6) fa0[2] = G_RA(1, 0, 2); G_SB
+                G_MM4(1, 3, fb0, fa1) G_DMA(7) fa0[3] = G_RA(1, 0, 3); G_SB
+                G_MM4(0, 0, fb1, fa0) fa1[0] = G_RA(1, 1, 0); G_SB
+                G_MM4(0, 1, fb1, fa0) fa1[1] = G_RA(1, 1, 1); G_SB
+                G_MM4(0, 2, fb1, fa0) fa1[2] = G_RA(1, 1, 2); G_SB
+                G_MM4(0, 3, fb1, fa0) fa1[3] = G_RA(1, 1, 3); G_SB
+                } else {   // PIN == 2: one LDS-DMA every other step
+                G_MM4(0, 0, fb0, fa0) G_DMA(0) fa1[0] = G_RA(0, 1, 0); fb1[0] = G_RB(1, 0); G_SB
+                G_MM4(0, 1, fb0, fa0) fa1[1] = G_RA(0, 1, 1); fb1[1] = G_RB(1, 1); G_SB
+                G_MM4(0, 2, fb0, fa0) G_DMA(1) fa1[2] = G_RA(0, 1, 2); fb1[2] = G_RB(1, 2); G_SB
+                G_MM4(0, 3, fb0, fa0) fa1[3] = G_RA(0, 1, 3); fb1[3] = G_RB(1, 3); G_SB
+                G_MM4(1, 0, fb0, fa1) G_DMA(2) fa0[0] = G_RA(1, 0, 0); G_SB
+                G_MM4(1, 1, fb0, fa1) fa0[1] = G_RA(1, 0, 1); G_SB
+                G_MM4(1, 2, fb0, fa1) G_DMA(3) fa0[2] = G_RA(1, 0, 2); G_SB
+                G_MM4(1, 3, fb0, fa1) fa0[3] = G_RA(1, 0, 3); G_SB
+                G_MM4(0, 0, fb1, fa0) G_DMA(4) fa1[0] = G_RA(1, 1, 0); G_SB
+                G_MM4(0, 1, fb1, fa0) fa1[1] = G_RA(1, 1, 1); G_SB
+                G_MM4(0, 2, fb1, fa0) G_DMA(5) fa1[2] = G_RA(1, 1, 2); G_SB
+                G_MM4(0, 3, fb1, fa0) fa1[3] = G_RA(1, 1, 3); G_SB
+                }
+                if constexpr (PIN == 2) { G_MM4(1, 0, fb1, fa1) G_DMA(6) G_SB G_MM4(1, 1, fb1, fa1) G_SB G_MM4(1, 2, fb1, fa1) G_DMA(7) G_SB G_MM4(1, 3, fb1, fa1) G_SB }
+                else {
+                G_MM4(1, 0, fb1, fa1) G_SB
+                G_MM4(1, 1, fb1, fa1) G_SB
+                G_MM4(1, 2, fb1, fa1) G_SB
+                G_MM4(1, 3, fb1, fa1) G_SB
+                }
+#undef G_RA
+#undef G_RB
+#undef G_MM4
+#undef G_SB
+#undef G_DMA
+                continue;
+            }
+        }
         if (kt + 1 < nk && !(p.debug & 4)) {
             char* nxt = smem + ((kt + 1) & 1) * STAGE2;
             glds_tile<TA>(A, p.lda, m0, kbeg + (kt + 1) * 64, nxt, wave, lane);
@@ -1330,7 +1393,8 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
               (p.k_per_split % 64 == 0);
     if (ss && use_ss < 0 && use256 != 2) {
         const bool nt = !a->trans_a && !a->trans_b;
-        if (nt && big) ss = false;     // 256^2 wins every NT shape it can tile since the epilogue left LDS (proj 80 vs 99 us, fc2 271 vs 289-317 us)
+        static const int nt_min = [] { const char* e = getenv("DEVIAS_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 0; }();   // A/B knob (old policy: 1000)
+        if (nt && big && (int64_t)(a->M / T2) * (a->N / T2) * split >= nt_min) ss = false;     // 256^2 wins every NT shape it can tile since the epilogue left LDS (proj 80 vs 99 us, fc2 271 vs 289-317 us)
     }
     if (use256 >= 2 && big) ss = false;
     bool colsum_fused = false;
@@ -1380,6 +1444,8 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(NT2);
         const int ta = a->trans_a, tb = a->trans_b;
         if (!ta && !tb && use256 == 3 && split == 1) hipLaunchKernelGGL(gemm256r_kernel, grid, block, 0, st, p);
+        else if (!ta && !tb && (p.debug & 256)) hipLaunchKernelGGL((gemm256_kernel<false, false, 2>), grid, block, 0, st, p);
+        else if (!ta && !tb && !(p.debug & 512)) hipLaunchKernelGGL((gemm256_kernel<false, false, 1>), grid, block, 0, st, p);
         else if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, block, 0, st, p);
         else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, block, 0, st, p);
         else if (ta && tb) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, block, 0, st, p);
