@@ -57,11 +57,14 @@ def device_info(device: int = 0):
     return {"cus": out[0], "clock_khz": out[1], "lds_per_block": out[2], "wave": out[3], "gfx": out[4]}
 
 
+_WGRAD_SLOTS = int(__import__("os").environ.get("DEVIAS_WGRAD_SLOTS", "512"))     # A/B knob (tools/ab_bench.py)
+
+
 def auto_split_k(M: int, N: int, K: int, bk: int = 64) -> int:
     """Split the long reduction of a weight-gradient GEMM so that (tiles x splits) is just under ONE full round of the kernel
     that will run it: 512 slots for the bf16 256x128 kernel (256 CUs x 2 workgroups), 768 for the 128x128 kernel."""
     if bk == 64 and M % 256 == 0 and N % 128 == 0:
-        tiles, slots = (M // 256) * (N // 128), 512
+        tiles, slots = (M // 256) * (N // 128), _WGRAD_SLOTS
     else:
         tiles, slots = ((M + 127) // 128) * ((N + 127) // 128), 768
     if tiles >= slots or K < 8 * bk:
