@@ -29,6 +29,7 @@ struct GemmP {
     float* colsum_part;   // optional: per-(wave row-tile) partial column sums of the stored output, [M / (16*NI)][N]
     int group_m;          // tile rasterisation: GM row-tiles per group (m fastest inside a group); 1 = n fastest
     int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
+    int nt_store;         // experiment: non-temporal C / aux stores (keep the operand panels in L2)
     int epi_swap;         // 1 = register-transposed epilogue (epilogue_swap), 0 = LDS-staged (epilogue_staged)
     int stagger;          // experiment: first-round workgroups start (blockIdx/8 % 4) * stagger ticks (10 ns) late, to spread the store bursts
     int debug;            // timing ablations only (DEVIAS_GEMM_DEBUG): 1 = one K-tile, 2 = no epilogue stores, 4 = no LDS-DMA after tile 0
@@ -332,7 +333,8 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
             if (p.act == DEVIAS_ACT_GELU) {
                 if (aux_out) {
                     bf16x8 pre = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                    *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
+                    if (p.nt_store) __builtin_nontemporal_store(pre, reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol));
+                    else *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
@@ -383,7 +385,8 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                 *reinterpret_cast<f32x4*>(C + 4) = o1;
             } else {
                 bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                if (!(p.debug & 64) || v[0] == 12345.678f)
+                if (p.nt_store == 1) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol));
+                else if (!(p.debug & 64) || v[0] == 12345.678f)
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
             }
         }
@@ -1363,7 +1366,8 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     p.vec_c = vc ? 1 : 0;
     { const char* e = getenv("DEVIAS_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
     { const char* e = getenv("DEVIAS_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
-    { const char* e = getenv("DEVIAS_GEMM_EPI"); p.epi_swap = e ? atoi(e) : 1; }       // read per call: tests compare both epilogues
+    { const char* e = getenv("DEVIAS_GEMM_EPI"); p.epi_swap = e ? atoi(e) : 1; }
+    { static const int nts = [] { const char* e = getenv("DEVIAS_GEMM_NTSTORE"); return e ? atoi(e) : 0; }(); p.nt_store = nts; }       // read per call: tests compare both epilogues
     {   // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
         // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
         static const int gm = [] { const char* e = getenv("DEVIAS_GEMM_GROUPM"); return e ? atoi(e) : 0; }();
