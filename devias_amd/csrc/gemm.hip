@@ -29,9 +29,7 @@ struct GemmP {
     float* colsum_part;   // optional: per-(wave row-tile) partial column sums of the stored output, [M / (16*NI)][N]
     int group_m;          // tile rasterisation: GM row-tiles per group (m fastest inside a group); 1 = n fastest
     int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
-    int nt_store;         // experiment: non-temporal C / aux stores (keep the operand panels in L2)
     int epi_swap;         // 1 = register-transposed epilogue (epilogue_swap), 0 = LDS-staged (epilogue_staged)
-    int stagger;          // experiment: first-round workgroups start (blockIdx/8 % 4) * stagger ticks (10 ns) late, to spread the store bursts
     int debug;            // timing ablations only (DEVIAS_GEMM_DEBUG): 1 = one K-tile, 2 = no epilogue stores, 4 = no LDS-DMA after tile 0
 };
 
@@ -333,8 +331,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
             if (p.act == DEVIAS_ACT_GELU) {
                 if (aux_out) {
                     bf16x8 pre = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                    if (p.nt_store) __builtin_nontemporal_store(pre, reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol));
-                    else *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
+                    *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
@@ -385,8 +382,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                 *reinterpret_cast<f32x4*>(C + 4) = o1;
             } else {
                 bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                if (p.nt_store == 1) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol));
-                else if (!(p.debug & 64) || v[0] == 12345.678f)
+                if (!(p.debug & 64) || v[0] == 12345.678f)
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
             }
         }
@@ -664,10 +660,6 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
 
-    if (p.stagger > 0 && blockIdx.x < 256) {
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(((blockIdx.x >> 3) & 3) * p.stagger);
-        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-    }
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
     if (p.debug & 8) st0 = __builtin_amdgcn_s_memrealtime();
     f32x4 acc[8][4];
@@ -707,7 +699,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fa0[i] = G_RA(0, 0, i);
                 G_SB
-                if constexpr (PIN == 1) {
+                {
                 G_MM4(0, 0, fb0, fa0) G_DMA(0) fa1[0] = G_RA(0, 1, 0); fb1[0] = G_RB(1, 0); G_SB
                 G_MM4(0, 1, fb0, fa0) G_DMA(1) fa1[1] = G_RA(0, 1, 1); fb1[1] = G_RB(1, 1); G_SB
                 G_MM4(0, 2, fb0, fa0) G_DMA(2) fa1[2] = G_RA(0, 1, 2); fb1[2] = G_RB(1, 2); G_SB
@@ -720,27 +712,11 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
                 G_MM4(0, 1, fb1, fa0) fa1[1] = G_RA(1, 1, 1); G_SB
                 G_MM4(0, 2, fb1, fa0) fa1[2] = G_RA(1, 1, 2); G_SB
                 G_MM4(0, 3, fb1, fa0) fa1[3] = G_RA(1, 1, 3); G_SB
-                } else {   // PIN == 2: one LDS-DMA every other step
-                G_MM4(0, 0, fb0, fa0) G_DMA(0) fa1[0] = G_RA(0, 1, 0); fb1[0] = G_RB(1, 0); G_SB
-                G_MM4(0, 1, fb0, fa0) fa1[1] = G_RA(0, 1, 1); fb1[1] = G_RB(1, 1); G_SB
-                G_MM4(0, 2, fb0, fa0) G_DMA(1) fa1[2] = G_RA(0, 1, 2); fb1[2] = G_RB(1, 2); G_SB
-                G_MM4(0, 3, fb0, fa0) fa1[3] = G_RA(0, 1, 3); fb1[3] = G_RB(1, 3); G_SB
-                G_MM4(1, 0, fb0, fa1) G_DMA(2) fa0[0] = G_RA(1, 0, 0); G_SB
-                G_MM4(1, 1, fb0, fa1) fa0[1] = G_RA(1, 0, 1); G_SB
-                G_MM4(1, 2, fb0, fa1) G_DMA(3) fa0[2] = G_RA(1, 0, 2); G_SB
-                G_MM4(1, 3, fb0, fa1) fa0[3] = G_RA(1, 0, 3); G_SB
-                G_MM4(0, 0, fb1, fa0) G_DMA(4) fa1[0] = G_RA(1, 1, 0); G_SB
-                G_MM4(0, 1, fb1, fa0) fa1[1] = G_RA(1, 1, 1); G_SB
-                G_MM4(0, 2, fb1, fa0) G_DMA(5) fa1[2] = G_RA(1, 1, 2); G_SB
-                G_MM4(0, 3, fb1, fa0) fa1[3] = G_RA(1, 1, 3); G_SB
                 }
-                if constexpr (PIN == 2) { G_MM4(1, 0, fb1, fa1) G_DMA(6) G_SB G_MM4(1, 1, fb1, fa1) G_SB G_MM4(1, 2, fb1, fa1) G_DMA(7) G_SB G_MM4(1, 3, fb1, fa1) G_SB }
-                else {
                 G_MM4(1, 0, fb1, fa1) G_SB
                 G_MM4(1, 1, fb1, fa1) G_SB
                 G_MM4(1, 2, fb1, fa1) G_SB
                 G_MM4(1, 3, fb1, fa1) G_SB
-                }
 #undef G_RA
 #undef G_RB
 #undef G_MM4
@@ -786,79 +762,6 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     if (p.epi_swap) { epilogue_swap<8>(p, acc, m0 + wm * 128, n0 + wn * 64, z, lane); return; }
     __syncthreads();                                   // every wave is done reading the operand stages
     epilogue_staged<8, 4>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, z, lane);
-}
-
-
-// =====================================================================================================================
-// Experiment (DEVIAS_GEMM256=3): the 256 x 256 x 64 kernel with REGISTER-staged operands (global_load_dwordx4 -> VGPR ->
-// ds_write_b128 into the same swizzled images) instead of LDS-DMA, k-contiguous operands only.  Question it answers: is the
-// per-instruction issue cost of LDS-DMA (60-185 cycles per 1-KiB piece, MI355X_MICROARCH.md) what holds the K loop at 1.38 PFLOP/s?
-// =====================================================================================================================
-__global__ __launch_bounds__(NT2) void gemm256r_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int t = xcd_remap(blockIdx.x, ntiles);
-    int tm, tn;
-    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-    const int m0 = tm * T2, n0 = tn * T2;
-    const int nk = p.K / 64;
-    const bf16* A = reinterpret_cast<const bf16*>(p.A);
-    const bf16* B = reinterpret_cast<const bf16*>(p.B);
-    // thread -> 4 A pieces + 4 B pieces of 16 B per K-tile: row = (tid >> 3) + 64 * i, chunk = tid & 7
-    const int prow = tid >> 3, pch = tid & 7;
-    const bf16* ap = A + (int64_t)(m0 + prow) * p.lda + pch * 8;
-    const bf16* bp = B + (int64_t)(n0 + prow) * p.ldb + pch * 8;
-    const int64_t astep = (int64_t)64 * p.lda, bstep = (int64_t)64 * p.ldb;
-    u32x4 ra[4], rb[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const u32x4*>(ap + i * astep + kt * 64);
-            rb[i] = *reinterpret_cast<const u32x4*>(bp + i * bstep + kt * 64);
-        }
-    };
-    auto lstore = [&](char* st) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = prow + 64 * i;
-            *reinterpret_cast<u32x4*>(st + off_kc2(row, pch)) = ra[i];
-            *reinterpret_cast<u32x4*>(st + 32768 + off_kc2(row, pch)) = rb[i];
-        }
-    };
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gload(0);
-    lstore(smem);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        char* cur = smem + (kt & 1) * STAGE2;
-        if (kt + 1 < nk) gload(kt + 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = read_frag2<false>(cur + 32768, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-            for (int ih = 0; ih < 2; ++ih) {
-                bf16x8 fa[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = read_frag2<false>(cur, wm * 128 + (ih * 4 + i) * 16, ks, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ih * 4 + i][j] = mfma16(fb[j], fa[i], acc[ih * 4 + i][j]);
-            }
-        }
-        if (kt + 1 < nk) lstore(smem + ((kt + 1) & 1) * STAGE2);      // stage (kt+1)&1 was last read in iteration kt-1 (barrier below)
-        __syncthreads();
-    }
-    epilogue_swap<8>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane);
 }
 
 
@@ -1365,9 +1268,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
                       (!a->aux_out || aligned16(a->aux_out)) && aligned16(a->C);
     p.vec_c = vc ? 1 : 0;
     { const char* e = getenv("DEVIAS_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
-    { const char* e = getenv("DEVIAS_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
-    { const char* e = getenv("DEVIAS_GEMM_EPI"); p.epi_swap = e ? atoi(e) : 1; }
-    { static const int nts = [] { const char* e = getenv("DEVIAS_GEMM_NTSTORE"); return e ? atoi(e) : 0; }(); p.nt_store = nts; }       // read per call: tests compare both epilogues
+    { const char* e = getenv("DEVIAS_GEMM_EPI"); p.epi_swap = e ? atoi(e) : 1; }       // read per call: tests compare both epilogues
     {   // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
         // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
         static const int gm = [] { const char* e = getenv("DEVIAS_GEMM_GROUPM"); return e ? atoi(e) : 0; }();
@@ -1400,7 +1301,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         static const int nt_min = [] { const char* e = getenv("DEVIAS_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 0; }();   // A/B knob (old policy: 1000)
         if (nt && big && (int64_t)(a->M / T2) * (a->N / T2) * split >= nt_min) ss = false;     // 256^2 wins every NT shape it can tile since the epilogue left LDS (proj 80 vs 99 us, fc2 271 vs 289-317 us)
     }
-    if (use256 >= 2 && big) ss = false;
+    if (use256 == 2 && big) ss = false;
     bool colsum_fused = false;
     if (a->colsum) {
         DEVIAS_REQUIRE(split == 1 && a->ws && !(a->c_f32 && a->dtype == DEVIAS_BF16),
@@ -1447,9 +1348,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;
         dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(NT2);
         const int ta = a->trans_a, tb = a->trans_b;
-        if (!ta && !tb && use256 == 3 && split == 1) hipLaunchKernelGGL(gemm256r_kernel, grid, block, 0, st, p);
-        else if (!ta && !tb && (p.debug & 256)) hipLaunchKernelGGL((gemm256_kernel<false, false, 2>), grid, block, 0, st, p);
-        else if (!ta && !tb && !(p.debug & 512)) hipLaunchKernelGGL((gemm256_kernel<false, false, 1>), grid, block, 0, st, p);
+        if (!ta && !tb && !(p.debug & 512)) hipLaunchKernelGGL((gemm256_kernel<false, false, 1>), grid, block, 0, st, p);
         else if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, block, 0, st, p);
         else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, block, 0, st, p);
         else if (ta && tb) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, block, 0, st, p);
