@@ -12,7 +12,7 @@ int devias_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int devias_version(void) { return 100; }   // 0.1.0
+extern "C" int devias_version(void) { return 120; }   // 0.1.20: + multi-tensor optimizer entry points (110), + devias_fame_* (120)
 
 extern "C" const char* devias_last_error(void) { return g_err; }
 

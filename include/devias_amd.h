@@ -43,7 +43,7 @@ extern "C" {
 #define DEVIAS_ACT_DGELU 4     /* backward: v *= gelu'(aux_in) with aux_in = saved pre-activation */
 #define DEVIAS_ACT_DRELU 5     /* backward: v = aux_in > 0 ? v : 0 with aux_in = saved ReLU output */
 
-int devias_version(void);
+int devias_version(void);          /* 100 + additions: 110 = multi-tensor optimizer entry points, 120 = devias_fame_* */
 const char* devias_last_error(void);
 /* fills: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes per block, [3]=wavefront size, [4]=gfx arch number (e.g. 950) */
 int devias_device_info(int device, int64_t* out5);
