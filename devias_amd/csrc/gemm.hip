@@ -641,6 +641,35 @@ __device__ __forceinline__ bf16x8 read_frag2(const char* lds, int base16, int ks
     }
 }
 
+// Transposing LDS read issued from inline asm.  Why: the compiler cannot see which LDS bytes an in-flight LDS-DMA writes, and for the
+// ds_read_tr builtin (unlike plain C++ LDS loads) it protects itself with s_waitcnt vmcnt(0) before the first such read -- which waits
+// for the NEXT K-tile's DMA and turns a 2-stage ring into a single-stage one.  The asm read is invisible to that logic; the price is
+// that its result is not tracked either: tr_fence() below is the (only) point where the values become usable.
+__device__ __forceinline__ u32x2 ds_read_tr_asm(const char* lds_ptr) {
+    u32x2 r;
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds_ptr;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+template <bool KSTRIDED>
+__device__ __forceinline__ bf16x8 read_frag2a(const char* lds, int base16, int ks, int lane) {
+    if constexpr (!KSTRIDED) return read_frag2<false>(lds, base16, ks, lane);
+    else {
+        int g = lane >> 4, t = lane & 15, q = t >> 2, pp = t & 3;
+        int k = ks * 32 + g * 8 + q;
+        int col = base16 + 4 * pp;
+        const u32x2 lo = ds_read_tr_asm(lds + off_ks2(k, col)), hi = ds_read_tr_asm(lds + off_ks2(k + 4, col));
+        const u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+        return *reinterpret_cast<const bf16x8*>(&r);
+    }
+}
+// wait for every outstanding LDS read; the fragments are operands so that no consumer can be scheduled above the wait
+__device__ __forceinline__ void tr_fence(bf16x8 (&a)[8], bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 :: "memory");
+}
+
 template <bool TA, bool TB, int PIN = 0>
 __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
@@ -733,10 +762,19 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[8], fb[4];
+            if constexpr (TA || TB) {
+                // plain (compiler-tracked) reads first, asm transposing reads after them, one fence for all
+                if constexpr (!TB) { _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = read_frag2<false>(cur + 32768, wn * 64 + j * 16, ks, lane); }
+                if constexpr (!TA) { _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = read_frag2<false>(cur, wm * 128 + i * 16, ks, lane); }
+                if constexpr (TB) { _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = read_frag2a<true>(cur + 32768, wn * 64 + j * 16, ks, lane); }
+                if constexpr (TA) { _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = read_frag2a<true>(cur, wm * 128 + i * 16, ks, lane); }
+                tr_fence(fa, fb);
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j] = read_frag2<TB>(cur + 32768, wn * 64 + j * 16, ks, lane);
 #pragma unroll
             for (int i = 0; i < 8; ++i) fa[i] = read_frag2<TA>(cur, wm * 128 + i * 16, ks, lane);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1286,22 +1324,21 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     bool big = use256 && a->dtype == DEVIAS_BF16 && vec && vc && (a->M % T2 == 0) && (a->N % T2 == 0) && (a->K % 64 == 0) &&
                (p.k_per_split % 64 == 0);
     big = big && v16;
-    // Kernel choice, measured on MI355X at the ViT-B shapes (M = 50176; tools/gemm_ablate.py):
-    //   * 256x128 single-stage kernel (2 workgroups/CU): best for every dgrad (B k-strided) and wgrad (both k-strided) shape
-    //     and for NT shapes with a small grid (proj) -- co-resident workgroups hide each other's HBM-write-bound epilogue;
-    //   * 256x256 two-stage kernel (1 workgroup/CU): best steady state (1.38 PFLOP/s per K-tile), wins the NT forward
-    //     GEMMs with >= ~4 rounds of 256 tiles (qkv, fc1, fc2, agg K|V);
+    // Kernel choice, measured on MI355X at the ViT-B shapes (M = 50176; tools/gemm_block_shapes.py, tools/ab_bench.py):
+    //   * 256x256 two-stage LDS-DMA kernel (1 workgroup/CU): every shape it can tile, all four operand layouts.  (Its k-strided layouts
+    //     were slower than the single-stage kernel until their transposing LDS reads moved to inline asm: the compiler fenced the
+    //     builtin with vmcnt(0), i.e. waited for the NEXT K-tile's DMA, which made the ring single-stage.  After: dgrad/wgrad 5-12 %
+    //     faster than the single-stage kernel, step +2.4 %.)
+    //   * 256x128 single-stage kernel (2 workgroups/CU): N a multiple of 128 but not of 256;
     //   * 128x128 register-staged kernel: ragged / unaligned / fp32 shapes.
-    // DEVIAS_GEMM_SS = 0 disables / 1 forces the single-stage kernel; DEVIAS_GEMM256 = 0 disables / 2 forces the 256^2 kernel.
+    // DEVIAS_GEMM_SS = 0 disables / 1 prefers the single-stage kernel (the round-1 policy for dgrad/wgrad); DEVIAS_GEMM256 = 0 disables the 256^2 kernel.
     static const int use_ss = [] { const char* e = getenv("DEVIAS_GEMM_SS"); return e ? atoi(e) : -1; }();
     bool ss = use_ss != 0 && a->dtype == DEVIAS_BF16 && vec && v16 && (a->M % SS_BM == 0) && (a->N % SS_BN == 0) && (a->K % 64 == 0) &&
               (p.k_per_split % 64 == 0);
-    if (ss && use_ss < 0 && use256 != 2) {
+    if (ss && big) {
         const bool nt = !a->trans_a && !a->trans_b;
-        static const int nt_min = [] { const char* e = getenv("DEVIAS_GEMM_NT_MIN_TILES"); return e ? atoi(e) : 0; }();   // A/B knob (old policy: 1000)
-        if (nt && big && (int64_t)(a->M / T2) * (a->N / T2) * split >= nt_min) ss = false;     // 256^2 wins every NT shape it can tile since the epilogue left LDS (proj 80 vs 99 us, fc2 271 vs 289-317 us)
+        if (use_ss < 0 || nt) ss = false;
     }
-    if (use256 == 2 && big) ss = false;
     bool colsum_fused = false;
     if (a->colsum) {
         DEVIAS_REQUIRE(split == 1 && a->ws && !(a->c_f32 && a->dtype == DEVIAS_BF16),
