@@ -651,23 +651,38 @@ __device__ __forceinline__ u32x2 ds_read_tr_asm(const char* lds_ptr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
     return r;
 }
-template <bool KSTRIDED>
-__device__ __forceinline__ bf16x8 read_frag2a(const char* lds, int base16, int ks, int lane) {
-    if constexpr (!KSTRIDED) return read_frag2<false>(lds, base16, ks, lane);
-    else {
-        int g = lane >> 4, t = lane & 15, q = t >> 2, pp = t & 3;
-        int k = ks * 32 + g * 8 + q;
-        int col = base16 + 4 * pp;
-        const u32x2 lo = ds_read_tr_asm(lds + off_ks2(k, col)), hi = ds_read_tr_asm(lds + off_ks2(k + 4, col));
-        const u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
-        return *reinterpret_cast<const bf16x8*>(&r);
-    }
+// One k-strided fragment = two transposing reads.  The halves stay separate register pairs until tr_fence has run: nothing (not even
+// a register copy that assembles the 128-bit operand) may touch them while the reads are in flight.
+struct TrFrag { u32x2 lo, hi; };
+__device__ __forceinline__ TrFrag read_frag2a(const char* lds, int base16, int ks, int lane) {
+    int g = lane >> 4, t = lane & 15, q = t >> 2, pp = t & 3;
+    int k = ks * 32 + g * 8 + q;
+    int col = base16 + 4 * pp;
+    TrFrag f;
+    f.lo = ds_read_tr_asm(lds + off_ks2(k, col));
+    f.hi = ds_read_tr_asm(lds + off_ks2(k + 4, col));
+    return f;
 }
-// wait for every outstanding LDS read; the fragments are operands so that no consumer can be scheduled above the wait
-__device__ __forceinline__ void tr_fence(bf16x8 (&a)[8], bf16x8 (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
-                 :: "memory");
+__device__ __forceinline__ bf16x8 tr_assemble(const TrFrag& f) {
+    const u32x4 r = {f.lo[0], f.lo[1], f.hi[0], f.hi[1]};
+    return *reinterpret_cast<const bf16x8*>(&r);
+}
+// wait for every outstanding LDS read; the raw halves are operands so that nothing that reads them can be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void tr_fence(TrFrag (&f)[N]) {
+    static_assert(N == 4 || N == 8, "fragment groups of 4 (B) or 8 (A)");
+    if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo), "+v"(f[3].hi) :: "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo), "+v"(f[3].hi),
+                     "+v"(f[4].lo), "+v"(f[4].hi), "+v"(f[5].lo), "+v"(f[5].hi), "+v"(f[6].lo), "+v"(f[6].hi), "+v"(f[7].lo), "+v"(f[7].hi) :: "memory");
+}
+// plain (compiler-tracked) fragments ride through the same wait so that they, too, are complete after it
+template <int N>
+__device__ __forceinline__ void plain_fence(bf16x8 (&f)[N]) {
+    static_assert(N == 4 || N == 8, "fragment groups of 4 (B) or 8 (A)");
+    if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) :: "memory");
 }
 
 template <bool TA, bool TB, int PIN = 0>
@@ -763,12 +778,15 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[8], fb[4];
             if constexpr (TA || TB) {
-                // plain (compiler-tracked) reads first, asm transposing reads after them, one fence for all
+                // plain (compiler-tracked) reads first, the asm transposing reads after them, then the waits; fragments are assembled
+                // only after their wait
+                TrFrag ta[TA ? 8 : 1], tb[TB ? 4 : 1];
                 if constexpr (!TB) { _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = read_frag2<false>(cur + 32768, wn * 64 + j * 16, ks, lane); }
                 if constexpr (!TA) { _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = read_frag2<false>(cur, wm * 128 + i * 16, ks, lane); }
-                if constexpr (TB) { _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = read_frag2a<true>(cur + 32768, wn * 64 + j * 16, ks, lane); }
-                if constexpr (TA) { _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = read_frag2a<true>(cur, wm * 128 + i * 16, ks, lane); }
-                tr_fence(fa, fb);
+                if constexpr (TB) { _Pragma("unroll") for (int j = 0; j < 4; ++j) tb[j] = read_frag2a(cur + 32768, wn * 64 + j * 16, ks, lane); }
+                if constexpr (TA) { _Pragma("unroll") for (int i = 0; i < 8; ++i) ta[i] = read_frag2a(cur, wm * 128 + i * 16, ks, lane); }
+                if constexpr (TB) { tr_fence(tb); _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = tr_assemble(tb[j]); } else plain_fence(fb);
+                if constexpr (TA) { tr_fence(ta); _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = tr_assemble(ta[i]); } else plain_fence(fa);
             } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j] = read_frag2<TB>(cur + 32768, wn * 64 + j * 16, ks, lane);
