@@ -45,9 +45,14 @@ class FAME(nn.Module):
         _call("devias_fame_blur", diffs.data_ptr(), tmp.data_ptr(), B * S, H, W, self.gauss_size, self.gauss_sigma, st)
         _call("devias_fame_seg_refine", tmp.data_ptr(), cmap.data_ptr(), B * S, S, HW, self.eps, diffs.data_ptr(), st)
         _call("devias_fame_blur", diffs.data_ptr(), tmp.data_ptr(), B * S, H, W, self.gauss_size, self.gauss_sigma, st)
-        binmask = torch.empty(B * S, H, W, dtype=torch.uint8, device=dev)
-        pooled = torch.empty(B * S, (H // 16) * (W // 16), dtype=torch.float32, device=dev)
-        _call("devias_fame_binarize_pool", tmp.data_ptr(), B * S, H, W, int(self.beta * HW), 16, binmask.data_ptr(), pooled.data_ptr(), st)
+        num_fg = int(self.beta * HW)
+        if num_fg <= 0:                                                # torch.topk(k=0): an empty foreground
+            binmask = torch.zeros(B * S, H, W, dtype=torch.uint8, device=dev)
+            pooled = torch.zeros(B * S, (H // 16) * (W // 16), dtype=torch.float32, device=dev)
+        else:
+            binmask = torch.empty(B * S, H, W, dtype=torch.uint8, device=dev)
+            pooled = torch.empty(B * S, (H // 16) * (W // 16), dtype=torch.float32, device=dev)
+            _call("devias_fame_binarize_pool", tmp.data_ptr(), B * S, H, W, min(num_fg, HW), 16, binmask.data_ptr(), pooled.data_ptr(), st)
         pooled = pooled.view(B, S, -1)
         return binmask.view(B, S, H, W), pooled[:, 0], pooled[:, 1:]
 
