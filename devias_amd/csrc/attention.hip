@@ -37,6 +37,13 @@ __device__ __forceinline__ bf16x8 frag_rows(const char* img, int base, int ks, i
     int row = base + (lane & 15);
     return *reinterpret_cast<const bf16x8*>(img + img_row_off(row, ks * 4 + (lane >> 4)));
 }
+// the SAME fragment as frag_rows, read from the transposed-read image: its 32-byte-window swizzle also keeps ds_read_b128 conflict free
+// (a 16-lane group of that instruction covers 16 rows x one window: 8 rows take its low half, 8 its high half, and (row & 1, (row >> 1) & 3)
+// is distinct within each eight) -- so a tile that is consumed both row-wise and transposed needs ONE image, one pass of LDS writes
+__device__ __forceinline__ bf16x8 frag_rows_tr(const char* img, int base, int ks, int lane) {
+    int row = base + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(img + img_tr_off(row, 32 * ks + 8 * (lane >> 4)));
+}
 // fragment of the transposed image for the product over ROWS of the tile (k = tile row, permuted as in the header):
 // lane holds tile[row = 16*(2s + (j>>2)) + 4g + (j&3)][col = cbase + (lane&15)], j = 0..7
 __device__ __forceinline__ bf16x8 frag_tr(const char* img, int cbase, int s, int lane) {
@@ -56,6 +63,21 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// Block -> (block-in-head, head, batch).  Every block of one (batch, head) streams the same K/V (forward, dQ) or Q/dO (dK/dV) rows.  Workgroups go
+// to the 8 XCDs round-robin by linear id, and each XCD has a private L2: with the plain (x = block-in-head, y = head, z = batch) order the ~13
+// blocks of a head land on 8 different L2s and each fetches the head's rows from the Infinity Cache again.  With `xcd` the grid is linear
+// and all blocks of a head get ids congruent mod 8: one XCD, one fetch.  (Speed only; any mapping is correct.)
+struct HeadMap { int blk, h, b; };
+__device__ __forceinline__ HeadMap head_map(int nblk, int H, int B, bool xcd) {
+    HeadMap m;
+    if (!xcd) { m.blk = blockIdx.x; m.h = blockIdx.y; m.b = blockIdx.z; return m; }
+    const int bid = blockIdx.x, x = bid & 7, slot = bid >> 3;
+    const int hidx = (slot / nblk) * 8 + x;
+    m.blk = slot - (slot / nblk) * nblk;
+    m.h = hidx % H; m.b = hidx / H;
+    return m;
 }
 
 // stage a [64][64] bf16 tile: 512 16-byte chunks, 512/NT per thread.  rows >= nrows are zero-filled.
@@ -108,17 +130,18 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
 // ======================================= forward (bf16) ===================================================
 template <int QT, int NW, bool DMA, int OCC = 1>
 __global__ __launch_bounds__(NW * 64, OCC) void mhsa_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
-                                                            float* __restrict__ lse, int N, int H, float scale) {
+                                                            float* __restrict__ lse, int N, int H, float scale, int xcd) {
     __shared__ __attribute__((aligned(16))) char smem[DMA ? 32768 : 16384];   // DMA: two stages of (K row image | V transposed-read image)
     char* imgK = smem;            // row image of K tile  [key][d]
     char* imgV = smem + 8192;     // transposed-read image of V tile [key][d]
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = blockIdx.y, b = blockIdx.z;
+    const HeadMap hm = head_map((N + NW * 16 * QT - 1) / (NW * 16 * QT), H, xcd >> 16, (xcd & 1) != 0);
+    const int h = hm.h, b = hm.b;
     const int D = H * 64;
     const int64_t RS = 3 * (int64_t)D;
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
-    const int q0 = blockIdx.x * (NW * 16 * QT) + wave * (16 * QT);
+    const int q0 = hm.blk * (NW * 16 * QT) + wave * (16 * QT);
     const float sl2 = scale * LOG2E;
 
     bf16x8 qf[QT][2];
@@ -265,17 +288,17 @@ template <int QT, int NW>
 __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                               int N, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[24576];
-    char* imgK = smem;             // K rows   (S^T = K Q^T)
-    char* imgKt = smem + 8192;     // K transposed-read (dQ^T = K^T dS^T)
-    char* imgV = smem + 16384;     // V rows   (dP^T = V dO^T)
+                                                               int N, int H, float scale, int xcd) {
+    __shared__ __attribute__((aligned(16))) char smem[16384];
+    char* imgKt = smem;            // K, one image for both uses: row reads (S^T = K Q^T) and transposed reads (dQ^T = K^T dS^T)
+    char* imgV = smem + 8192;      // V rows   (dP^T = V dO^T)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const HeadMap hm = head_map((N + NW * 16 * QT - 1) / (NW * 16 * QT), H, xcd >> 16, (xcd & 1) != 0);
+    const int h = hm.h, b = hm.b;
     const int D = H * 64;
     const int64_t RS = 3 * (int64_t)D;
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
-    const int q0 = blockIdx.x * (NW * 16 * QT) + wave * (16 * QT);
+    const int q0 = hm.blk * (NW * 16 * QT) + wave * (16 * QT);
     const float sl2 = scale * LOG2E;
 
     bf16x8 qf[QT][2], dof[QT][2];
@@ -311,7 +334,6 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
     rk.load(base + D, RS, 0, N, tid);
     rv.load(base + 2 * D, RS, 0, N, tid);
     for (int t = 0; t < nkv; ++t) {
-        rk.store_rows(imgK, tid);
         rk.store_tr(imgKt, tid);
         rv.store_rows(imgV, tid);
         __syncthreads();
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                bf16x8 kf = frag_rows(imgK, 16 * kt, ks, lane);
+                bf16x8 kf = frag_rows_tr(imgKt, 16 * kt, ks, lane);
                 bf16x8 vf = frag_rows(imgV, 16 * kt, ks, lane);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
@@ -388,21 +410,20 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 // ======================================= backward dK, dV (bf16) ==========================================
 __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                 bf16* __restrict__ dqkv, int N, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 8192 + 512];
-    char* imgQ = smem;              // Q rows    (S = Q K^T)
-    char* imgQt = smem + 8192;      // Q transposed-read (dK^T = Q^T dS)
-    char* imgO = smem + 16384;      // dO rows   (dP = dO V^T)
-    char* imgOt = smem + 24576;     // dO transposed-read (dV^T = dO^T P)
-    float* s_lse = reinterpret_cast<float*>(smem + 32768);   // [64] log2-domain logsumexp (+inf for invalid rows)
+                                                                 bf16* __restrict__ dqkv, int N, int H, float scale, int xcd) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 512];
+    char* imgQt = smem;             // Q, one image: row reads (S = Q K^T) and transposed reads (dK^T = Q^T dS)
+    char* imgOt = smem + 8192;      // dO, one image: row reads (dP = dO V^T) and transposed reads (dV^T = dO^T P)
+    float* s_lse = reinterpret_cast<float*>(smem + 16384);   // [64] log2-domain logsumexp (+inf for invalid rows)
     float* s_dl = s_lse + 64;                                // [64] delta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const HeadMap hm = head_map((N + 127) / 128, H, xcd >> 16, (xcd & 1) != 0);
+    const int h = hm.h, b = hm.b;
     const int D = H * 64;
     const int64_t RS = 3 * (int64_t)D;
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
     const bf16* dobase = d_o + (int64_t)b * N * D + h * 64;
-    const int key0 = blockIdx.x * 128 + wave * 32;
+    const int key0 = hm.blk * 128 + wave * 32;
     const float sl2 = scale * LOG2E;
 
     bf16x8 kreg[2][2], vreg[2][2];
@@ -431,9 +452,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
     if (tid < 64) rstat = tid < N ? lse_bh[tid] * LOG2E : INFINITY;
     else if (tid < 128) rstat = (tid - 64) < N ? dl_bh[tid - 64] : 0.f;
     for (int t = 0; t < nq; ++t) {
-        rq.store_rows(imgQ, tid);
         rq.store_tr(imgQt, tid);
-        rdo.store_rows(imgO, tid);
         rdo.store_tr(imgOt, tid);
         if (tid < 128) s_lse[tid] = rstat;      // s_dl follows s_lse contiguously
         __syncthreads();
@@ -454,8 +473,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
-                bf16x8 qfr = frag_rows(imgQ, 16 * qt, ks, lane);
-                bf16x8 dofr = frag_rows(imgO, 16 * qt, ks, lane);
+                bf16x8 qfr = frag_rows_tr(imgQt, 16 * qt, ks, lane);
+                bf16x8 dofr = frag_rows_tr(imgOt, 16 * qt, ks, lane);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
                     acc_s[qt][kt] = mfma(qfr, kreg[kt][ks], acc_s[qt][kt]);
@@ -681,6 +700,12 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dkdv_f32_kernel(const float* __r
 
 }  // namespace
 
+// bit 0: XCD-aware linear grid (needs B*H % 8 == 0); bits 16..: B.  DEVIAS_ATTN_XCD=0 restores the plain 3-D grid.
+static int attn_xcd_flag(int B, int H) {
+    static const int on = [] { const char* e = getenv("DEVIAS_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    return (B << 16) | ((on && ((B * H) % 8 == 0)) ? 1 : 0);
+}
+
 extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
                                int32_t dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -690,12 +715,15 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
     if (dtype == DEVIAS_BF16)
         {
         static const int cfg = [] { const char* e = getenv("DEVIAS_ATTN_CFG"); return e ? atoi(e) : 0; }();
-        if (cfg == 1) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 2, false>), dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-        else if (cfg == 2) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 4, false>), dim3(cdiv(N, 256), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-        else if (cfg == 3) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 2, false>), dim3(cdiv(N, 64), H, B), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-        else if (cfg == 4) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, false>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-        else if (cfg == 5) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true, 4>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
-        else hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        const int xcd = attn_xcd_flag(B, H);
+#define FWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
+        if (cfg == 1) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 2, false>), FWD_GRID(128), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        else if (cfg == 2) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 4, false>), FWD_GRID(256), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        else if (cfg == 3) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 2, false>), FWD_GRID(64), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        else if (cfg == 4) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, false>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        else if (cfg == 5) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true, 4>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        else hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+#undef FWD_GRID
     }
     else if (dtype == DEVIAS_F32)
         hipLaunchKernelGGL(mhsa_fwd_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (float*)o, lse, N, H, scale);
@@ -712,15 +740,18 @@ extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, 
     DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_bwd: H and B must be <= 65535");
     if (dtype == DEVIAS_BF16) {
         static const int cfg = [] { const char* e = getenv("DEVIAS_ATTN_CFG"); return e ? atoi(e) : 0; }();
-#define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale
-        if (cfg == 1) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 2>), dim3(cdiv(N, 128), H, B), dim3(128), 0, st, DQ_ARGS);
-        else if (cfg == 2) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 4>), dim3(cdiv(N, 256), H, B), dim3(256), 0, st, DQ_ARGS);
-        else if (cfg == 3) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 2>), dim3(cdiv(N, 64), H, B), dim3(128), 0, st, DQ_ARGS);
-        else hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 4>), dim3(cdiv(N, 128), H, B), dim3(256), 0, st, DQ_ARGS);
+        const int xcd = attn_xcd_flag(B, H);
+#define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, xcd
+#define BWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
+        if (cfg == 1) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 2>), BWD_GRID(128), dim3(128), 0, st, DQ_ARGS);
+        else if (cfg == 2) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 4>), BWD_GRID(256), dim3(256), 0, st, DQ_ARGS);
+        else if (cfg == 3) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 2>), BWD_GRID(64), dim3(128), 0, st, DQ_ARGS);
+        else hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 4>), BWD_GRID(128), dim3(256), 0, st, DQ_ARGS);
 #undef DQ_ARGS
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");
-        hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel, dim3(cdiv(N, 128), H, B), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
-                           lse, delta, (bf16*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
+                           lse, delta, (bf16*)dqkv, N, H, scale, xcd);
+#undef BWD_GRID
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv)");
     } else if (dtype == DEVIAS_F32) {
         hipLaunchKernelGGL(mhsa_bwd_dq_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)o,
