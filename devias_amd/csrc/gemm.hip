@@ -1246,6 +1246,16 @@ __global__ void splitk_reduce_kernel(GemmP p) {
     }
 }
 
+// the weight-gradient case of the reduce (fp32 C with ldc == N, no epilogue beyond beta): 16 bytes per lane, no per-element div/mod
+__global__ __launch_bounds__(256) void splitk_reduce_plain_kernel(const float* __restrict__ ws, int split_k, int64_t total4, float* __restrict__ C, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(ws + i * 4);
+        for (int z = 1; z < split_k; ++z) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)z * total4 + i) * 4);
+        if (beta != 0.f) v += beta * *reinterpret_cast<const f32x4*>(C + i * 4);
+        *reinterpret_cast<f32x4*>(C + i * 4) = v;
+    }
+}
+
 // out[n] = beta*out[n] + sum_p part[p][n]; block (64 columns, 16 partial lanes), fixed order
 __global__ void gemm_colsum_final_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out, float beta) {
     __shared__ float sm[16][64];
@@ -1428,7 +1438,12 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     if (split > 1) {
         int64_t total = (int64_t)a->M * a->N;
         int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-        if (a->dtype == DEVIAS_BF16) hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3(blocks), dim3(256), 0, st, p);
+        const bool plain = p.c_f32 && a->ldc == a->N && (total % 4 == 0) && !a->bias && a->act == DEVIAS_ACT_NONE && !a->res && !a->row_scale &&
+                           aligned16(a->ws) && aligned16(a->C);
+        if (plain) {
+            int b4 = (int)((total / 4 + 255) / 256); if (b4 > 2048) b4 = 2048;
+            hipLaunchKernelGGL(splitk_reduce_plain_kernel, dim3(b4), dim3(256), 0, st, a->ws, split, total / 4, reinterpret_cast<float*>(a->C), a->beta);
+        } else if (a->dtype == DEVIAS_BF16) hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3(blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
         DEVIAS_CHECK_LAUNCH("devias_gemm(split-k reduce)");
     }
