@@ -264,3 +264,39 @@ def test_knn_classifier_matches_reference():
     for case in g["cases"]:
         t1, t5 = knn_classifier(f_tr.cuda(), lab_tr.cuda(), f_te.cuda(), lab_te.cuda(), case["k"], case["T"], num_classes=C)
         assert abs(t1 - case["top1"]) <= 0.9 and abs(t5 - case["top5"]) <= 0.9, (case, t1, t5)     # <= 2 of 230 borderline votes (fp32 summation order)
+
+
+def test_short_training_run_decreases_the_loss():
+    """integration: train_one_epoch (FAME masks, teacher logits as a tensor, layer-decay groups, cosine LR with warm-up, clipped fused
+    AdamW) on a fixed batch of 4 clips for 12 steps in bf16 -- the loss must stay finite and fall at every step"""
+    import types
+    import devias_amd
+    from devias_amd import optim_factory as of
+    from devias_amd.engine_for_slot import train_class_batch
+    from devias_amd.train_loss import TrainLoss
+    model = devias_amd.create_model("slot_vit_small_patch16_224", num_classes=400, all_frames=4, num_latents=2, slot_matching_method="matching",
+                                    agg_weights_tie=True, agg_depth=2, num_scene_classes=365, compute_dtype="bf16")
+    synth.fill_module_(model, seed=0)
+    model = model.cuda().train()
+    B = 4
+    x = synth.scene_video(B, 4, 224).cuda()
+    y = synth.targets(B, 400).cuda()
+    tl = synth.teacher_logits(B, 365).cuda()
+    fg = tuple(m.cuda() for m in synth.fg_masks(B, model.patch_embed.num_patches))
+    crit = TrainLoss(scene_criterion="KL", num_action_classes=400, slot_matching_method="matching", scene_loss_weight=4000,
+                     mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0)
+    assigner = of.LayerDecayValueAssigner.from_decay(0.75, model.get_num_layers())
+    args = types.SimpleNamespace(opt="adamw", lr=2e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=[0.9, 0.999])
+    opt = of.create_optimizer(args, model, get_num_layer=assigner.get_layer_id, get_layer_scale=assigner.get_scale)
+    sched = of.cosine_scheduler(2e-3, 1e-5, epochs=1, niter_per_ep=12, warmup_epochs=1, warmup_steps=2)
+    losses = []
+    for it in range(12):
+        for g in opt.param_groups:
+            g["lr"] = sched[it] * g["lr_scale"]
+        opt.zero_grad(set_to_none=True)
+        loss, out, ld = train_class_batch(model, tl, x, y, crit, fg_mask=fg)
+        loss.backward()
+        opt.step(max_norm=5.0)
+        losses.append(float(loss.detach().float().sum()))
+        assert np.isfinite(losses[-1]) and float(opt.last_grad_norm) > 0
+    assert losses[-1] < losses[0] - 0.3 and all(b <= a + 1e-3 for a, b in zip(losses[1:], losses[2:])), losses     # falls every step after the lr = 0 warm-up step
