@@ -90,3 +90,20 @@ def test_engine_step_with_fame():
     opt = FusedAdamW(model.parameters(), lr=1e-4)
     st = train_one_epoch(model, tl, crit, [(x, y)], opt, "cuda", 0, max_norm=1.0, mask_model=FAME(beta=0.5, prob_aug=0.5), check_finite_every=1)
     assert np.isfinite(st["loss"]) and st["grad_norm"] > 0
+
+
+@pytest.mark.parametrize("B,T,size,beta", [(2, 4, 96, 0.5), (3, 6, 160, 0.25), (1, 2, 224, 0.7)])
+def test_fame_masks_match_oracle_other_geometries(B, T, size, beta):
+    """sizes other than the goldens' (image not a multiple of the 32-pixel blur tile, 2-frame clips, other foreground fractions): device
+    masks vs the CPU oracle on the same structured clips"""
+    from devias_amd.fame import FAME
+    x = synth.scene_video(B, T, size, seed=2100 + size)
+    o = FameOracle(beta=beta, prob_aug=1.0)
+    _, _, (om, ompf), (obin, _, _) = o.forward(x, torch.arange(B), torch.arange(B).flip(0), torch.zeros(B))
+    f = FAME(beta=beta, prob_aug=1.0)
+    binmask, pooled, pooled_pf = f.masks(x.cuda())
+    assert int(binmask[:, 0].sum()) == B * int(beta * size * size)
+    agree = float((binmask[:, 0].cpu().float() == obin).float().mean())
+    assert agree >= 0.995, agree
+    assert float((pooled.cpu() - om).abs().mean()) < 2e-3
+    assert float((pooled_pf.reshape(B, -1).cpu() - ompf).abs().mean()) < 2e-3
