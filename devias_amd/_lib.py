@@ -46,6 +46,9 @@ PROTOTYPES = {
     "devias_version": (c_int, []),
     "devias_last_error": (c_char_p, []),
     "devias_device_info": (c_int, [c_int, POINTER(c_int64)]),
+    "devias_counter": (c_int64, [c_int32]),
+    "devias_counters_reset": (None, []),
+    "devias_set_option": (c_int, [c_char_p, c_int32]),
     "devias_gemm": (c_int, [POINTER(GemmArgs), _P]),
     "devias_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
     "devias_cast": (c_int, [_P, _I, _P, _I, _L, _P]),
@@ -80,6 +83,8 @@ PROTOTYPES = {
     "devias_fame_binarize_pool": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "devias_fame_mix": (c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
+COUNTERS = {"gemm128_f32": 0, "gemm128_bf16": 1, "gemm_ss": 2, "gemm256": 3, "gemm256p": 4, "splitk_reduce": 5,
+            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9}     # DEVIAS_CNT_*
 OPT_CHUNK = 16384          # DEVIAS_OPT_CHUNK
 OPT_TENSOR_BYTES = 64      # sizeof(devias_opt_tensor)
 

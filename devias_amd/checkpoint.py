@@ -75,6 +75,8 @@ def load_state_dict(model: torch.nn.Module, state_dict: dict, prefix: str = "", 
                 load(child, pfx + name + ".")
 
     load(model, prefix)
+    from .modeling_slot import invalidate_weight_cache
+    invalidate_weight_cache()          # belt and braces: copy_ under no_grad already moves Tensor._version
     warn = [k for k in missing if not any(ig in k for ig in ignore_missing.split("|"))]
     if warn:
         print("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, warn))

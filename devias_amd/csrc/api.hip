@@ -12,7 +12,20 @@ int devias_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int devias_version(void) { return 120; }   // 0.1.20: + multi-tensor optimizer entry points (110), + devias_fame_* (120)
+extern "C" int devias_version(void) { return 130; }   // 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options
+
+// ---- launch counters: which kernel family served a call (tests assert that the measured kernels are the ones under test) ----
+#include <atomic>
+static std::atomic<int64_t> g_cnt[DEVIAS_CNT_MAX];
+void devias_count(int id) { if (id >= 0 && id < DEVIAS_CNT_MAX) g_cnt[id].fetch_add(1, std::memory_order_relaxed); }
+extern "C" int64_t devias_counter(int32_t id) { return (id >= 0 && id < DEVIAS_CNT_MAX) ? g_cnt[id].load(std::memory_order_relaxed) : -1; }
+extern "C" void devias_counters_reset(void) { for (int i = 0; i < DEVIAS_CNT_MAX; ++i) g_cnt[i].store(0, std::memory_order_relaxed); }
+
+extern "C" int devias_set_option(const char* name, int32_t value) {
+    if (!name) return devias_set_error(DEVIAS_EINVAL, "devias_set_option: null name");
+    if (devias_gemm_set_option(name, value) || devias_attn_set_option(name, value)) return DEVIAS_OK;
+    return devias_set_error(DEVIAS_EINVAL, "devias_set_option: unknown option '%s'", name);
+}
 
 extern "C" const char* devias_last_error(void) { return g_err; }
 

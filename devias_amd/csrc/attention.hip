@@ -16,6 +16,8 @@
 //
 // qkv layout is [B, N, 3, H, 64] exactly as produced by the fused QKV GEMM; o / d_o are [B, N, H*64].
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -700,10 +702,29 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dkdv_f32_kernel(const float* __r
 
 }  // namespace
 
-// bit 0: XCD-aware linear grid (needs B*H % 8 == 0); bits 16..: B.  DEVIAS_ATTN_XCD=0 restores the plain 3-D grid.
+// process-wide options, read from the environment once; devias_set_option("attn_cfg" | "attn_xcd", v) changes them at run time
+namespace {
+struct AttnKnobs { int cfg, xcd; };
+AttnKnobs& attn_knobs() {
+    static AttnKnobs k = [] {
+        AttnKnobs x;
+        const char* e = getenv("DEVIAS_ATTN_CFG"); x.cfg = e ? atoi(e) : 0;
+        e = getenv("DEVIAS_ATTN_XCD"); x.xcd = e ? atoi(e) : 1;
+        return x;
+    }();
+    return k;
+}
+}  // namespace
+int devias_attn_set_option(const char* name, int value) {
+    if (!strcmp(name, "attn_cfg")) attn_knobs().cfg = value;
+    else if (!strcmp(name, "attn_xcd")) attn_knobs().xcd = value;
+    else return 0;
+    return 1;
+}
+
+// bit 0: XCD-aware linear grid (needs B*H % 8 == 0); bits 16..: B.  Option attn_xcd = 0 restores the plain 3-D grid.
 static int attn_xcd_flag(int B, int H) {
-    static const int on = [] { const char* e = getenv("DEVIAS_ATTN_XCD"); return e ? atoi(e) : 1; }();
-    return (B << 16) | ((on && ((B * H) % 8 == 0)) ? 1 : 0);
+    return (B << 16) | ((attn_knobs().xcd && ((B * H) % 8 == 0)) ? 1 : 0);
 }
 
 extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
@@ -714,8 +735,9 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
     DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_fwd: H and B must be <= 65535");
     if (dtype == DEVIAS_BF16)
         {
-        static const int cfg = [] { const char* e = getenv("DEVIAS_ATTN_CFG"); return e ? atoi(e) : 0; }();
+        const int cfg = attn_knobs().cfg;
         const int xcd = attn_xcd_flag(B, H);
+        devias_count(DEVIAS_CNT_MHSA_FWD_BF16);
 #define FWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
         if (cfg == 1) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 2, false>), FWD_GRID(128), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
         else if (cfg == 2) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 4, false>), FWD_GRID(256), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
@@ -725,9 +747,10 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
         else hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
 #undef FWD_GRID
     }
-    else if (dtype == DEVIAS_F32)
+    else if (dtype == DEVIAS_F32) {
+        devias_count(DEVIAS_CNT_MHSA_FWD_F32);
         hipLaunchKernelGGL(mhsa_fwd_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (float*)o, lse, N, H, scale);
-    else return devias_set_error(DEVIAS_EINVAL, "devias_mhsa_fwd: bad dtype %d", dtype);
+    } else return devias_set_error(DEVIAS_EINVAL, "devias_mhsa_fwd: bad dtype %d", dtype);
     DEVIAS_CHECK_LAUNCH("devias_mhsa_fwd");
     return DEVIAS_OK;
 }
@@ -739,8 +762,9 @@ extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, 
     DEVIAS_REQUIRE(aligned16(qkv) && aligned16(o) && aligned16(d_o) && aligned16(dqkv), "devias_mhsa_bwd: unaligned pointer");
     DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_bwd: H and B must be <= 65535");
     if (dtype == DEVIAS_BF16) {
-        static const int cfg = [] { const char* e = getenv("DEVIAS_ATTN_CFG"); return e ? atoi(e) : 0; }();
+        const int cfg = attn_knobs().cfg;
         const int xcd = attn_xcd_flag(B, H);
+        devias_count(DEVIAS_CNT_MHSA_BWD_BF16);
 #define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, xcd
 #define BWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
         if (cfg == 1) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 2>), BWD_GRID(128), dim3(128), 0, st, DQ_ARGS);
@@ -754,6 +778,7 @@ extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, 
 #undef BWD_GRID
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv)");
     } else if (dtype == DEVIAS_F32) {
+        devias_count(DEVIAS_CNT_MHSA_BWD_F32);
         hipLaunchKernelGGL(mhsa_bwd_dq_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)o,
                            (const float*)d_o, lse, delta, (float*)dqkv, N, H, scale);
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");

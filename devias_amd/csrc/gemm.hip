@@ -11,6 +11,7 @@
 // (8-byte bf16 / 16-byte f32 epilogue accesses, bias as one float4).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -30,8 +31,16 @@ struct GemmP {
     int group_m;          // tile rasterisation: GM row-tiles per group (m fastest inside a group); 1 = n fastest
     int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
     int epi_swap;         // 1 = register-transposed epilogue (epilogue_swap), 0 = LDS-staged (epilogue_staged)
-    int debug;            // timing ablations only (DEVIAS_GEMM_DEBUG): 1 = one K-tile, 2 = no epilogue stores, 4 = no LDS-DMA after tile 0
+    int debug;            // timing ablations, compiled in only with -DDEVIAS_GEMM_DEBUG (option "gemm_debug"): 1 = one K-tile, 2 = no epilogue,
+                          // 4 = no LDS-DMA after tile 0, 8 = s_memrealtime stamps into ws, 64 = epilogue without its global stores
+    int epi_vm;           // persistent kernel: VMEM operations every wave is guaranteed to issue in one epilogue (counted vmcnt)
 };
+
+#ifdef DEVIAS_GEMM_DEBUG
+#define GDBG(flag) (p.debug & (flag))
+#else
+#define GDBG(flag) 0
+#endif
 
 template <typename T> struct Tr;
 template <> struct Tr<bf16> {
@@ -247,7 +256,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
                 *reinterpret_cast<f32x4*>(C + 4) = o1;
             } else {
                 bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                if (!(p.debug & 64) || v[0] == 12345.678f)       // ablation: staging + math without the global stores
+                if (!GDBG(64) || v[0] == 12345.678f)       // ablation: staging + math without the global stores
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
             }
         }
@@ -382,7 +391,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                 *reinterpret_cast<f32x4*>(C + 4) = o1;
             } else {
                 bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                if (!(p.debug & 64) || v[0] == 12345.678f)
+                if (!GDBG(64) || v[0] == 12345.678f)
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
             }
         }
@@ -602,24 +611,35 @@ __device__ __forceinline__ int off_ks2(int k, int col) { return k * 512 + ((((co
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-// issue the 4 LDS-DMA instructions this wave owns for one 256 x 64 operand tile
+// issue the 4 LDS-DMA instructions this wave owns for one 256 x 64 operand tile.  Addressing: everything that varies per instruction
+// (tile origin, K-tile, piece index, wave) is wave-uniform and lives in a scalar base; the per-lane part is ONE 32-bit byte offset per
+// operand layout (two for the k-strided one) -> global_load_lds v_off, s[base] and no 64-bit per-lane pointers held across the K loop.
+__device__ __forceinline__ uint32_t glds_voff_kc(int ld, int lane) {       // 8 rows x 128 B per instruction; chunk XOR (row & 7)
+    return (uint32_t)(((lane >> 3) * ld + (((lane & 7) ^ ((lane >> 3) & 7)) * 8)) * 2);
+}
+__device__ __forceinline__ uint32_t glds_voff_ks(int ld, int lane, int kpar, int i) {   // 2 k-rows x 512 B per instruction; k = 8*wave + 2*i + (lane >> 5)
+    const int klo = (2 * i + (lane >> 5)) & 3;                  // k & 3
+    const int f = klo | (kpar << 2);                            // ks_f(k): (k & 3) | (((k >> 3) & 1) << 2), (k >> 3) & 1 == wave & 1
+    const int slot = lane & 31;
+    return (uint32_t)(((lane >> 5) * ld + ((((slot >> 1) ^ f)) << 4) + (slot & 1) * 8) * 2);
+}
 template <bool KSTRIDED>
 __device__ __forceinline__ void glds_tile(const bf16* __restrict__ ptr, int ld, int r0, int k0, char* lds, int wave, int lane) {
+    if constexpr (!KSTRIDED) {
+        const uint32_t vo = glds_voff_kc(ld, lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if constexpr (!KSTRIDED) {
+        for (int i = 0; i < 4; ++i) {
             const int r8 = wave * 32 + i * 8;                    // 8 rows x 128 B = 1 KiB per instruction
-            const int row = r8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ (row & 7);
-            const bf16* src = ptr + (int64_t)(r0 + row) * ld + k0 + chunk * 8;
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + r8 * 128), 16, 0, 0);
-        } else {
+            const char* ub = reinterpret_cast<const char*>(ptr + (int64_t)(r0 + r8) * ld + k0);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo), (lds_void_ptr)(lds + r8 * 128), 16, 0, 0);
+        }
+    } else {
+        const uint32_t vo0 = glds_voff_ks(ld, lane, wave & 1, 0), vo1 = glds_voff_ks(ld, lane, wave & 1, 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             const int k2 = wave * 8 + i * 2;                     // 2 k-rows x 512 B = 1 KiB per instruction
-            const int k = k2 + (lane >> 5);
-            const int slot = lane & 31;
-            const int col = (((slot >> 1) ^ ks_f(k)) << 4) + (slot & 1) * 8;
-            const bf16* src = ptr + (int64_t)(k0 + k) * ld + r0 + col;
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(lds + k2 * 512), 16, 0, 0);
+            const char* ub = reinterpret_cast<const char*>(ptr + (int64_t)(k0 + k2) * ld + r0);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + ((i & 1) ? vo1 : vo0)), (lds_void_ptr)(lds + k2 * 512), 16, 0, 0);
         }
     }
 }
@@ -685,6 +705,80 @@ __device__ __forceinline__ void plain_fence(bf16x8 (&f)[N]) {
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) :: "memory");
 }
 
+// ---- one K-tile (64 deep) of the 256 x 256 tile: 64 MFMAs per wave ---------------------------------------------------------------------
+// NT layout, order pinned by hand: 16 steps of 4 MFMAs (one A row-tile x 4 B column-tiles); the 8 LDS-DMA instructions of the NEXT K-tile
+// (source origins a_next / b_next = first row of the tile at the K-tile's first k; nullptr = nothing to load) go one per step over the
+// first 8 steps, fragment reads run two steps ahead of their use.
+__device__ __forceinline__ void ktile_nt_pinned(f32x4 (&acc)[8][4], const char* cur, char* nxt, const bf16* a_next, int lda,
+                                                const bf16* b_next, int ldb, int wave, int lane, int wm, int wn) {
+    const char* sA = cur; const char* sB = cur + 32768;
+    const uint32_t vo_a = glds_voff_kc(lda, lane), vo_b = glds_voff_kc(ldb, lane);
+    bf16x8 fb0[4], fb1[4], fa0[4], fa1[4];
+#define G_RA(ks, ih, i) read_frag2<false>(sA, wm * 128 + ((ih) * 4 + (i)) * 16, ks, lane)
+#define G_RB(ks, j) read_frag2<false>(sB, wn * 64 + (j) * 16, ks, lane)
+#define G_MM4(ih, i, fb, fa) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[(ih) * 4 + (i)][j] = mfma16(fb[j], fa[i], acc[(ih) * 4 + (i)][j]);
+#define G_SB __builtin_amdgcn_sched_barrier(0);
+#define G_DMA(n) { const int r8 = wave * 32 + ((n) & 3) * 8; \
+                   const char* ub = reinterpret_cast<const char*>((n) < 4 ? a_next + (int64_t)r8 * lda : b_next + (int64_t)r8 * ldb); \
+                   __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + ((n) < 4 ? vo_a : vo_b)), (lds_void_ptr)(nxt + ((n) < 4 ? 0 : 32768) + r8 * 128), 16, 0, 0); }
+    G_SB
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb0[j] = G_RB(0, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa0[i] = G_RA(0, 0, i);
+    G_SB
+    G_MM4(0, 0, fb0, fa0) G_DMA(0) fa1[0] = G_RA(0, 1, 0); fb1[0] = G_RB(1, 0); G_SB
+    G_MM4(0, 1, fb0, fa0) G_DMA(1) fa1[1] = G_RA(0, 1, 1); fb1[1] = G_RB(1, 1); G_SB
+    G_MM4(0, 2, fb0, fa0) G_DMA(2) fa1[2] = G_RA(0, 1, 2); fb1[2] = G_RB(1, 2); G_SB
+    G_MM4(0, 3, fb0, fa0) G_DMA(3) fa1[3] = G_RA(0, 1, 3); fb1[3] = G_RB(1, 3); G_SB
+    G_MM4(1, 0, fb0, fa1) G_DMA(4) fa0[0] = G_RA(1, 0, 0); G_SB
+    G_MM4(1, 1, fb0, fa1) G_DMA(5) fa0[1] = G_RA(1, 0, 1); G_SB
+    G_MM4(1, 2, fb0, fa1) G_DMA(6) fa0[2] = G_RA(1, 0, 2); G_SB
+    G_MM4(1, 3, fb0, fa1) G_DMA(7) fa0[3] = G_RA(1, 0, 3); G_SB
+    G_MM4(0, 0, fb1, fa0) fa1[0] = G_RA(1, 1, 0); G_SB
+    G_MM4(0, 1, fb1, fa0) fa1[1] = G_RA(1, 1, 1); G_SB
+    G_MM4(0, 2, fb1, fa0) fa1[2] = G_RA(1, 1, 2); G_SB
+    G_MM4(0, 3, fb1, fa0) fa1[3] = G_RA(1, 1, 3); G_SB
+    G_MM4(1, 0, fb1, fa1) G_SB
+    G_MM4(1, 1, fb1, fa1) G_SB
+    G_MM4(1, 2, fb1, fa1) G_SB
+    G_MM4(1, 3, fb1, fa1) G_SB
+#undef G_RA
+#undef G_RB
+#undef G_MM4
+#undef G_SB
+#undef G_DMA
+}
+
+// any layout, compiler-scheduled: fragments of one 32-deep k-step, then its 32 MFMAs; k-strided operands use the asm transposing reads
+template <bool TA, bool TB>
+__device__ __forceinline__ void ktile_generic(f32x4 (&acc)[8][4], const char* cur, int lane, int wm, int wn) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa[8], fb[4];
+        if constexpr (TA || TB) {
+            // plain (compiler-tracked) reads first, the asm transposing reads after them, then the waits; fragments are assembled
+            // only after their wait
+            TrFrag ta[TA ? 8 : 1], tb[TB ? 4 : 1];
+            if constexpr (!TB) { _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = read_frag2<false>(cur + 32768, wn * 64 + j * 16, ks, lane); }
+            if constexpr (!TA) { _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = read_frag2<false>(cur, wm * 128 + i * 16, ks, lane); }
+            if constexpr (TB) { _Pragma("unroll") for (int j = 0; j < 4; ++j) tb[j] = read_frag2a(cur + 32768, wn * 64 + j * 16, ks, lane); }
+            if constexpr (TA) { _Pragma("unroll") for (int i = 0; i < 8; ++i) ta[i] = read_frag2a(cur, wm * 128 + i * 16, ks, lane); }
+            if constexpr (TB) { tr_fence(tb); _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = tr_assemble(tb[j]); } else plain_fence(fb);
+            if constexpr (TA) { tr_fence(ta); _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = tr_assemble(ta[i]); } else plain_fence(fa);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag2<TB>(cur + 32768, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = read_frag2<TA>(cur, wm * 128 + i * 16, ks, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+    }
+}
+
 template <bool TA, bool TB, int PIN = 0>
 __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
@@ -700,12 +794,14 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     const int kbeg = z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     int nk = (kend - kbeg) / 64;
-    if (p.debug & 1) nk = min(nk, 1);
+    if (GDBG(1)) nk = min(nk, 1);
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
 
+#ifdef DEVIAS_GEMM_DEBUG
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
-    if (p.debug & 8) st0 = __builtin_amdgcn_s_memrealtime();
+    if (GDBG(8)) st0 = __builtin_amdgcn_s_memrealtime();
+#endif
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -717,96 +813,35 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
         glds_tile<TB>(B, p.ldb, n0, kbeg, smem + 32768, wave, lane);
     }
     for (int kt = 0; kt < nk; ++kt) {
-        if ((p.debug & 8) && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
+#ifdef DEVIAS_GEMM_DEBUG
+        if (GDBG(8) && kt == 0) st1 = __builtin_amdgcn_s_memrealtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA for tile kt has landed
         __syncthreads();
-        if ((p.debug & 8) && kt == 0) st2 = __builtin_amdgcn_s_memrealtime();
+#ifdef DEVIAS_GEMM_DEBUG
+        if (GDBG(8) && kt == 0) st2 = __builtin_amdgcn_s_memrealtime();
+#endif
         char* cur = smem + (kt & 1) * STAGE2;
+        char* nxt = smem + ((kt + 1) & 1) * STAGE2;
         if constexpr (!TA && !TB && PIN != 0) {
-            {
-                // experiment (DEVIAS_GEMM_DEBUG=128): the 8 LDS-DMA instructions of tile kt+1 spread over the first 8 of 16 four-MFMA
-                // steps, fragment reads two steps ahead of their use, order pinned step by step
-                char* nxt = smem + ((kt + 1) & 1) * STAGE2;
-                const int kn = kbeg + (kt + 1 < nk ? kt + 1 : kt) * 64;       // last tile: harmless re-read into the free stage
-                const char* sA = cur; const char* sB = cur + 32768;
-                bf16x8 fb0[4], fb1[4], fa0[4], fa1[4];
-#define G_RA(ks, ih, i) read_frag2<false>(sA, wm * 128 + ((ih) * 4 + (i)) * 16, ks, lane)
-#define G_RB(ks, j) read_frag2<false>(sB, wn * 64 + (j) * 16, ks, lane)
-#define G_MM4(ih, i, fb, fa) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[(ih) * 4 + (i)][j] = mfma16(fb[j], fa[i], acc[(ih) * 4 + (i)][j]);
-#define G_SB __builtin_amdgcn_sched_barrier(0);
-#define G_DMA(n) { const int r8 = wave * 32 + ((n) & 3) * 8; const int row = r8 + (lane >> 3); const int chunk = (lane & 7) ^ (row & 7); \
-                   const bf16* src = ((n) < 4 ? A + (int64_t)(m0 + row) * p.lda : B + (int64_t)(n0 + row) * p.ldb) + kn + chunk * 8; \
-                   __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(nxt + ((n) < 4 ? 0 : 32768) + r8 * 128), 16, 0, 0); }
-                G_SB
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fb0[j] = G_RB(0, j);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa0[i] = G_RA(0, 0, i);
-                G_SB
-                {
-                G_MM4(0, 0, fb0, fa0) G_DMA(0) fa1[0] = G_RA(0, 1, 0); fb1[0] = G_RB(1, 0); G_SB
-                G_MM4(0, 1, fb0, fa0) G_DMA(1) fa1[1] = G_RA(0, 1, 1); fb1[1] = G_RB(1, 1); G_SB
-                G_MM4(0, 2, fb0, fa0) G_DMA(2) fa1[2] = G_RA(0, 1, 2); fb1[2] = G_RB(1, 2); G_SB
-                G_MM4(0, 3, fb0, fa0) G_DMA(3) fa1[3] = G_RA(0, 1, 3); fb1[3] = G_RB(1, 3); G_SB
-                G_MM4(1, 0, fb0, fa1) G_DMA(4) fa0[0] = G_RA(1, 0, 0); G_SB
-                G_MM4(1, 1, fb0, fa1) G_DMA(5) fa0[1] = G_RA(1, 0, 1); G_SB
-                G_MM4(1, 2, fb0, fa1) G_DMA(6) fa0[2] = G_RA(1, 0, 2); G_SB
-                G_MM4(1, 3, fb0, fa1) G_DMA(7) fa0[3] = G_RA(1, 0, 3); G_SB
-                G_MM4(0, 0, fb1, fa0) fa1[0] = G_RA(1, 1, 0); G_SB
-                G_MM4(0, 1, fb1, fa0) fa1[1] = G_RA(1, 1, 1); G_SB
-                G_MM4(0, 2, fb1, fa0) fa1[2] = G_RA(1, 1, 2); G_SB
-                G_MM4(0, 3, fb1, fa0) fa1[3] = G_RA(1, 1, 3); G_SB
-                }
-                G_MM4(1, 0, fb1, fa1) G_SB
-                G_MM4(1, 1, fb1, fa1) G_SB
-                G_MM4(1, 2, fb1, fa1) G_SB
-                G_MM4(1, 3, fb1, fa1) G_SB
-#undef G_RA
-#undef G_RB
-#undef G_MM4
-#undef G_SB
-#undef G_DMA
-                continue;
+            const int kn = kbeg + (kt + 1 < nk ? kt + 1 : kt) * 64;       // last tile: harmless re-read into the free stage
+            ktile_nt_pinned(acc, cur, nxt, A + (int64_t)m0 * p.lda + kn, p.lda, B + (int64_t)n0 * p.ldb + kn, p.ldb, wave, lane, wm, wn);
+        } else {
+            if (kt + 1 < nk && !GDBG(4)) {
+                glds_tile<TA>(A, p.lda, m0, kbeg + (kt + 1) * 64, nxt, wave, lane);
+                glds_tile<TB>(B, p.ldb, n0, kbeg + (kt + 1) * 64, nxt + 32768, wave, lane);
             }
-        }
-        if (kt + 1 < nk && !(p.debug & 4)) {
-            char* nxt = smem + ((kt + 1) & 1) * STAGE2;
-            glds_tile<TA>(A, p.lda, m0, kbeg + (kt + 1) * 64, nxt, wave, lane);
-            glds_tile<TB>(B, p.ldb, n0, kbeg + (kt + 1) * 64, nxt + 32768, wave, lane);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[8], fb[4];
-            if constexpr (TA || TB) {
-                // plain (compiler-tracked) reads first, the asm transposing reads after them, then the waits; fragments are assembled
-                // only after their wait
-                TrFrag ta[TA ? 8 : 1], tb[TB ? 4 : 1];
-                if constexpr (!TB) { _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = read_frag2<false>(cur + 32768, wn * 64 + j * 16, ks, lane); }
-                if constexpr (!TA) { _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = read_frag2<false>(cur, wm * 128 + i * 16, ks, lane); }
-                if constexpr (TB) { _Pragma("unroll") for (int j = 0; j < 4; ++j) tb[j] = read_frag2a(cur + 32768, wn * 64 + j * 16, ks, lane); }
-                if constexpr (TA) { _Pragma("unroll") for (int i = 0; i < 8; ++i) ta[i] = read_frag2a(cur, wm * 128 + i * 16, ks, lane); }
-                if constexpr (TB) { tr_fence(tb); _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = tr_assemble(tb[j]); } else plain_fence(fb);
-                if constexpr (TA) { tr_fence(ta); _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = tr_assemble(ta[i]); } else plain_fence(fa);
-            } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = read_frag2<TB>(cur + 32768, wn * 64 + j * 16, ks, lane);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = read_frag2<TA>(cur, wm * 128 + i * 16, ks, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);
+            ktile_generic<TA, TB>(acc, cur, lane, wm, wn);
         }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     // The MFMA layout gives each lane 4 columns of 16 different rows: stored directly that is 16 partial 128-B lines per
-    // wave-instruction and the store path, not HBM, bounds the kernel (measured: 105 of 260 us on the QKV shape).  So the
-    // accumulators (+bias) go through LDS (the operand ring is dead by now: one 16 KiB fp32 region per wave, two passes of
-    // 64 rows) and every global access of the epilogue -- C, the saved pre-activation, the residual, aux_in, split-K slabs --
-    // is row-contiguous, 16 bytes per lane, whole 128-B lines.
-    if (p.debug & 8) {
+    // wave-instruction and the store path, not HBM, bounds the kernel (measured: 105 of 260 us on the QKV shape).  Default: the
+    // register-transposed epilogue (epilogue_swap); option gemm_epi = 0: through LDS (the operand ring is dead by now: one 16 KiB
+    // fp32 region per wave, two passes of 64 rows), every global access row-contiguous, 16 bytes per lane.
+#ifdef DEVIAS_GEMM_DEBUG
+    if (GDBG(8)) {
         st3 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
             unsigned long long* d = reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 6;
@@ -814,10 +849,101 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
             d[4] = __builtin_amdgcn_s_getreg(0x1800 | 20) /* HW_REG_XCC_ID */; d[5] = t;
         }
     }
-    if ((p.debug & 2) && acc[0][0][0] != 12345.678f) return;
+    if (GDBG(2) && acc[0][0][0] != 12345.678f) return;
+#endif
+    if constexpr (PIN != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing re-read must land before the LDS is released
     if (p.epi_swap) { epilogue_swap<8>(p, acc, m0 + wm * 128, n0 + wn * 64, z, lane); return; }
     __syncthreads();                                   // every wave is done reading the operand stages
     epilogue_staged<8, 4>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, z, lane);
+}
+
+
+// =====================================================================================================================
+// Persistent form of the 256 x 256 kernel (split_k == 1, A k-contiguous): one workgroup per CU walks a static list of tiles and the
+// K-tile stream of the 2-stage LDS-DMA ring runs ACROSS tile boundaries -- the first K-tile of the next tile is requested before the
+// last K-tile of the current one is multiplied, so its fetch (an HBM / L2 round trip that nothing hides in the one-tile-per-workgroup
+// kernel) lands under those MFMAs and the register-only epilogue (epilogue_swap).  The epilogue's stores are left in flight:
+// the wait at the top of the next tile's first K-tile is a COUNTED vmcnt that covers the LDS-DMA only (vmcnt is in issue order and
+// every wave issues >= p.epi_vm (16) stores after the DMA), so the output drains under the next tile's MFMAs.
+// Tile order: XCD x (block ids congruent to x mod 8) owns the same contiguous range of logical tiles as in xcd_remap; its G/8 workgroups
+// stride through it together, so at any moment an XCD works on ~32 consecutive tiles (operand panels shared in its L2).
+// =====================================================================================================================
+template <bool TB>
+__global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / 64;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    // this XCD-group's logical tile range and this workgroup's stride through it (gridDim.x is a multiple of 8)
+    const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int cnt = q + (xcd < r ? 1 : 0);
+    int li = blockIdx.x >> 3;
+    if (li >= cnt) return;
+    auto coords = [&](int l, int& m0, int& n0) {
+        int tm, tn;
+        tile_coords(base + l, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        m0 = tm * T2; n0 = tn * T2;
+    };
+    int m0, n0;
+    coords(li, m0, n0);
+    glds_tile<false>(A, p.lda, m0, 0, smem, wave, lane);
+    glds_tile<TB>(B, p.ldb, n0, 0, smem + 32768, wave, lane);
+    int ln = li + stride;
+    bool has_next = ln < cnt;
+    int m0n = m0, n0n = n0;
+    if (has_next) coords(ln, m0n, n0n);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ONE flat loop over the K-tile stream (ring stage = g & 1); the wait for K-tile g + 1 sits at the END of iteration g so that the loop has
+    // no first-iteration special case (a peeled copy is where the compiler re-inserts full vmcnt drains)
+    for (int g = 0, kt = 0;; ++g) {
+        __builtin_amdgcn_s_barrier();                      // K-tile g has landed for every wave, and everyone is done reading stage (g + 1) & 1
+        asm volatile("" ::: "memory");
+        char* cur = smem + (g & 1) * STAGE2;
+        char* nxt = smem + ((g + 1) & 1) * STAGE2;
+        // source of K-tile g + 1: this tile's next one, or the next tile's first; at the very end a harmless re-read
+        const bool same = kt + 1 < nk;
+        const int am = (same || !has_next) ? m0 : m0n, bn = (same || !has_next) ? n0 : n0n;
+        const int kn = same ? (kt + 1) * 64 : (has_next ? 0 : kt * 64);
+        if constexpr (!TB) {
+            ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane, wm, wn);
+        } else {
+            glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane);
+            glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane);
+            ktile_generic<false, true>(acc, cur, lane, wm, wn);
+        }
+        if (same) {
+            ++kt;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA for K-tile g + 1 has landed
+            continue;
+        }
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
+        epilogue_swap<8>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
+        if (!has_next) break;
+        // the epilogue issued >= 16 stores per wave AFTER the DMA of the next tile's first K-tile: wait for the DMA only, the stores drain under the next MFMAs
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        kt = 0;
+        li = ln; m0 = m0n; n0 = n0n;
+        ln = li + stride;
+        has_next = ln < cnt;
+        if (has_next) coords(ln, m0n, n0n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing re-read must land before the LDS is released
 }
 
 
@@ -926,295 +1052,6 @@ __global__ __launch_bounds__(SS_NT, OCC) void gemm_ss_kernel(GemmP p) {
 
 
 
-// =====================================================================================================================
-// Persistent 256 x 128 x 64 kernel: ONE workgroup of 4 waves per CU (one wave per SIMD, 512-register budget) walks a list of
-// output tiles.  What it removes is the per-tile prologue and the HBM-write-bound epilogue burst of the kernels above:
-//   * the operand ring (3 stages x 48 KiB, LDS-DMA, prefetch distance 2) runs CONTINUOUSLY across tile boundaries: the first
-//     K-tiles of tile i+1 are in flight while tile i finishes;
-//   * at the end of a tile the accumulators go through a private 4 KiB LDS region per wave (16 rows at a time), get their
-//     epilogue (bias, GELU / dGELU, row scale, residual; residual / aux_in rows were prefetched during the last K-tile), and
-//     are PARKED in registers as row-contiguous bf16 pieces (16 B per lane, whole 128-B lines);
-//   * the parked pieces are stored two per K-iteration during the NEXT tile's K loop, so the output leaves at the average
-//     rate of the GEMM (~1-2 TB/s), under the MFMAs, instead of in bursts while the matrix cores idle.
-// vmcnt is counted exactly (stores count on gfx950): at the top of K-iteration g only the operations issued after the loads
-// of K-tile g may be outstanding.  EPI is a compile-time epilogue shape (1 = aux_in, 2 = residual, 4 = aux_out) so that only the
-// register arrays a GEMM needs exist.
-// =====================================================================================================================
-enum { PK_BM = 256, PK_BN = 128, PK_NT = 256, PK_STAGE = 49152, PK_NSTAGE = 3, PK_SCRATCH = 4096, PK_LPW = 12 };
-
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// n is wave-uniform; only the counts this kernel produces exist as exact cases, anything else waits for everything
-__device__ __forceinline__ void wait_vm_dyn(int n) {
-    switch (n) {
-        case 12: wait_vm<12>(); break;
-        case 14: wait_vm<14>(); break;
-        case 16: wait_vm<16>(); break;
-        case 2: wait_vm<2>(); break;
-        case 4: wait_vm<4>(); break;
-        default: wait_vm<0>(); break;
-    }
-}
-
-template <bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(PK_NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_pk_kernel(GemmP p) {
-    constexpr bool HAS_AUXIN = (EPI & 1) != 0, HAS_RES = (EPI & 2) != 0, HAS_AUXOUT = (EPI & 4) != 0;
-    __shared__ __attribute__((aligned(16))) char smem[PK_NSTAGE * PK_STAGE + 4 * PK_SCRATCH];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int G = gridDim.x;
-    const int nk = p.K / 64;
-    const bf16* A = reinterpret_cast<const bf16*>(p.A);
-    const bf16* B = reinterpret_cast<const bf16*>(p.B);
-    bf16* Cb = reinterpret_cast<bf16*>(p.C);
-    bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
-    const bf16* aux_in = reinterpret_cast<const bf16*>(p.aux_in);
-    const bf16* res = reinterpret_cast<const bf16*>(p.res);
-    char* scratch = smem + PK_NSTAGE * PK_STAGE + wave * PK_SCRATCH;
-
-    auto coords = [&](int v, int& m0, int& n0) {
-        int tm, tn;
-        tile_coords(xcd_remap(v, ntiles), p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-        m0 = tm * PK_BM; n0 = tn * PK_BN;
-    };
-    // LDS-DMA addressing: per-lane byte offsets are constants of the kernel; everything that changes (tile origin, K-tile,
-    // instruction index) is wave-uniform and lives in the scalar base -> no vector ALU work per DMA instruction
-    const uint32_t vo_a = (uint32_t)(((lane >> 3) * p.lda + (((lane & 7) ^ ((lane >> 3) & 7)) * 8)) * 2);          // A: k contiguous
-    uint32_t vo_b[2];
-    if constexpr (!TB) {
-        vo_b[0] = vo_b[1] = (uint32_t)(((lane >> 3) * p.ldb + (((lane & 7) ^ ((lane >> 3) & 7)) * 8)) * 2);
-    } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                      // k-strided rows: 4 k-rows x 16 slots of 16 B per instruction
-            const int slot = lane & 15, f = (lane >> 4) | (h << 2);
-            vo_b[h] = (uint32_t)(((lane >> 4) * p.ldb + ((((slot >> 1) ^ f)) << 4) + (slot & 1) * 8) * 2);
-        }
-    }
-    // one LDS-DMA instruction (1 KiB) of the 12 this wave owns per K-tile: n < 8 -> A rows, else B
-    auto issue_one = [&](int n, int m0, int n0, int kt, int stage) {
-        char* s = smem + stage * PK_STAGE;
-        if (n < 8) {
-            const int r8 = (wave * 8 + n) * 8;
-            const char* ub = reinterpret_cast<const char*>(A + (int64_t)(m0 + r8) * p.lda + kt * 64);
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo_a), (lds_void_ptr)(s + r8 * 128), 16, 0, 0);
-        } else if constexpr (!TB) {
-            const int r8 = (wave * 4 + (n - 8)) * 8;
-            const char* ub = reinterpret_cast<const char*>(B + (int64_t)(n0 + r8) * p.ldb + kt * 64);
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo_b[0]), (lds_void_ptr)(s + 32768 + r8 * 128), 16, 0, 0);
-        } else {
-            const int kb = (wave * 4 + (n - 8)) * 4;
-            const char* ub = reinterpret_cast<const char*>(B + (int64_t)(kt * 64 + kb) * p.ldb + n0);
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo_b[((n - 8) >> 1) & 1]), (lds_void_ptr)(s + 32768 + kb * 256), 16, 0, 0);
-        }
-    };
-    auto issue = [&](int m0, int n0, int kt, int stage) {
-#pragma unroll
-        for (int n = 0; n < PK_LPW; ++n) issue_one(n, m0, n0, kt, stage);
-    };
-
-    int v = blockIdx.x;
-    int m0, n0, m0n = 0, n0n = 0;
-    coords(v, m0, n0);
-    bool has_next = v + G < ntiles;
-    if (has_next) coords(v + G, m0n, n0n);
-    issue(m0, n0, 0, 0);
-    issue(m0, n0, 1, 1);                                   // nk >= 2 (host)
-    int st = 0;                                            // ring stage of the current K-tile
-    int pend = PK_LPW;                                     // operations issued after the loads of the current K-tile
-    bool parked = false;
-    int pm = 0, pn = 0;                                    // origin of this wave's parked 128 x 64 block
-    u32x4 park[16], park2[HAS_AUXOUT ? 16 : 1];
-    const int rr = lane >> 3, cl = (lane & 7) * 8;         // piece geometry: row inside an 8-row group, first of 8 columns
-
-#define PK_STORE(q)                                                                                                      \
-    {                                                                                                                    \
-        const int row_ = ((q) >> 1) * 16 + ((q) & 1) * 8 + rr;                                                           \
-        *reinterpret_cast<u32x4*>(Cb + (int64_t)(pm + row_) * p.ldc + pn + cl) = park[q];                                \
-        if constexpr (HAS_AUXOUT) *reinterpret_cast<u32x4*>(aux_out + (int64_t)(pm + row_) * p.ld_aux + pn + cl) = park2[q]; \
-    }
-#define PK_STORE_STEP(i) case i: PK_STORE(2 * i) PK_STORE(2 * i + 1) break;
-#define PK_STORE_SWITCH(i) switch (i) { PK_STORE_STEP(0) PK_STORE_STEP(1) PK_STORE_STEP(2) PK_STORE_STEP(3) PK_STORE_STEP(4) PK_STORE_STEP(5) PK_STORE_STEP(6) PK_STORE_STEP(7) default: break; }
-    constexpr int NS_STEP = HAS_AUXOUT ? 4 : 2;            // store instructions per store step
-
-    for (;;) {
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 pre_aux[HAS_AUXIN ? 16 : 1], pre_res[HAS_RES ? 16 : 1];
-        f32x4 bias4[4];
-        const int mrow0 = m0 + wm * 128, ncol0 = n0 + wn * 64;
-
-        for (int kt = 0; kt < nk; ++kt) {
-            wait_vm_dyn(pend);                             // this wave's LDS-DMA for the current K-tile has landed
-            __builtin_amdgcn_s_barrier();                  // ... everyone's has, and stage (st + 2) % 3 is free again
-            int ns = 0;
-            if (parked && kt < 8) { PK_STORE_SWITCH(kt) ns = NS_STEP; }
-            // K-tile g + 2 of the continuous stream: this tile's, or the next tile's first ones; when nothing is left the (free)
-            // stage is filled with a harmless re-read so that the loop body stays one basic block for the scheduler
-            const int k2 = kt + 2;
-            int s2 = st + 2; if (s2 >= PK_NSTAGE) s2 -= PK_NSTAGE;
-            const bool same = k2 < nk;
-            const int lm0 = (same || !has_next) ? m0 : m0n, ln0 = (same || !has_next) ? n0 : n0n;
-            const int lk = same ? k2 : (has_next ? k2 - nk : 0);
-            pend = ns + PK_LPW;
-            if (kt == nk - 1) {                            // what the epilogue will read: fetch it under the last MFMAs
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 16 + (lane >> 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias) pend = 99;
-                if constexpr (HAS_AUXIN) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        pre_aux[q] = *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)(mrow0 + (q >> 1) * 16 + (q & 1) * 8 + rr) * p.ld_aux + ncol0 + cl);
-                    pend = 99;
-                }
-                if constexpr (HAS_RES) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int m = mrow0 + (q >> 1) * 16 + (q & 1) * 8 + rr;
-                        const int mr = p.res_mod > 0 ? m % p.res_mod : m;
-                        pre_res[q] = *reinterpret_cast<const bf16x8*>(res + (int64_t)mr * p.ldr + ncol0 + cl);
-                    }
-                    pend = 99;
-                }
-            }
-            const char* sA = smem + st * PK_STAGE;
-            const char* sB = sA + 32768;
-            // 64 MFMAs in 16 steps of 4 (one A row-tile x 4 B column-tiles); each step also issues one of the 12 LDS-DMA
-            // instructions of K-tile g + 2 and the LDS reads of fragments needed two phases later.  The order is pinned step
-            // by step: with one wave per SIMD nothing else hides DMA issue or LDS latency.
-            bf16x8 fb0[4], fb1[4], fa0[4], fa1[4], fa2[4], fa3[4];
-#define PK_RA(ks, ih, i) read_frag_ss<TA, PK_BM>(sA, wm * 128 + ((ih) * 4 + (i)) * 16, ks, lane)
-#define PK_RB(ks, j) read_frag_ss<TB, PK_BN>(sB, wn * 64 + (j) * 16, ks, lane)
-#define PK_MM4(ih, i, fb, fa) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[(ih) * 4 + (i)][j] = mfma16(fb[j], fa[i], acc[(ih) * 4 + (i)][j]);
-#define PK_SB __builtin_amdgcn_sched_barrier(0);
-#define PK_DMA(n) issue_one(n, lm0, ln0, lk, s2);
-            PK_SB
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb0[j] = PK_RB(0, j);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa0[i] = PK_RA(0, 0, i);
-            PK_SB
-            PK_MM4(0, 0, fb0, fa0) PK_DMA(0) fa1[0] = PK_RA(0, 1, 0); fb1[0] = PK_RB(1, 0); PK_SB
-            PK_MM4(0, 1, fb0, fa0) PK_DMA(1) fa1[1] = PK_RA(0, 1, 1); fb1[1] = PK_RB(1, 1); PK_SB
-            PK_MM4(0, 2, fb0, fa0) PK_DMA(2) fa1[2] = PK_RA(0, 1, 2); fb1[2] = PK_RB(1, 2); PK_SB
-            PK_MM4(0, 3, fb0, fa0) PK_DMA(3) fa1[3] = PK_RA(0, 1, 3); fb1[3] = PK_RB(1, 3); PK_SB
-            PK_MM4(1, 0, fb0, fa1) PK_DMA(4) fa2[0] = PK_RA(1, 0, 0); PK_SB
-            PK_MM4(1, 1, fb0, fa1) PK_DMA(5) fa2[1] = PK_RA(1, 0, 1); PK_SB
-            PK_MM4(1, 2, fb0, fa1) PK_DMA(6) fa2[2] = PK_RA(1, 0, 2); PK_SB
-            PK_MM4(1, 3, fb0, fa1) PK_DMA(7) fa2[3] = PK_RA(1, 0, 3); PK_SB
-            PK_MM4(0, 0, fb1, fa2) PK_DMA(8) fa3[0] = PK_RA(1, 1, 0); PK_SB
-            PK_MM4(0, 1, fb1, fa2) PK_DMA(9) fa3[1] = PK_RA(1, 1, 1); PK_SB
-            PK_MM4(0, 2, fb1, fa2) PK_DMA(10) fa3[2] = PK_RA(1, 1, 2); PK_SB
-            PK_MM4(0, 3, fb1, fa2) PK_DMA(11) fa3[3] = PK_RA(1, 1, 3); PK_SB
-            PK_MM4(1, 0, fb1, fa3) PK_SB
-            PK_MM4(1, 1, fb1, fa3) PK_SB
-            PK_MM4(1, 2, fb1, fa3) PK_SB
-            PK_MM4(1, 3, fb1, fa3) PK_SB
-#undef PK_RA
-#undef PK_RB
-#undef PK_MM4
-#undef PK_SB
-#undef PK_DMA
-            if (++st == PK_NSTAGE) st = 0;
-        }
-
-        // ---- tile end: pieces the K loop was too short to store, then epilogue + park ---------------------------------
-        if (parked && nk < 8) {
-            for (int i = nk; i < 8; ++i) { PK_STORE_SWITCH(i) }
-            pend = 99;
-        }
-        if (!(p.debug & 32) || acc[0][0][0] == 12345.678f) {
-            const int lm = lane & 15, g = lane >> 4;
-            float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const int c0 = (lane & 7) * 2;
-#pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<f32x4*>(scratch + lm * 256 + (((4 * j + g) ^ lm) << 4)) = acc[pass][j] + bias4[j];
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int q = pass * 2 + it;
-                    const int row = it * 8 + rr;
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(scratch + row * 256 + ((c0 ^ (row & 15)) << 4));
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(scratch + row * 256 + (((c0 + 1) ^ (row & 15)) << 4));
-                    float vv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    const int m = mrow0 + pass * 16 + row;
-                    if constexpr (HAS_AUXOUT) {
-                        const bf16x8 pre = {(bf16)vv[0], (bf16)vv[1], (bf16)vv[2], (bf16)vv[3], (bf16)vv[4], (bf16)vv[5], (bf16)vv[6], (bf16)vv[7]};
-                        park2[q] = *reinterpret_cast<const u32x4*>(&pre);
-                    }
-                    if (p.act == DEVIAS_ACT_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; e += 2) {
-                            const f32x2 y = gelu_fast2(f32x2{vv[e], vv[e + 1]});
-                            vv[e] = y[0]; vv[e + 1] = y[1];
-                        }
-                    }
-                    if constexpr (HAS_AUXIN) {
-                        const bf16x8 a8 = pre_aux[q];
-                        if (p.act == DEVIAS_ACT_DGELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; e += 2) {
-                                const f32x2 d = dgelu_fast2(f32x2{(float)a8[e], (float)a8[e + 1]});
-                                vv[e] *= d[0]; vv[e + 1] *= d[1];
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) vv[e] = (float)a8[e] > 0.f ? vv[e] : 0.f;
-                        }
-                    }
-                    if (p.row_scale) {
-                        const float rs = p.row_scale[m / p.rows_per_scale];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) vv[e] *= rs;
-                        pend = 99;
-                    }
-                    if constexpr (HAS_RES) {
-                        const bf16x8 r8 = pre_res[q];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) vv[e] += (float)r8[e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) cs[e] += vv[e];
-                    const bf16x8 o = {(bf16)vv[0], (bf16)vv[1], (bf16)vv[2], (bf16)vv[3], (bf16)vv[4], (bf16)vv[5], (bf16)vv[6], (bf16)vv[7]};
-                    park[q] = *reinterpret_cast<const u32x4*>(&o);
-                }
-            }
-            if (p.colsum_part) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    cs[e] += __shfl_xor(cs[e], 8, 64);
-                    cs[e] += __shfl_xor(cs[e], 16, 64);
-                    cs[e] += __shfl_xor(cs[e], 32, 64);
-                }
-                if (lane < 8) {
-                    float* dst = p.colsum_part + (int64_t)(mrow0 / 128) * p.N + ncol0 + cl;
-                    *reinterpret_cast<f32x4*>(dst) = f32x4{cs[0], cs[1], cs[2], cs[3]};
-                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
-                }
-                pend = 99;
-            }
-        }
-        parked = true; pm = mrow0; pn = ncol0;
-        if (!has_next) break;
-        v += G; m0 = m0n; n0 = n0n;
-        has_next = v + G < ntiles;
-        if (has_next) coords(v + G, m0n, n0n);
-    }
-    wait_vm<0>();                                          // the trailing (unused) LDS-DMA must land before the LDS is released
-#pragma unroll
-    for (int q = 0; q < 16; ++q) PK_STORE(q)
-#undef PK_STORE
-#undef PK_STORE_STEP
-#undef PK_STORE_SWITCH
-}
-
-
 // C[i] = epilogue(sum_s ws[s][i])   (fixed summation order -> bitwise reproducible); the full fused epilogue is available
 // here too so that small-M, long-K GEMMs (the B*S = 64-row slot MLPs) can be split along K to fill the chip
 template <typename T>
@@ -1289,6 +1126,49 @@ extern "C" int64_t devias_gemm_workspace_bytes(int32_t M, int32_t N, int32_t spl
     return split_k > 1 ? (int64_t)split_k * M * N * 4 : 0;
 }
 
+// ---- process-wide options: read from the environment ONCE, changeable at run time through devias_set_option (tests, A/B tools) --------
+namespace {
+struct GemmKnobs {
+    int epi_swap;      // "gemm_epi"        DEVIAS_GEMM_EPI      1 = register-transposed epilogue (default), 0 = LDS-staged
+    int use256;        // "gemm256"         DEVIAS_GEMM256       0 disables the 256x256 kernels
+    int use_ss;        // "gemm_ss"         DEVIAS_GEMM_SS       -1 = measured policy, 0 = never, 1 = prefer the single-stage 256x128 kernel for k-strided layouts
+    int group_m;       // "gemm_groupm"     DEVIAS_GEMM_GROUPM   0 = measured policy, > 0 forces the rasterisation group height
+    int persistent;    // "gemm_persistent" DEVIAS_GEMM_PERSIST  1 = persistent 256x256 kernel where it applies (default), 0 = one tile per workgroup
+    int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
+    int ncu;
+};
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+GemmKnobs& knobs() {
+    static GemmKnobs k = [] {
+        GemmKnobs x;
+        x.epi_swap = env_int("DEVIAS_GEMM_EPI", 1);
+        x.use256 = env_int("DEVIAS_GEMM256", 1);
+        x.use_ss = env_int("DEVIAS_GEMM_SS", -1);
+        x.group_m = env_int("DEVIAS_GEMM_GROUPM", 0);
+        x.persistent = env_int("DEVIAS_GEMM_PERSIST", 1);
+        x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        x.ncu = n;
+        return x;
+    }();
+    return k;
+}
+}  // namespace
+
+int devias_gemm_set_option(const char* name, int value) {
+    GemmKnobs& k = knobs();
+    if (!strcmp(name, "gemm_epi")) k.epi_swap = value;
+    else if (!strcmp(name, "gemm256")) k.use256 = value;
+    else if (!strcmp(name, "gemm_ss")) k.use_ss = value;
+    else if (!strcmp(name, "gemm_groupm")) k.group_m = value;
+    else if (!strcmp(name, "gemm_persistent")) k.persistent = value;
+    else if (!strcmp(name, "gemm_debug")) k.debug = value;
+    else return 0;
+    return 1;
+}
+
 extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     DEVIAS_REQUIRE(a && a->A && a->B && a->C, "devias_gemm: null operand");
@@ -1297,6 +1177,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     DEVIAS_REQUIRE(a->act >= 0 && a->act <= DEVIAS_ACT_DRELU, "devias_gemm: bad act %d", a->act);
     if (a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU)
         DEVIAS_REQUIRE(a->aux_in, "devias_gemm: act %d needs aux_in", a->act);
+    const GemmKnobs& kn = knobs();
     const int es = a->dtype == DEVIAS_BF16 ? 2 : 4;
     const int ch = 16 / es;
     GemmP p;
@@ -1333,39 +1214,33 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     if (es == 4) vc = vc && (!a->res || aligned16(a->res)) && (!a->aux_in || aligned16(a->aux_in)) &&
                       (!a->aux_out || aligned16(a->aux_out)) && aligned16(a->C);
     p.vec_c = vc ? 1 : 0;
-    { const char* e = getenv("DEVIAS_GEMM_DEBUG"); p.debug = e ? atoi(e) : 0; }
-    { const char* e = getenv("DEVIAS_GEMM_EPI"); p.epi_swap = e ? atoi(e) : 1; }       // read per call: tests compare both epilogues
-    {   // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
-        // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
-        static const int gm = [] { const char* e = getenv("DEVIAS_GEMM_GROUPM"); return e ? atoi(e) : 0; }();
-        p.group_m = gm > 0 ? gm : ((!a->trans_a && a->N >= 2048) ? 8 : 1);
-    }
-    { static const int nt = [] { const char* e = getenv("DEVIAS_GEMM_NTA"); return e ? atoi(e) : 0; }(); p.nt_a = nt; }
+    p.debug = kn.debug;
+    p.epi_swap = kn.epi_swap;
+    p.epi_vm = 16;
+    p.nt_a = 0;
+    // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
+    // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
+    p.group_m = kn.group_m > 0 ? kn.group_m : ((!a->trans_a && a->N >= 2048) ? 8 : 1);
 
-    static const int use256 = [] { const char* e = getenv("DEVIAS_GEMM256"); return e ? atoi(e) : 1; }();
     // 16 bytes per lane in the staged epilogue (8 bf16 / 2 x 4 fp32): leading dims % 8 and 16-byte aligned bases
     const bool v16 = vc && (a->N % 8 == 0) && (a->ldc % 8 == 0) && aligned16(a->C) && (!a->bias || aligned16(a->bias)) &&
                      (!a->res || ((a->ldr % 8 == 0) && aligned16(a->res))) &&
                      (!a->aux_in || ((a->ld_aux % 8 == 0) && aligned16(a->aux_in))) &&
                      (!a->aux_out || ((a->ld_aux % 8 == 0) && aligned16(a->aux_out))) && (split == 1 || aligned16(a->ws));
     p.vec16 = (v16 && a->dtype == DEVIAS_BF16) ? 1 : 0;
-    bool big = use256 && a->dtype == DEVIAS_BF16 && vec && vc && (a->M % T2 == 0) && (a->N % T2 == 0) && (a->K % 64 == 0) &&
+    bool big = kn.use256 && a->dtype == DEVIAS_BF16 && vec && vc && (a->M % T2 == 0) && (a->N % T2 == 0) && (a->K % 64 == 0) &&
                (p.k_per_split % 64 == 0);
     big = big && v16;
     // Kernel choice, measured on MI355X at the ViT-B shapes (M = 50176; tools/gemm_block_shapes.py, tools/ab_bench.py):
-    //   * 256x256 two-stage LDS-DMA kernel (1 workgroup/CU): every shape it can tile, all four operand layouts.  (Its k-strided layouts
-    //     were slower than the single-stage kernel until their transposing LDS reads moved to inline asm: the compiler fenced the
-    //     builtin with vmcnt(0), i.e. waited for the NEXT K-tile's DMA, which made the ring single-stage.  After: dgrad/wgrad 5-12 %
-    //     faster than the single-stage kernel, step +2.4 %.)
+    //   * 256x256 two-stage LDS-DMA kernel (1 workgroup/CU): every shape it can tile, all four operand layouts; its persistent form
+    //     (gemm256p_kernel) when there is more than one round of tiles, no split-K and a bf16 output (forward and dgrad GEMMs);
     //   * 256x128 single-stage kernel (2 workgroups/CU): N a multiple of 128 but not of 256;
     //   * 128x128 register-staged kernel: ragged / unaligned / fp32 shapes.
-    // DEVIAS_GEMM_SS = 0 disables / 1 prefers the single-stage kernel (the round-1 policy for dgrad/wgrad); DEVIAS_GEMM256 = 0 disables the 256^2 kernel.
-    static const int use_ss = [] { const char* e = getenv("DEVIAS_GEMM_SS"); return e ? atoi(e) : -1; }();
-    bool ss = use_ss != 0 && a->dtype == DEVIAS_BF16 && vec && v16 && (a->M % SS_BM == 0) && (a->N % SS_BN == 0) && (a->K % 64 == 0) &&
+    bool ss = kn.use_ss != 0 && a->dtype == DEVIAS_BF16 && vec && v16 && (a->M % SS_BM == 0) && (a->N % SS_BN == 0) && (a->K % 64 == 0) &&
               (p.k_per_split % 64 == 0);
     if (ss && big) {
         const bool nt = !a->trans_a && !a->trans_b;
-        if (use_ss < 0 || nt) ss = false;
+        if (kn.use_ss < 0 || nt) ss = false;
     }
     bool colsum_fused = false;
     if (a->colsum) {
@@ -1373,57 +1248,41 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
                        "devias_gemm: colsum needs split_k == 1, a workspace (M/128 * N floats) and a T-typed C");
         if (ss || big) { p.colsum_part = a->ws; colsum_fused = true; }      // the full-tile kernels fold it into their epilogue
     }
-    // persistent 256x128 kernel (continuous 3-stage operand ring, deferred stores).  Measured (tools/gemm_block_shapes.py, M = 50176):
-    // it wins where the operand stream is HBM-latency bound and the K loop is long -- NT, K >= 2048, narrow N (fc2 forward:
-    // 288 vs 317 us) -- and loses elsewhere (one wave per SIMD cannot hide LDS-DMA issue and LDS latency behind a second wave:
-    // qkv 273 vs 232 us, every k-strided-B shape).  DEVIAS_GEMM_PK: unset = that measured policy, 0 = never, 1 = wherever the
-    // single-stage kernel would run, 2 = also where the 256^2 kernel would run.
-    const int use_pk = [] { const char* e = getenv("DEVIAS_GEMM_PK"); return e ? atoi(e) : -1; }();   // read per call: tests toggle it
-    int epi = (a->aux_in ? 1 : 0) | (a->res ? 2 : 0) | (a->aux_out ? 4 : 0);
-    bool pk = use_pk != 0 && (ss || (use_pk >= 2 && big)) && !a->trans_a && split == 1 && !p.c_f32 && a->beta == 0.f && a->K >= 128 &&
-              (a->M % PK_BM == 0) && (a->N % PK_BN == 0) && (epi == 0 || epi == 1 || epi == 2 || epi == 4) &&
-              (a->act == DEVIAS_ACT_NONE || (a->act == DEVIAS_ACT_GELU && epi == 4) || ((a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU) && epi == 1)) &&
-              (int64_t)(a->M / PK_BM) * (a->N / PK_BN) >= 256;
-    if (use_pk < 0) pk = false;    // measured policy: never by default (see the note above; the 256^2 kernel with the register-transposed epilogue took its one win)
-    if (pk) {
-        if (a->colsum) { p.colsum_part = a->ws; colsum_fused = true; }
-        p.tiles_m = a->M / PK_BM; p.tiles_n = a->N / PK_BN;
-        static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        int nt = p.tiles_m * p.tiles_n;
-        int g = nt < ncu ? nt : ncu;
-        g &= ~7; if (g < 8) g = nt < 8 ? nt : 8;            // the XCD remap wants a multiple of 8 workgroups
-        dim3 grid(g), block(PK_NT);
-        const int tb = a->trans_b;
-#define PK_LAUNCH(TB_, E_) hipLaunchKernelGGL((gemm_pk_kernel<false, TB_, E_>), grid, block, 0, st, p)
-        if (!tb) { if (epi == 0) PK_LAUNCH(false, 0); else if (epi == 2) PK_LAUNCH(false, 2); else if (epi == 4) PK_LAUNCH(false, 4); else PK_LAUNCH(false, 1); }
-        else { if (epi == 0) PK_LAUNCH(true, 0); else if (epi == 2) PK_LAUNCH(true, 2); else if (epi == 4) PK_LAUNCH(true, 4); else PK_LAUNCH(true, 1); }
-#undef PK_LAUNCH
-    } else if (ss) {
+    if (ss) {
         p.tiles_m = a->M / SS_BM; p.tiles_n = a->N / SS_BN;
         dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(SS_NT);
         const int ta = a->trans_a, tb = a->trans_b;
-#define SS_LAUNCH(OCC)                                                                                      \
-        if (!ta && !tb) hipLaunchKernelGGL((gemm_ss_kernel<false, false, OCC>), grid, block, 0, st, p);     \
-        else if (!ta && tb) hipLaunchKernelGGL((gemm_ss_kernel<false, true, OCC>), grid, block, 0, st, p);  \
-        else if (ta && tb) hipLaunchKernelGGL((gemm_ss_kernel<true, true, OCC>), grid, block, 0, st, p);    \
-        else hipLaunchKernelGGL((gemm_ss_kernel<true, false, OCC>), grid, block, 0, st, p)
-        SS_LAUNCH(2);
-#undef SS_LAUNCH
+        if (!ta && !tb) hipLaunchKernelGGL((gemm_ss_kernel<false, false, 2>), grid, block, 0, st, p);
+        else if (!ta && tb) hipLaunchKernelGGL((gemm_ss_kernel<false, true, 2>), grid, block, 0, st, p);
+        else if (ta && tb) hipLaunchKernelGGL((gemm_ss_kernel<true, true, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_ss_kernel<true, false, 2>), grid, block, 0, st, p);
+        devias_count(DEVIAS_CNT_GEMM_SS);
     } else if (big) {
         p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;
-        dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(NT2);
         const int ta = a->trans_a, tb = a->trans_b;
-        if (!ta && !tb && !(p.debug & 512)) hipLaunchKernelGGL((gemm256_kernel<false, false, 1>), grid, block, 0, st, p);
-        else if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<false, false>), grid, block, 0, st, p);
-        else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, block, 0, st, p);
-        else if (ta && tb) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, block, 0, st, p);
+        const int nt = p.tiles_m * p.tiles_n;
+        const int gp = kn.ncu & ~7;
+        if (kn.persistent && !ta && split == 1 && !p.c_f32 && p.epi_swap && gp >= 8 && nt > gp) {
+            dim3 grid(gp), block(NT2);
+            if (!tb) hipLaunchKernelGGL((gemm256p_kernel<false>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((gemm256p_kernel<true>), grid, block, 0, st, p);
+            devias_count(DEVIAS_CNT_GEMM256P);
+        } else {
+            dim3 grid(nt, p.split_k), block(NT2);
+            if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<false, false, 1>), grid, block, 0, st, p);
+            else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, block, 0, st, p);
+            else if (ta && tb) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((gemm256_kernel<true, false>), grid, block, 0, st, p);
+            devias_count(DEVIAS_CNT_GEMM256);
+        }
     } else if (a->dtype == DEVIAS_BF16) {
         if (vec) launch<bf16, true>(p, a->trans_a, a->trans_b, st);
         else launch<bf16, false>(p, a->trans_a, a->trans_b, st);
+        devias_count(DEVIAS_CNT_GEMM128_BF16);
     } else {
         if (vec) launch<float, true>(p, a->trans_a, a->trans_b, st);
         else launch<float, false>(p, a->trans_a, a->trans_b, st);
+        devias_count(DEVIAS_CNT_GEMM128_F32);
     }
     DEVIAS_CHECK_LAUNCH("devias_gemm");
     if (a->colsum) {
@@ -1445,6 +1304,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
             hipLaunchKernelGGL(splitk_reduce_plain_kernel, dim3(b4), dim3(256), 0, st, a->ws, split, total / 4, reinterpret_cast<float*>(a->C), a->beta);
         } else if (a->dtype == DEVIAS_BF16) hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3(blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
+        devias_count(DEVIAS_CNT_SPLITK_REDUCE);
         DEVIAS_CHECK_LAUNCH("devias_gemm(split-k reduce)");
     }
     return DEVIAS_OK;

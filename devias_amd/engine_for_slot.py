@@ -62,6 +62,9 @@ def train_one_epoch(model, scene_model, train_criterion, data_loader: Iterable, 
         loss, output, loss_dict = train_class_batch(model, teacher, samples, targets, train_criterion, fg_mask=masks)
         if update_freq > 1:
             loss = loss / update_freq
+        if grad_sync is not None:
+            # gradient accumulation: only the LAST micro-batch of a window starts the bucket all-reduces (earlier ones just accumulate)
+            grad_sync.set_accumulate((data_iter_step + 1) % update_freq != 0)
         loss.backward()
         if (data_iter_step + 1) % update_freq == 0:
             if grad_sync is not None:

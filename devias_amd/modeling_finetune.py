@@ -100,17 +100,15 @@ class VisionTransformer(nn.Module):
         hv[:, 0] = cls
         hv[:, 1:] = tok.view(B, N, D)
         scale = 64 ** -0.5
+        # attention output buffer, padded like h: allocated ONCE, mhsa_fwd writes its first M rows in place every block and the pad rows
+        # stay zero (no per-block zeros() + slice copy)
+        o = torch.zeros((Mp, D), dtype=cdt, device=x.device) if Mp != M else torch.empty((M, D), dtype=cdt, device=x.device)
         for blk in self.blocks:
             a = blk.attn
             Wqkv, Wp, W1, W2 = (_WCACHE.get(w, cdt) for w in (a.qkv.weight, a.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight))
             u, _, _ = ops.layernorm_fwd(h, _f32(blk.norm1.weight), _f32(blk.norm1.bias), blk.norm1.eps)
             qkv = ops.gemm(u, Wqkv, bias=torch.cat((_f32(a.q_bias), torch.zeros_like(_f32(a.v_bias)), _f32(a.v_bias))))
-            o = torch.zeros((Mp, D), dtype=cdt, device=x.device) if Mp != M else None
-            oo, _ = ops.mhsa_fwd(qkv[:M], B, Nt, a.num_heads, scale)
-            if o is None:
-                o = oo
-            else:
-                o[:M] = oo
+            ops.mhsa_fwd(qkv[:M], B, Nt, a.num_heads, scale, out=o[:M])
             h1 = ops.gemm(o, Wp, bias=_f32(a.proj.bias), res=h)
             u2, _, _ = ops.layernorm_fwd(h1, _f32(blk.norm2.weight), _f32(blk.norm2.bias), blk.norm2.eps)
             act = ops.gemm(u2, W1, bias=_f32(blk.mlp.fc1.bias), act=ACT_GELU)

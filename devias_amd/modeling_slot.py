@@ -67,11 +67,51 @@ def get_sinusoid_encoding_table(n_position: int, d_hid: int) -> torch.Tensor:
 
 
 # =====================================================================================================
-# compute-dtype weight copies (bf16 mode): one cast per parameter per optimizer step, keyed on Tensor._version
+# compute-dtype weight copies (bf16 mode): one cast per parameter per WEIGHT UPDATE
 # =====================================================================================================
+# A copy is valid while (weights epoch, Tensor._version, storage address, device) are unchanged.  `_version` catches every in-place
+# update made through autograd-visible tensors (torch optimizers, load_state_dict, EMA copy_); updates made behind autograd's back --
+# the fused optimizer writes parameters through raw pointers in the C ABI, and `.data` writes such as broadcast_parameters -- do not
+# bump it, so those call invalidate_weight_cache(), which advances the global epoch.  Entries are keyed on the Parameter OBJECT
+# through a WeakKeyDictionary: they die with their model, and an id()/address reused by a later model cannot hit them.
+import weakref
+
+_WEIGHTS_EPOCH = [0]
+
+
+def invalidate_weight_cache() -> None:
+    """Call after changing parameter VALUES in a way `Tensor._version` cannot see (raw-pointer kernels, `.data` writes)."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
+class _WeakIdDict:
+    """object -> value, keyed on IDENTITY and holding the key weakly (WeakKeyDictionary compares keys with ==, which is elementwise for
+    tensors).  An entry disappears when its key object dies, so a recycled id() can never alias it."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, obj, default=None):
+        e = self._d.get(id(obj))
+        return e[1] if e is not None and e[0]() is obj else default
+
+    def __setitem__(self, obj, value):
+        k = id(obj)
+        self._d[k] = (weakref.ref(obj, lambda _r, k=k, d=self._d: d.pop(k, None) if (d.get(k) is not None and d[k][0] is _r) else None), value)
+
+    def __len__(self):
+        return len(self._d)
+
+
 class _WeightCache:
     def __init__(self):
-        self._c = {}
+        self._c = _WeakIdDict()                      # Parameter -> (stamp, compute-dtype copy)
+        self._cat = _WeakIdDict()                    # first Parameter of a concatenation -> {ids of the others: (stamps, weakrefs, copy)}
+        self.casts = 0                               # number of casts performed (tests)
+
+    @staticmethod
+    def _stamp(p: torch.Tensor):
+        return (_WEIGHTS_EPOCH[0], p._version, p.data_ptr(), p.device)
 
     def get(self, p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         d = p.detach()
@@ -79,43 +119,71 @@ class _WeightCache:
             d = d.reshape(d.shape[0], -1)
         if dtype == torch.float32:
             return d if d.is_contiguous() else d.contiguous()
-        key = id(p)
-        hit = self._c.get(key)
-        if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and hit[2].device == p.device:
-            return hit[2]
+        stamp = self._stamp(p)
+        hit = self._c.get(p)
+        if hit is not None and hit[0] == stamp and hit[1].dtype == dtype:
+            return hit[1]
         w = ops.cast(d.contiguous(), dtype)
-        self._c[key] = (p._version, p.data_ptr(), w)
+        self.casts += 1
+        self._c[p] = (stamp, w)
         return w
 
     def get_cat(self, ps, dtype: torch.dtype) -> torch.Tensor:
         """row-concatenation of several weights (to_k | to_v) in the compute dtype, cached like get()."""
-        key = tuple(id(p) for p in ps)
-        ver = tuple((p._version, p.data_ptr()) for p in ps)
-        hit = self._c.get(key)
-        if hit is not None and hit[0] == ver and hit[2].device == ps[0].device:
-            return hit[2]
+        stamps = tuple(self._stamp(p) for p in ps)
+        slot = self._cat.get(ps[0])
+        key = tuple(id(p) for p in ps[1:])
+        if slot is not None:
+            hit = slot.get(key)
+            if hit is not None and hit[0] == stamps and hit[2].dtype == dtype and all(r() is q for r, q in zip(hit[1], ps[1:])):
+                return hit[2]
         w = torch.cat([self.get(p, dtype) for p in ps], dim=0).contiguous()
-        self._c[key] = (ver, None, w)
+        if slot is None:
+            slot = self._cat[ps[0]] = {}
+        slot[key] = (stamps, tuple(weakref.ref(q) for q in ps[1:]), w)
         return w
 
 
 _WCACHE = _WeightCache()
 
 
-# column sums of a residual-stream gradient, produced for free by the LayerNorm-backward kernel that wrote it and consumed
-# by the next backward region as the bias gradient of its last Linear (keyed on the gradient's storage address)
-_DX_COLSUM: Dict[int, torch.Tensor] = {}
+# column sums of a residual-stream gradient, produced for free by the LayerNorm-backward kernel that wrote it and consumed by the
+# next backward region as the bias gradient of its last Linear.  The sum travels ON the gradient tensor object (autograd hands the
+# same object to the next node when there is a single consumer); if autograd had to build a new tensor (accumulation, hooks) the
+# attribute is simply absent and the column sum is recomputed -- a stale sum can never be picked up.
+_COLSUM_STATS = {"hit": 0, "miss": 0}
 
 
 def _publish_colsum(dx: torch.Tensor, cs: torch.Tensor) -> None:
-    _DX_COLSUM[dx.data_ptr()] = cs
+    dx._devias_colsum = (cs, dx.data_ptr())
 
 
-def _take_colsum(dy: torch.Tensor) -> torch.Tensor:
-    cs = _DX_COLSUM.pop(dy.data_ptr(), None)
-    if cs is None or cs.numel() != dy.shape[1] or cs.device != dy.device:
-        cs = ops.colsum(dy)
-    return cs
+def _take_colsum(dy: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    tag = getattr(dy, "_devias_colsum", None)
+    if tag is not None:
+        del dy._devias_colsum
+        cs, ptr = tag
+        if ptr == dy.data_ptr() and cs.numel() == dy.shape[1] and cs.device == dy.device:
+            _COLSUM_STATS["hit"] += 1
+            if out is not None:
+                out.copy_(cs)
+                return out
+            return cs
+    _COLSUM_STATS["miss"] += 1
+    return ops.colsum(dy, out=out)
+
+
+# ---- gradient destinations ---------------------------------------------------------------------------------------------------------
+# A data-parallel gradient bucket (devias_amd.parallel.GradSync) registers, on every parameter, the fp32 view of its flat bucket
+# (`_devias_grad_out`).  When the parameter has no gradient yet, the weight-gradient kernels write straight into that view and return
+# it: autograd adopts the tensor as `.grad` without a copy, so a bucket is complete the moment its last kernel finishes (no pack pass).
+def _gout(p: Optional[torch.Tensor], shape=None) -> Optional[torch.Tensor]:
+    if p is None or p.grad is not None:
+        return None                                   # accumulation (update_freq > 1, tied uses): autograd adds a fresh tensor in place
+    v = getattr(p, "_devias_grad_out", None)
+    if v is None:
+        return None
+    return v if shape is None else v.view(shape)
 
 
 # ---- weight-gradient side stream ------------------------------------------------------------------------------------
@@ -175,14 +243,15 @@ class PatchEmbedFn(Function):
         w = _WCACHE.get(weight, cdt)
         y = ops.gemm(A, w, bias=_f32(bias), res=pos, res_mod=pos.shape[0])
         ctx.A = A
-        ctx.wshape = weight.shape
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
-        dW = ops.wgrad(dy, ctx.A).reshape(ctx.wshape)
-        db = _take_colsum(dy)
+        weight, bias = ctx.params
+        dW = ops.wgrad(dy, ctx.A, out=_gout(weight, (weight.shape[0], -1))).view(weight.shape)
+        db = _take_colsum(dy, out=_gout(bias))
         ctx.A = None
         return None, dW, db, None, None
 
@@ -207,6 +276,7 @@ class EncoderBlockFn(Function):
         x2 = ops.gemm(hact, W2, bias=_f32(f2b), res=x1, row_scale=ds2, rows_per_scale=N)   # x1 + drop_path(mlp(.))
         ctx.meta = meta
         ctx.ds = (ds1, ds2)
+        ctx.params = (n1w, n1b, qkvw, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b)
         ctx.saved = (x, u, mean1, rstd1, qkv, o, lse, x1, u2, mean2, rstd2, hpre, hact, n1w_, n2w_, Wqkv, Wp, W1, W2)
         return x2
 
@@ -221,37 +291,41 @@ class EncoderBlockFn(Function):
         dev = x.device
         ds1, ds2 = ctx.ds
         lane = _WgradLane(dev)
+        (p_n1w, p_n1b, p_qkvw, p_pw, p_pb, p_n2w, p_n2b, p_f1w, p_f1b, p_f2w, p_f2b) = ctx.params
+        f32 = lambda n: torch.empty((n,), dtype=torch.float32, device=dev)          # noqa: E731
+        dst = lambda p_, n: _gout(p_) if _gout(p_) is not None else f32(n)          # noqa: E731  (gradient bucket view, or a fresh buffer)
         # ---- MLP branch (g2 = gradient of the branch output: dx2 scaled by the per-sample stochastic-depth factor, if any)
         if ds2 is None:
-            g2, db2 = dx2, _take_colsum(dx2)                                            # fc2 bias gradient
+            g2, db2 = dx2, _take_colsum(dx2, out=_gout(p_f2b))                          # fc2 bias gradient
         else:
             g2 = ops.row_scale(dx2, ds2, N)
-            db2 = ops.colsum(g2)
+            db2 = ops.colsum(g2, out=_gout(p_f2b))
         with lane.after_main():
-            dW2 = ops.wgrad(g2, hact)
-        db1 = torch.empty((W1.shape[0],), dtype=torch.float32, device=dev)
+            dW2 = ops.wgrad(g2, hact, out=_gout(p_f2w))
+        db1 = dst(p_f1b, W1.shape[0])
         dhpre = ops.gemm(g2, W2, trans_b=True, act=ACT_DGELU, aux_in=hpre, colsum=db1)   # (g2 W2) * gelu'(pre); db1 = colsum
         with lane.after_main():
-            dW1 = ops.wgrad(dhpre, u2)
+            dW1 = ops.wgrad(dhpre, u2, out=_gout(p_f1w))
         du2 = ops.gemm(dhpre, W1, trans_b=True)
-        dbp = torch.empty((D,), dtype=torch.float32, device=dev)
-        dx1, dn2w, dn2b = ops.layernorm_bwd(du2, x1, n2w_, mean2, rstd2, dres=dx2, dx_colsum=dbp)   # + residual gradient; dbp = colsum(dx1)
+        dbp = dst(p_pb, D)
+        dx1, dn2w, dn2b = ops.layernorm_bwd(du2, x1, n2w_, mean2, rstd2, dres=dx2, dx_colsum=dbp,
+                                            dgamma=_gout(p_n2w), dbeta=_gout(p_n2b))      # + residual gradient; dbp = colsum(dx1)
         # ---- attention branch
         if ds1 is None:
             g1 = dx1
         else:
             g1 = ops.row_scale(dx1, ds1, N)
-            dbp = ops.colsum(g1)
+            dbp = ops.colsum(g1, out=dbp)
         with lane.after_main():
-            dWp = ops.wgrad(g1, o)
+            dWp = ops.wgrad(g1, o, out=_gout(p_pw))
         d_o = ops.gemm(g1, Wp, trans_b=True)
         dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale)
         with lane.after_main():
-            dWqkv = ops.wgrad(dqkv, u)
+            dWqkv = ops.wgrad(dqkv, u, out=_gout(p_qkvw))
             dbqkv = ops.colsum(dqkv)
         du = ops.gemm(dqkv, Wqkv, trans_b=True)
-        dxs = torch.empty((D,), dtype=torch.float32, device=dev)
-        dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1, dx_colsum=dxs)
+        dxs = f32(D)
+        dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1, dx_colsum=dxs, dgamma=_gout(p_n1w), dbeta=_gout(p_n1b))
         _publish_colsum(dx, dxs)
         lane.join(dW2, dW1, dWp, dWqkv, dbqkv)
         return (dx, dn1w, dn1b, dWqkv, dbqkv[:D], dbqkv[2 * D:], dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None)

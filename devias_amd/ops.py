@@ -57,6 +57,20 @@ def device_info(device: int = 0):
     return {"cus": out[0], "clock_khz": out[1], "lds_per_block": out[2], "wave": out[3], "gfx": out[4]}
 
 
+def set_option(name: str, value: int) -> None:
+    """devias_set_option: process-wide kernel-selection knobs (gemm_epi, gemm256, gemm_ss, gemm_groupm, gemm_persistent, attn_cfg, attn_xcd ...)"""
+    _lib.check(_lib.load().devias_set_option(name.encode(), int(value)), "devias_set_option")
+
+
+def counters(reset: bool = False) -> dict:
+    """launch counts per kernel family since the last reset (devias_counter): tests assert WHICH kernels served a step"""
+    lib = _lib.load()
+    out = {k: int(lib.devias_counter(i)) for k, i in _lib.COUNTERS.items()}
+    if reset:
+        lib.devias_counters_reset()
+    return out
+
+
 _WGRAD_SLOTS = int(__import__("os").environ.get("DEVIAS_WGRAD_SLOTS", "512"))     # A/B knob (tools/ab_bench.py)
 
 
@@ -233,10 +247,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
     _chk(dy, "layernorm_bwd.dy"); _chk(x, "layernorm_bwd.x", dy.dtype)
     M, D = x.shape
     dx = torch.empty_like(x)
-    if dgamma is None:
+    if dgamma is None or dbeta is None:
         assert beta_acc == 0.0
-        dgamma = torch.empty((D,), dtype=torch.float32, device=x.device)
-        dbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
+        dgamma = dgamma if dgamma is not None else torch.empty((D,), dtype=torch.float32, device=x.device)
+        dbeta = dbeta if dbeta is not None else torch.empty((D,), dtype=torch.float32, device=x.device)
+    _chk(dgamma, "layernorm_bwd.dgamma", torch.float32); _chk(dbeta, "layernorm_bwd.dbeta", torch.float32)
     if dres is not None:
         _chk(dres, "layernorm_bwd.dres", dy.dtype)
     ws = workspace(_lib.load().devias_layernorm_bwd_workspace_bytes(M, D), x.device)
@@ -246,10 +261,14 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
     return dx, dgamma, dbeta
 
 
-def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float):
+def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, out: Optional[torch.Tensor] = None):
     _chk(qkv, "mhsa_fwd.qkv")
     assert qkv.numel() == B * N * 3 * H * 64, "mhsa: head dim must be 64"
-    o = torch.empty((B * N, H * 64), dtype=qkv.dtype, device=qkv.device)
+    if out is None:
+        o = torch.empty((B * N, H * 64), dtype=qkv.dtype, device=qkv.device)
+    else:
+        o = _chk(out, "mhsa_fwd.out", qkv.dtype)
+        assert o.shape == (B * N, H * 64)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     _lib.check(_lib.load().devias_mhsa_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), _stream()),
                "devias_mhsa_fwd")

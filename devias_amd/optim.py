@@ -95,6 +95,11 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         by_hyper = self._gather()
+        if by_hyper:
+            # the kernels below write parameters through raw pointers (Tensor._version does not move): compute-dtype weight copies
+            # held by the model code are stale from here on (stale bf16 weights after the first step)
+            from .modeling_slot import invalidate_weight_cache
+            invalidate_weight_cache()
         if not self.multi_tensor:
             if max_norm is not None:
                 raise RuntimeError("FusedAdamW(multi_tensor=False) has no fused gradient-norm path")

@@ -4,11 +4,19 @@
 Replaces DDP / DeepSpeed ZeRO-0 gradient all-reduce of the reference (run_slot_finetuning.py:552-563):
   * parameters are bucketed in REVERSE registration order (head / mask_predictor / agg_block first, then blocks.11 ... 0,
     patch_embed last) -- the order backward produces their gradients;
-  * when the last gradient of a bucket has been accumulated (post-accumulate-grad hook) the bucket is packed into a flat
-    fp32 buffer, an event is recorded on the compute stream and the all-reduce is enqueued on the side stream;
-  * finish() makes the compute stream wait for all buckets and leaves p.grad as views of the averaged flat buffers.
+  * every parameter gets the fp32 view of its place in the flat bucket (`p._devias_grad_out`): the weight-gradient kernels of the
+    encoder blocks write straight into it (modeling_slot._gout), autograd adopts the view as `.grad`, and nothing is packed;
+    gradients that arrive as other tensors (small agg-block / head ones) are copied into their view by the hook;
+  * when the last gradient of a bucket has arrived (post-accumulate-grad hook) an event is recorded on the compute stream and the
+    all-reduce is enqueued on the side stream;
+  * gradient accumulation (engine `update_freq` > 1): `set_accumulate(True)` for every micro-batch but the last -- hooks then only
+    home the gradients in the buckets, the collectives start during the last micro-batch's backward;
+  * finish() zero-fills the gradients of parameters that received none (unused parameters: every rank must issue the same
+    collectives), makes the compute stream wait for all buckets and leaves p.grad as views of the averaged flat buffers.
 xGMI is point-to-point (7 links/GPU); a few large buckets (default 64 MiB) keep each ring step bandwidth-bound.
-Reduction is fp32 SUM followed by a 1/world scale (exact mean of fp32 gradients), stated in DESIGN.md.
+Reduction: fp32 SUM followed by a 1/world scale (exact mean of fp32 gradients) by default; `comm_dtype=torch.bfloat16` halves the
+bytes on the links (196.8 MB instead of 393.7 MB at ViT-B): gradients are rounded to bf16 once, RCCL sums them with bf16 partial
+results between ring steps, the mean is widened back into the fp32 bucket.  bench.py states which one it ran.
 """
 from __future__ import annotations
 
@@ -19,57 +27,75 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, module: torch.nn.Module, process_group=None, bucket_bytes: int = 64 << 20, average: bool = True):
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_bytes: int = 64 << 20, average: bool = True,
+                 comm_dtype: torch.dtype = torch.float32):
+        if comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("GradSync: comm_dtype must be torch.float32 or torch.bfloat16")
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
+        self.comm_dtype = comm_dtype
         params = [p for p in module.parameters() if p.requires_grad]
         self.params = list(reversed(params))
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, cur_bytes = [], 0
         for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("GradSync: master parameters must be fp32")
             cur.append(p)
             cur_bytes += p.numel() * 4
             if cur_bytes >= bucket_bytes:
                 self.buckets.append(cur); cur, cur_bytes = [], 0
         if cur:
             self.buckets.append(cur)
-        self.flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self.flat: List[torch.Tensor] = []
+        self._view = {}
         self._where = {}
         for bi, b in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
+            self.flat.append(flat)
             off = 0
             for p in b:
-                self._where[p] = (bi, off)
+                v = flat[off:off + p.numel()].view(p.shape)
+                self._view[p] = v
+                self._where[p] = bi
+                p._devias_grad_out = v                 # destination of the weight-gradient kernels (modeling_slot._gout)
                 off += p.numel()
+        self._comm = [None] * len(self.buckets)        # bf16 wire buffers (comm_dtype = bf16 only)
         self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
         self._works = []
         self._side = None
+        self._accumulate = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.reset()
 
     # -------------------------------------------------------------------------------------------------
     def reset(self):
         self._pending = [len(b) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._seen = set()
         self._works = []
 
-    def _flat_for(self, bi: int, like: torch.Tensor) -> torch.Tensor:
-        if self.flat[bi] is None or self.flat[bi].device != like.device:
-            n = sum(p.numel() for p in self.buckets[bi])
-            self.flat[bi] = torch.empty(n, dtype=torch.float32, device=like.device)
-        return self.flat[bi]
+    def set_accumulate(self, flag: bool):
+        """True for every micro-batch of an accumulation window except the last one (no collective is started)."""
+        self._accumulate = bool(flag)
 
     def _on_grad(self, p: torch.nn.Parameter):
-        bi, off = self._where[p]
-        flat = self._flat_for(bi, p.grad)
-        view = flat[off:off + p.numel()].view_as(p)
-        if p.grad.data_ptr() != view.data_ptr():
+        view = self._view[p]
+        if p.grad.data_ptr() != view.data_ptr():       # produced elsewhere (or accumulated by autograd into a private tensor): home it
             view.copy_(p.grad)
             p.grad = view
+        if self._accumulate or p in self._seen:
+            return
+        self._seen.add(p)
+        bi = self._where[p]
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
 
     def _launch(self, bi: int):
+        self._launched[bi] = True
         flat = self.flat[bi]
         if self.world == 1:
             return
@@ -80,29 +106,63 @@ class GradSync:
             ev.record(torch.cuda.current_stream(flat.device))
             self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
-                w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                self._works.append((w, flat))
+                buf = self._wire(bi, flat)
+                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                self._works.append((w, bi, buf))
         else:
-            w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._works.append((w, flat))
+            buf = self._wire(bi, flat)
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._works.append((w, bi, buf))
+
+    def _wire(self, bi: int, flat: torch.Tensor) -> torch.Tensor:
+        if self.comm_dtype == torch.float32:
+            return flat
+        if self._comm[bi] is None:
+            self._comm[bi] = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+        if flat.is_cuda:
+            from . import ops
+            ops.cast(flat, torch.bfloat16, out=self._comm[bi])
+        else:
+            self._comm[bi].copy_(flat)
+        return self._comm[bi]
 
     def finish(self):
         """Block the COMPUTE STREAM (not the host) until every bucket is reduced, then scale to the mean."""
-        for bi, n in enumerate(self._pending):
-            if n != 0 and n != len(self.buckets[bi]):
-                raise RuntimeError(f"GradSync: bucket {bi} has {n} parameters without a gradient this step")
-        for w, flat in self._works:
+        if self._accumulate:
+            raise RuntimeError("GradSync.finish() inside an accumulation window: call set_accumulate(False) before the last backward")
+        for bi, b in enumerate(self.buckets):
+            if self._launched[bi]:
+                continue
+            for p in b:                                 # parameters without a gradient this step: zeros, so that every rank reduces every bucket
+                if p not in self._seen:
+                    v = self._view[p]
+                    if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                        v.zero_()
+                        p.grad = v
+            self._launch(bi)
+        for w, bi, buf in self._works:
             w.wait()                       # for NCCL/RCCL: makes the current stream wait for the collective (no host block)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
-        if self.world > 1 and self.average:
-            for w, flat in self._works:
-                flat.mul_(1.0 / self.world)
+        scale = (1.0 / self.world) if (self.world > 1 and self.average) else 1.0
+        for w, bi, buf in self._works:
+            flat = self.flat[bi]
+            if buf is not flat:                         # bf16 wire format: widen the sum back into the fp32 bucket
+                if flat.is_cuda:
+                    from . import ops
+                    ops.cast(buf, torch.float32, out=flat)
+                else:
+                    flat.copy_(buf)
+            if scale != 1.0:
+                flat.mul_(scale)
         self.reset()
 
     def remove(self):
         for h in self._hooks:
             h.remove()
+        for p in self.params:
+            if hasattr(p, "_devias_grad_out"):
+                del p._devias_grad_out
 
 
 def init_distributed_from_env(backend: Optional[str] = None):
@@ -129,3 +189,5 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=No
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=process_group)
+    from .modeling_slot import invalidate_weight_cache
+    invalidate_weight_cache()              # `.data` writes do not move Tensor._version

@@ -43,8 +43,28 @@ extern "C" {
 #define DEVIAS_ACT_DGELU 4     /* backward: v *= gelu'(aux_in) with aux_in = saved pre-activation */
 #define DEVIAS_ACT_DRELU 5     /* backward: v = aux_in > 0 ? v : 0 with aux_in = saved ReLU output */
 
-int devias_version(void);          /* 100 + additions: 110 = multi-tensor optimizer entry points, 120 = devias_fame_* */
+int devias_version(void);          /* 100 + additions: 110 = multi-tensor optimizer entry points, 120 = devias_fame_*, 130 = counters + options */
 const char* devias_last_error(void);
+/* Launch counters: one per kernel family, incremented by the host side of each entry point (process-wide, relaxed atomics).
+ * Tests use them to ASSERT that the kernels a parity claim is made for are the kernels that ran (the reference has no analogue:
+ * its dispatch is ATen's). */
+#define DEVIAS_CNT_GEMM128_F32 0     /* 128x128 register-staged kernel, exact fp32 MFMA */
+#define DEVIAS_CNT_GEMM128_BF16 1    /* 128x128 register-staged kernel, bf16 (ragged / small shapes) */
+#define DEVIAS_CNT_GEMM_SS 2         /* 256x128 single-stage LDS-DMA kernel */
+#define DEVIAS_CNT_GEMM256 3         /* 256x256 two-stage LDS-DMA kernel, one tile per workgroup (wgrad / split-K / <= 1 round) */
+#define DEVIAS_CNT_GEMM256P 4        /* 256x256 persistent kernel (forward / dgrad GEMMs of the measured step) */
+#define DEVIAS_CNT_SPLITK_REDUCE 5
+#define DEVIAS_CNT_MHSA_FWD_BF16 6   /* MFMA flash forward */
+#define DEVIAS_CNT_MHSA_BWD_BF16 7   /* MFMA backward */
+#define DEVIAS_CNT_MHSA_FWD_F32 8    /* VALU parity kernels */
+#define DEVIAS_CNT_MHSA_BWD_F32 9
+#define DEVIAS_CNT_MAX 16
+int64_t devias_counter(int32_t id);          /* -1 for an unknown id */
+void devias_counters_reset(void);
+/* Process-wide integer options (initialised once from the DEVIAS_* environment variables of the same meaning): "gemm_epi",
+ * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_debug", "attn_cfg", "attn_xcd", "attn_bwd".  0 = ok, DEVIAS_EINVAL = unknown name. */
+int devias_set_option(const char* name, int32_t value);
+
 /* fills: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes per block, [3]=wavefront size, [4]=gfx arch number (e.g. 950) */
 int devias_device_info(int device, int64_t* out5);
 

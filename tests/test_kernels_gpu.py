@@ -41,7 +41,7 @@ def test_gemm_layouts(dtype, ta, tb, M, N, K):
     C = o.gemm(A, B, trans_a=ta, trans_b=tb)
     ref = (A.float().t() if ta else A.float()) @ (B.float() if tb else B.float().t())
     assert C.dtype == dtype and C.shape == (M, N)
-    assert rel(C.float(), ref) < TOL[dtype] * (4 if dtype == torch.bfloat16 else 1)
+    assert rel(C.float(), ref) < (1e-2 if dtype == torch.bfloat16 else TOL[dtype])      # bf16: output rounding 2^-9 of the largest element + fp32 accumulation
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -383,13 +383,24 @@ def test_fused_adamw_multi_equals_per_tensor_path_bitwise():
 
 
 # ------------------------------------------------------------------------------------------------ persistent GEMM
+@pytest.fixture
+def gemm_options():
+    """restores the process-wide kernel-selection options a test changes"""
+    o = ops()
+    yield o
+    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1)):
+        o.set_option(k, v)
+
+
 @pytest.mark.parametrize("tb", [False, True])
 @pytest.mark.parametrize("epi", ["bias", "res", "gelu_aux", "dgelu_colsum", "plain", "res_rowscale"])
-@pytest.mark.parametrize("M,N,K", [(256 * 40, 1024, 128), (256 * 33, 2048, 320), (256 * 70, 512, 768)])
-def test_gemm_persistent_kernel(tb, epi, M, N, K, monkeypatch):
-    """gemm_pk_kernel (deferred stores, continuous operand ring) against the fp32 op on the bf16-rounded inputs; the same
-    call through the non-persistent kernels must agree with it to bf16 rounding of identical fp32 values (bitwise)"""
-    o = ops()
+@pytest.mark.parametrize("M,N,K", [(256 * 70, 1024, 128), (256 * 300, 256, 320), (256 * 99, 768, 768), (256 * 131, 512, 64)])
+def test_gemm_persistent_kernel(tb, epi, M, N, K, gemm_options):
+    """gemm256p_kernel (persistent: K-tile stream across tile boundaries, epilogue stores left in flight behind a counted vmcnt)
+    against the fp32 op on the bf16-rounded inputs; the same call through the one-tile-per-workgroup kernel, with both epilogues,
+    must agree BITWISE (same MFMA order, same fp32 epilogue arithmetic).  Tile counts are not multiples of the CU count, K covers
+    one to twelve K-tiles, and the counters assert which kernel served each call."""
+    o = gemm_options
     from devias_amd._lib import ACT_DGELU, ACT_GELU
     A = rnd(M, K, dtype=torch.bfloat16, seed=1)
     B = rnd(*((K, N) if tb else (N, K)), dtype=torch.bfloat16, scale=0.1, seed=2)
@@ -412,18 +423,21 @@ def test_gemm_persistent_kernel(tb, epi, M, N, K, monkeypatch):
         dg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
         kw = dict(act=ACT_DGELU, aux_in=pre); ref = ref * dg
     outs = {}
-    for mode in ("2", "0", "0s"):                          # persistent kernel; other kernels with the register-transposed epilogue; with the LDS-staged one
-        monkeypatch.setenv("DEVIAS_GEMM_PK", mode[0])
-        monkeypatch.setenv("DEVIAS_GEMM_EPI", "0" if mode.endswith("s") else "1")
+    for mode in ("p", "0", "0s"):                          # persistent; one tile per workgroup, register-transposed epilogue; LDS-staged epilogue
+        o.set_option("gemm_persistent", 1 if mode == "p" else 0)
+        o.set_option("gemm_epi", 0 if mode.endswith("s") else 1)
         kw2 = dict(kw)
         if epi == "gelu_aux":
             kw2["aux_out"] = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         if epi == "dgelu_colsum":
             kw2["colsum"] = torch.zeros(N, device=DEV)
+        o.counters(reset=True)
         c = o.gemm(A, B, trans_b=tb, **kw2)
         torch.cuda.synchronize()
+        cnt = o.counters()
+        assert (cnt["gemm256p"], cnt["gemm256"]) == ((1, 0) if mode == "p" else (0, 1)), (mode, cnt)
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
-    c, aux, cs = outs["2"]
+    c, aux, cs = outs["p"]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]
     assert torch.equal(c, outs["0"][0]) and torch.equal(c, outs["0s"][0])
     if aux is not None:
@@ -432,3 +446,27 @@ def test_gemm_persistent_kernel(tb, epi, M, N, K, monkeypatch):
     if cs is not None:
         assert rel(cs, c.float().sum(0)) < 1e-2                 # sums the fp32 values before bf16 rounding
         assert rel(cs, outs["0"][2]) < 1e-5 and rel(cs, outs["0s"][2]) < 1e-5
+
+
+def test_gemm_persistent_kernel_repeatable(gemm_options):
+    """the persistent kernel's hand-placed waits (counted vmcnt behind the epilogue stores, raw barriers) are a race surface: the
+    same launch repeated 30 times under a concurrent memory-bound stream must give bitwise identical results every time"""
+    o = gemm_options
+    M, N, K = 256 * 196, 768, 768
+    A = rnd(M, K, dtype=torch.bfloat16, seed=11)
+    W = rnd(N, K, dtype=torch.bfloat16, scale=0.05, seed=12)
+    Wt = rnd(K, N, dtype=torch.bfloat16, scale=0.05, seed=13)
+    bias = rnd(N, seed=14)
+    res = rnd(M, N, dtype=torch.bfloat16, seed=15)
+    o.set_option("gemm_persistent", 0)
+    ref_nt = o.gemm(A, W, bias=bias, res=res)
+    ref_nn = o.gemm(A, Wt, trans_b=True)
+    o.set_option("gemm_persistent", 1)
+    junk = torch.empty(64 << 20, device=DEV)
+    side = torch.cuda.Stream()
+    for it in range(30):
+        with torch.cuda.stream(side):
+            junk.add_(1.0)                                # uneven memory load next to the GEMM
+        assert torch.equal(o.gemm(A, W, bias=bias, res=res), ref_nt), it
+        assert torch.equal(o.gemm(A, Wt, trans_b=True), ref_nn), it
+    torch.cuda.synchronize()

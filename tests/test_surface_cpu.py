@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     """every function declared in include/devias_amd.h is exported by libdevias_amd.so and bound in _lib.PROTOTYPES"""
     from devias_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "devias_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(devias_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|void|const char\*)\s+(devias_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 25
     lib = _lib.load()
     for name in declared:
@@ -26,6 +26,46 @@ def test_library_exports_every_declared_symbol():
     a = _lib.GemmArgs()
     assert lib.devias_gemm(ctypes.byref(a), None) == -1
     assert b"devias_gemm" in lib.devias_last_error()
+    # launch counters and process-wide options need no GPU either
+    lib.devias_counters_reset()
+    assert all(lib.devias_counter(i) == 0 for i in _lib.COUNTERS.values()) and lib.devias_counter(999) == -1
+    assert lib.devias_set_option(b"gemm_persistent", 1) == 0 and lib.devias_set_option(b"attn_xcd", 1) == 0
+    assert lib.devias_set_option(b"no_such_option", 1) == -1 and b"no_such_option" in lib.devias_last_error()
+
+
+def test_weight_cache_invalidation_logic(monkeypatch):
+    """ADVICE r1 (high / low): compute-dtype weight copies are refreshed when Tensor._version moves (torch optimizers, load_state_dict),
+    when invalidate_weight_cache() is called (the fused optimizer and `.data` writers call it: raw-pointer updates do not move the
+    version), and entries die with their parameter (no id()-keyed leak)."""
+    import gc
+    from devias_amd import modeling_slot as ms, ops
+    monkeypatch.setattr(ops, "cast", lambda t, dt, out=None: t.to(dt))            # the GPU cast kernel, stood in for on the CPU
+    cache = ms._WeightCache()
+    p = torch.nn.Parameter(torch.randn(8, 4))
+    w0 = cache.get(p, torch.bfloat16)
+    assert cache.get(p, torch.bfloat16) is w0 and cache.casts == 1
+    with torch.no_grad():
+        p.add_(1.0)                                                                # version bump
+    w1 = cache.get(p, torch.bfloat16)
+    assert w1 is not w0 and torch.equal(w1, p.detach().bfloat16()) and cache.casts == 2
+    p.data.mul_(2.0)                                                               # invisible to _version ...
+    assert cache.get(p, torch.bfloat16) is w1
+    ms.invalidate_weight_cache()                                                   # ... which is why such writers must say so
+    w2 = cache.get(p, torch.bfloat16)
+    assert w2 is not w1 and torch.equal(w2, p.detach().bfloat16())
+    q = torch.nn.Parameter(torch.randn(8, 4))
+    c0 = cache.get_cat((p, q), torch.bfloat16)
+    assert cache.get_cat((p, q), torch.bfloat16) is c0 and c0.shape == (16, 4)
+    with torch.no_grad():
+        q.zero_()
+    assert float(cache.get_cat((p, q), torch.bfloat16)[8:].abs().max()) == 0.0
+    n = len(cache._c)
+    del p, q, w0, w1, w2, c0
+    gc.collect()
+    assert len(cache._c) == n - 2 and len(cache._cat) == 0
+    # conv weights are viewed as matrices; fp32 mode never copies
+    c = torch.nn.Parameter(torch.randn(6, 3, 2, 4, 4))
+    assert cache.get(c, torch.float32).shape == (6, 96) and cache.get(c, torch.float32).data_ptr() == c.data_ptr()
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(num_latents=4, agg_weights_tie=False, agg_depth=4), dict(embed_dim=384, num_heads=6)])
