@@ -107,3 +107,42 @@ def test_fame_masks_match_oracle_other_geometries(B, T, size, beta):
     assert agree >= 0.995, agree
     assert float((pooled.cpu() - om).abs().mean()) < 2e-3
     assert float((pooled_pf.reshape(B, -1).cpu() - ompf).abs().mean()) < 2e-3
+
+
+def test_device_kernels_match_hand_computed_kornia_vectors():
+    """the HIP blur and colour-bin kernels against the float64 known-answer vectors of tests/golden/make_kornia_vectors.py (kornia's
+    published GaussianBlur2d / rgb_to_hsv formulas), not only against the oracle's restatement of them"""
+    import json
+    from devias_amd import _lib
+    kv = json.load(open(os.path.join(GOLD, "kornia_vectors.json")))
+    lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+    imgs, want = [], []
+    for case in kv["blur_cases"]:
+        H, W = case["shape"]
+        if "impulse" in case:
+            img = torch.zeros(H, W)
+            img[case["impulse"][0], case["impulse"][1]] = 1.0
+        else:
+            img = torch.tensor(case["image"], dtype=torch.float32)
+        imgs.append(img); want.append(torch.tensor(case["blurred"], dtype=torch.float64))
+    x = torch.stack(imgs).cuda().contiguous()
+    out = torch.empty_like(x)
+    _lib.check(lib.devias_fame_blur(x.data_ptr(), out.data_ptr(), x.shape[0], 16, 16, kv["ksize"], kv["sigma"], st), "blur")
+    assert float((out.cpu().double() - torch.stack(want)).abs().max()) < 5e-7
+    # colour bins: a clip that is constant in time, one listed colour per pixel, ImageNet-normalised as the data loader delivers it
+    cases = [c for c in kv["hsv_cases"] if c["bin_margin"] > 5e-3]
+    n = len(cases)
+    Wd = 16
+    rgb = torch.tensor([c["rgb"] for c in cases], dtype=torch.float32)
+    pad = rgb[:1].repeat(Wd - n % Wd if n % Wd else 0, 1)
+    px = torch.cat([rgb, pad]).t().reshape(3, 1, -1, Wd)                      # [3, 1, H, W]
+    mean = torch.tensor(synth.IMAGENET_MEAN).view(3, 1, 1, 1)
+    std = torch.tensor(synth.IMAGENET_STD).view(3, 1, 1, 1)
+    clip = ((px - mean) / std).repeat(1, 2, 1, 1)[None].contiguous().cuda()   # [1, 3, T=2, H, W]
+    H = clip.shape[3]
+    diffs = torch.empty(2, H, Wd, device="cuda")
+    cmap = torch.empty(1, H * Wd, dtype=torch.int16, device="cuda")
+    _lib.check(lib.devias_fame_diff_color(clip.data_ptr(), 1, 2, H, Wd, diffs.data_ptr(), cmap.data_ptr(), st), "diff_color")
+    got = cmap.cpu().reshape(-1)[:n].tolist()
+    assert got == [c["fame_bin"] for c in cases], (got, [c["fame_bin"] for c in cases])
+    assert float(diffs.abs().max()) == 0.0                                     # identical frames: no motion

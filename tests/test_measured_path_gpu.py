@@ -196,7 +196,9 @@ def test_vit_large_full_depth_fp32_vs_oracle_and_bf16_properties():
         t.backward()
         cnt = ops.counters()
         res.append((o[2][0].detach().clone(), t.detach().clone(), [p.grad.clone() for p in mb.parameters()]))
-    assert cnt["gemm256p"] >= 24 * 8 and cnt["mhsa_bwd_bf16"] == 24, cnt
+    # M = 12544 = 49 row tiles: the N = 3072 / 4096 shapes (qkv, fc1 forward, fc2 dgrad: 588 / 784 tiles) run persistent, the N = 1024 ones
+    # (196 tiles <= 256 CUs) one tile per workgroup
+    assert cnt["gemm256p"] >= 24 * 3 and cnt["gemm256"] >= 24 * 9 and cnt["mhsa_bwd_bf16"] == 24, cnt
     assert torch.isfinite(res[0][1]).all() and all(torch.isfinite(g).all() for g in res[0][2])
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
