@@ -64,7 +64,8 @@ PROTOTYPES = {
     "devias_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P, _P]),
     "devias_layernorm_bwd_workspace_bytes": (c_int64, [_I, _I]),
     "devias_mhsa_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
-    "devias_mhsa_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "devias_mhsa_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P]),
+    "devias_mhsa_bwd_workspace_bytes": (c_int64, [_I, _I, _I]),
     "devias_slot_attn_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "devias_slot_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "devias_slot_attn_kv_grad": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
@@ -84,7 +85,7 @@ PROTOTYPES = {
     "devias_fame_mix": (c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 COUNTERS = {"gemm128_f32": 0, "gemm128_bf16": 1, "gemm_ss": 2, "gemm256": 3, "gemm256p": 4, "splitk_reduce": 5,
-            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9}     # DEVIAS_CNT_*
+            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10}     # DEVIAS_CNT_*
 OPT_CHUNK = 16384          # DEVIAS_OPT_CHUNK
 OPT_TENSOR_BYTES = 64      # sizeof(devias_opt_tensor)
 

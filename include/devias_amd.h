@@ -55,9 +55,10 @@ const char* devias_last_error(void);
 #define DEVIAS_CNT_GEMM256P 4        /* 256x256 persistent kernel (forward / dgrad GEMMs of the measured step) */
 #define DEVIAS_CNT_SPLITK_REDUCE 5
 #define DEVIAS_CNT_MHSA_FWD_BF16 6   /* MFMA flash forward */
-#define DEVIAS_CNT_MHSA_BWD_BF16 7   /* MFMA backward */
+#define DEVIAS_CNT_MHSA_BWD_BF16 7   /* MFMA backward, two kernels (dQ; dK/dV) */
 #define DEVIAS_CNT_MHSA_FWD_F32 8    /* VALU parity kernels */
 #define DEVIAS_CNT_MHSA_BWD_F32 9
+#define DEVIAS_CNT_MHSA_BWD_FUSED 10 /* MFMA backward, single pass (dQ by ordered hand-off) */
 #define DEVIAS_CNT_MAX 16
 int64_t devias_counter(int32_t id);          /* -1 for an unknown id */
 void devias_counters_reset(void);
@@ -155,12 +156,17 @@ int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
  * Encoder multi-head self-attention core (Attention.forward, modeling_slot.py:102-112): non-causal, no mask,
  * head dim 64.  qkv: T [B,N,3,H,64] exactly as F.linear produces it (:101-102, no permute copy); o: T [B,N,H*64];
  * lse: fp32 [B,H,N] = log sum_j exp(scale * q.k_j).  The N x N score matrix is never materialised.
- * backward: dqkv T [B,N,3,H,64]; delta fp32 [B,H,N] scratch (rowsum(dO*O)).
+ * backward: dqkv T [B,N,3,H,64]; delta fp32 [B,H,N] scratch (rowsum(dO*O)).  bf16 with a workspace `ws` (16-byte aligned,
+ *   >= devias_mhsa_bwd_workspace_bytes; contents need not be initialised): ONE kernel, five matrix products per tile pair; dQ is summed over
+ *   the 128-key blocks of a head by an ordered workgroup-to-workgroup hand-off (fixed order: bitwise reproducible), and the first int32
+ *   words of `ws` hold hand-off state -- word [3] is non-zero afterwards if a bounded wait expired (results are then invalid).
+ *   ws == NULL (or fp32): two kernels (dQ; dK/dV), seven products, `delta` used as scratch.
  * ------------------------------------------------------------------------------------------------- */
 int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
                     int32_t dtype, void* stream);
 int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
-                    int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* stream);
+                    int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* ws, void* stream);
+int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H);
 
 /* ---------------------------------------------------------------------------------------------------
  * Slot cross-attention core (agg_block/attention.py:128-140): heads h, head dim dh (4 x 512 in DEVIAS),
