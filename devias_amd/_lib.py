@@ -32,6 +32,7 @@ class GemmArgs(Structure):
         ("beta", c_float), ("split_k", c_int32), ("ws", c_void_p),
         ("colsum", c_void_p), ("colsum_beta", c_float),
         ("row_scale", c_void_p), ("rows_per_scale", c_int32),
+        ("batch", c_int32), ("stride_a", c_int64), ("stride_b", c_int64), ("stride_c", c_int64),
     ]
 
 
@@ -70,6 +71,10 @@ PROTOTYPES = {
     "devias_slot_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "devias_slot_attn_kv_grad": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "devias_slot_attn_workspace_bytes": (c_int64, [_I, _I, _I, _I, _I]),
+    "devias_slotf_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "devias_slotf_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "devias_slotf_pack": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "devias_slotf_workspace_bytes": (c_int64, [_I, _I, _I, _I, _I]),
     "devias_slot_select": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "devias_head_match_loss_fwd": (c_int, [POINTER(LossDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "devias_head_match_loss_bwd": (c_int, [POINTER(LossDims), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

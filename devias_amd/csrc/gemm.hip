@@ -34,6 +34,7 @@ struct GemmP {
     int debug;            // timing ablations, compiled in only with -DDEVIAS_GEMM_DEBUG (option "gemm_debug"): 1 = one K-tile, 2 = no epilogue,
                           // 4 = no LDS-DMA after tile 0, 8 = s_memrealtime stamps into ws, 64 = epilogue without its global stores
     int epi_vm;           // persistent kernel: VMEM operations every wave is guaranteed to issue in one epilogue (counted vmcnt)
+    int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
 };
 
 #ifdef DEVIAS_GEMM_DEBUG
@@ -449,8 +450,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmP p) {
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
 
-    const T* A = reinterpret_cast<const T*>(p.A);
-    const T* B = reinterpret_cast<const T*>(p.B);
+    const T* A = reinterpret_cast<const T*>(p.A) + (int64_t)blockIdx.z * p.sA;
+    const T* B = reinterpret_cast<const T*>(p.B) + (int64_t)blockIdx.z * p.sB;
+    p.C = reinterpret_cast<char*>(p.C) + (int64_t)blockIdx.z * p.sC * (p.c_f32 ? 4 : (int)sizeof(T));
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -1111,8 +1113,8 @@ __global__ void gemm_colsum_final_kernel(const float* __restrict__ part, int npa
 }
 
 template <typename T, bool VEC>
-int launch(const GemmP& p, int ta, int tb, hipStream_t st) {
-    dim3 grid(p.tiles_m * p.tiles_n, p.split_k), block(NTHREADS);
+int launch(const GemmP& p, int ta, int tb, hipStream_t st, int batch = 1) {
+    dim3 grid(p.tiles_m * p.tiles_n, p.split_k, batch), block(NTHREADS);
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, VEC>), grid, block, 0, st, p);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, VEC>), grid, block, 0, st, p);
     else if (ta && tb) hipLaunchKernelGGL((gemm_kernel<T, true, true, VEC>), grid, block, 0, st, p);
@@ -1205,6 +1207,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     bool vec = aligned16(a->A) && aligned16(a->B) && (a->lda % ch == 0) && (a->ldb % ch == 0);
     vec = vec && (a->trans_a ? (a->M % ch == 0) : (a->K % ch == 0));
     vec = vec && (a->trans_b ? (a->N % ch == 0) : (a->K % ch == 0));
+    if (a->batch > 1) vec = vec && (a->stride_a % ch == 0) && (a->stride_b % ch == 0);
     // 4-wide epilogue accesses
     bool vc = (a->N % 4 == 0) && (a->ldc % 4 == 0) && (p.c_f32 ? aligned16(a->C) : aligned8(a->C));
     if (a->bias) vc = vc && aligned16(a->bias);
@@ -1213,7 +1216,13 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     if (a->aux_out) vc = vc && (a->ld_aux % 4 == 0) && aligned8(a->aux_out);
     if (es == 4) vc = vc && (!a->res || aligned16(a->res)) && (!a->aux_in || aligned16(a->aux_in)) &&
                       (!a->aux_out || aligned16(a->aux_out)) && aligned16(a->C);
+    if (a->batch > 1) vc = vc && (a->stride_c % 4 == 0);
     p.vec_c = vc ? 1 : 0;
+    const int batch = a->batch > 1 ? a->batch : 1;
+    p.sA = batch > 1 ? a->stride_a : 0; p.sB = batch > 1 ? a->stride_b : 0; p.sC = batch > 1 ? a->stride_c : 0;
+    if (batch > 1)
+        DEVIAS_REQUIRE(split == 1 && !a->colsum && !a->res && !a->aux_in && !a->aux_out && batch <= 65535,
+                       "devias_gemm: batched launches support bias / activation epilogues only (no split-K, residual, aux, colsum)");
     p.debug = kn.debug;
     p.epi_swap = kn.epi_swap;
     p.epi_vm = 16;
@@ -1230,14 +1239,14 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     p.vec16 = (v16 && a->dtype == DEVIAS_BF16) ? 1 : 0;
     bool big = kn.use256 && a->dtype == DEVIAS_BF16 && vec && vc && (a->M % T2 == 0) && (a->N % T2 == 0) && (a->K % 64 == 0) &&
                (p.k_per_split % 64 == 0);
-    big = big && v16;
+    big = big && v16 && batch == 1;
     // Kernel choice, measured on MI355X at the ViT-B shapes (M = 50176; tools/gemm_block_shapes.py, tools/ab_bench.py):
     //   * 256x256 two-stage LDS-DMA kernel (1 workgroup/CU): every shape it can tile, all four operand layouts; its persistent form
     //     (gemm256p_kernel) when there is more than one round of tiles, no split-K and a bf16 output (forward and dgrad GEMMs);
     //   * 256x128 single-stage kernel (2 workgroups/CU): N a multiple of 128 but not of 256;
     //   * 128x128 register-staged kernel: ragged / unaligned / fp32 shapes.
     bool ss = kn.use_ss != 0 && a->dtype == DEVIAS_BF16 && vec && v16 && (a->M % SS_BM == 0) && (a->N % SS_BN == 0) && (a->K % 64 == 0) &&
-              (p.k_per_split % 64 == 0);
+              (p.k_per_split % 64 == 0) && batch == 1;
     if (ss && big) {
         const bool nt = !a->trans_a && !a->trans_b;
         if (kn.use_ss < 0 || nt) ss = false;
@@ -1276,12 +1285,12 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
             devias_count(DEVIAS_CNT_GEMM256);
         }
     } else if (a->dtype == DEVIAS_BF16) {
-        if (vec) launch<bf16, true>(p, a->trans_a, a->trans_b, st);
-        else launch<bf16, false>(p, a->trans_a, a->trans_b, st);
+        if (vec) launch<bf16, true>(p, a->trans_a, a->trans_b, st, batch);
+        else launch<bf16, false>(p, a->trans_a, a->trans_b, st, batch);
         devias_count(DEVIAS_CNT_GEMM128_BF16);
     } else {
-        if (vec) launch<float, true>(p, a->trans_a, a->trans_b, st);
-        else launch<float, false>(p, a->trans_a, a->trans_b, st);
+        if (vec) launch<float, true>(p, a->trans_a, a->trans_b, st, batch);
+        else launch<float, false>(p, a->trans_a, a->trans_b, st, batch);
         devias_count(DEVIAS_CNT_GEMM128_F32);
     }
     DEVIAS_CHECK_LAUNCH("devias_gemm");

@@ -322,6 +322,273 @@ __global__ __launch_bounds__(256) void slot_kv_grad_kernel(const T* __restrict__
     }
 }
 
+// =========================================================================================================
+// Folded form (devias_slotf_*): the K and V projections are never materialised.
+//   sim[i,j] = scale * q_i . (Wk c_j) = scale * (Wk^T q_i) . c_j = scale * q'_i . c_j            q' = LN(x_s) (Wk_h^T Wq_h)^T   [B, S, h, D]
+//   o_i      = sum_j Abar[i,j] (Wv c_j) = Wv (sum_j Abar[i,j] c_j) = Wv z_i                      z  = sum_j Abar[i,j] c_j       [B, S, h, D]
+// (per head h; c = LayerNorm_ctx(features), D = embed dim).  Same arithmetic up to the association order of the sums; what changes is
+// the stream: every layer reads the D-wide context rows c (B*N*D elements, shared by the heads) instead of the 2*h*512-wide K|V rows,
+// and the [M, D] x [D, 2*h*512] projection GEMM with its dgrad and wgrad disappears -- the composite weights are D x D per head.
+// Kernel structure as above: a wave owns one token at a time, each lane EPL = D / 64 consecutive context dims, per-workgroup partials
+// reduced by a small finish kernel in a fixed order.  MAXS <= 4 (register budget); D in {384, 512, 768, 1024}.
+// =========================================================================================================
+template <typename T, int EPL> __device__ __forceinline__ void loadE(const T* p, float (&v)[EPL]);
+template <int EPL> __device__ __forceinline__ void loadE_bf16(const bf16* p, float (&v)[EPL]) {
+    if constexpr (EPL % 8 == 0) {
+#pragma unroll
+        for (int u = 0; u < EPL / 8; ++u) {
+            bf16x8 x = *reinterpret_cast<const bf16x8*>(p + 8 * u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[8 * u + e] = (float)x[e];
+        }
+    } else if constexpr (EPL % 4 == 0) {
+#pragma unroll
+        for (int u = 0; u < EPL / 4; ++u) {
+            bf16x4 x = *reinterpret_cast<const bf16x4*>(p + 4 * u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * u + e] = (float)x[e];
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < EPL / 2; ++u) {
+            bf16x2 x = *reinterpret_cast<const bf16x2*>(p + 2 * u);
+            v[2 * u] = (float)x[0]; v[2 * u + 1] = (float)x[1];
+        }
+    }
+}
+template <int EPL> __device__ __forceinline__ void loadE_f32(const float* p, float (&v)[EPL]) {
+    if constexpr (EPL % 4 == 0) {
+#pragma unroll
+        for (int u = 0; u < EPL / 4; ++u) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(p + 4 * u);
+            v[4 * u] = x[0]; v[4 * u + 1] = x[1]; v[4 * u + 2] = x[2]; v[4 * u + 3] = x[3];
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < EPL / 2; ++u) {
+            f32x2 x = *reinterpret_cast<const f32x2*>(p + 2 * u);
+            v[2 * u] = x[0]; v[2 * u + 1] = x[1];
+        }
+    }
+}
+template <typename T, int EPL> struct LoadE;
+template <int EPL> struct LoadE<bf16, EPL> { static __device__ __forceinline__ void run(const bf16* p, float (&v)[EPL]) { loadE_bf16<EPL>(p, v); } };
+template <int EPL> struct LoadE<float, EPL> { static __device__ __forceinline__ void run(const float* p, float (&v)[EPL]) { loadE_f32<EPL>(p, v); } };
+
+template <typename T, int MAXS, int EPL>
+__global__ __launch_bounds__(256) void slotf_fwd_kernel(const T* __restrict__ qp, const T* __restrict__ ctx, float* __restrict__ attn,
+                                                        float* __restrict__ ws_r, float* __restrict__ ws_z, int S, int N, int h, float scale) {
+    constexpr int D = 64 * EPL;
+    __shared__ __attribute__((aligned(16))) float sm_z[3][MAXS][D];
+    __shared__ float sm_r[3][MAXS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.y, b = bh / h, hh = bh % h, chunk = blockIdx.x, nchunks = gridDim.x;
+    float qv[MAXS][EPL], zacc[MAXS][EPL], rs[MAXS];
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+        if (i < S) LoadE<T, EPL>::run(qp + ((int64_t)b * S + i) * h * D + hh * D + lane * EPL, qv[i]);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { if (i >= S) qv[i][e] = 0.f; zacc[i][e] = 0.f; }
+        rs[i] = 0.f;
+    }
+    const int j0 = chunk * TCH, j1 = min(N, j0 + TCH);
+    for (int jj = j0 + wave * 2; jj < j1; jj += 8) {               // two tokens per wave iteration
+        const int ntok = min(2, j1 - jj);
+        float c8[2][EPL];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) LoadE<T, EPL>::run(ctx + ((int64_t)b * N + min(jj + u, j1 - 1)) * D + lane * EPL, c8[u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u >= ntok) break;
+            const int j = jj + u;
+            float sim[MAXS];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) {
+                if (i < S) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) d += qv[i][e] * c8[u][e];
+                    sim[i] = wave_sum(d) * scale;
+                    mx = fmaxf(mx, sim[i]);
+                }
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) if (i < S) { sim[i] = expf(sim[i] - mx); den += sim[i]; }
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) {
+                if (i < S) {
+                    const float a = sim[i] * inv;
+                    if (lane == 0) attn[((int64_t)bh * S + i) * N + j] = a;
+                    rs[i] += a;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) zacc[i][e] += a * c8[u][e];
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < MAXS; ++i) if (i < S) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) sm_z[wave - 1][i][lane * EPL + e] = zacc[i][e];
+            if (lane == 0) sm_r[wave - 1][i] = rs[i];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int64_t pb = (int64_t)bh * nchunks + chunk;
+#pragma unroll
+        for (int i = 0; i < MAXS; ++i) if (i < S) {
+            float r = rs[i];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) r += sm_r[w][i];
+            if (lane == 0) ws_r[pb * S + i] = r;
+            float* dst = ws_z + (pb * S + i) * D + lane * EPL;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                dst[e] = zacc[i][e] + sm_z[0][i][lane * EPL + e] + sm_z[1][i][lane * EPL + e] + sm_z[2][i][lane * EPL + e];
+        }
+    }
+}
+
+// finish: rsum[bh,i] = sum_chunks ws_r + 1e-7 ; z[b,i,hh*D+d] = sum_chunks ws_z / rsum
+template <typename T>
+__global__ void slotf_fwd_finish_kernel(const float* __restrict__ ws_r, const float* __restrict__ ws_z, float* __restrict__ rsum,
+                                        T* __restrict__ z, int S, int h, int D, int nchunks) {
+    const int bh = blockIdx.x / S, i = blockIdx.x % S, b = bh / h, hh = bh % h;
+    float r = 0.f;
+    for (int c = 0; c < nchunks; ++c) r += ws_r[((int64_t)bh * nchunks + c) * S + i];
+    r += 1e-7f;
+    if (threadIdx.x == 0) rsum[(int64_t)bh * S + i] = r;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < nchunks; ++c) s += ws_z[(((int64_t)bh * nchunks + c) * S + i) * D + d];
+        z[((int64_t)b * S + i) * h * D + hh * D + d] = from_f32<T>(s / r);
+    }
+}
+
+// backward of one layer: ds[bh,i,j] and per-chunk dq' partials.  delta_i = dz_i . z_i (= dO_i . o_i of the unfolded form)
+template <typename T, int MAXS, int EPL>
+__global__ __launch_bounds__(256) void slotf_bwd_kernel(const T* __restrict__ ctx, const float* __restrict__ attn, const float* __restrict__ rsum,
+                                                        const T* __restrict__ z, const T* __restrict__ dz, const float* __restrict__ dA_ext,
+                                                        float* __restrict__ ds_out, float* __restrict__ ws_q, int S, int N, int h, float scale) {
+    constexpr int D = 64 * EPL;
+    __shared__ __attribute__((aligned(16))) float sm_q[3][MAXS][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.y, b = bh / h, hh = bh % h, chunk = blockIdx.x, nchunks = gridDim.x;
+    float dzv[MAXS][EPL], dq[MAXS][EPL], dl[MAXS], rinv[MAXS];
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+        dl[i] = 0.f; rinv[i] = 0.f;
+        if (i < S) {
+            float zv[EPL];
+            const int64_t off = ((int64_t)b * S + i) * h * D + hh * D + lane * EPL;
+            LoadE<T, EPL>::run(dz + off, dzv[i]);
+            LoadE<T, EPL>::run(z + off, zv);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) d += dzv[i][e] * zv[e];
+            dl[i] = wave_sum(d);
+            rinv[i] = 1.0f / rsum[(int64_t)bh * S + i];
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { if (i >= S) dzv[i][e] = 0.f; dq[i][e] = 0.f; }
+    }
+    const int j0 = chunk * TCH, j1 = min(N, j0 + TCH);
+    for (int jj = j0 + wave * 2; jj < j1; jj += 8) {
+        const int ntok = min(2, j1 - jj);
+        float c8[2][EPL];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) LoadE<T, EPL>::run(ctx + ((int64_t)b * N + min(jj + u, j1 - 1)) * D + lane * EPL, c8[u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u >= ntok) break;
+            const int j = jj + u;
+            float a[MAXS], dA[MAXS];
+            float tsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) {
+                if (i < S) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) d += dzv[i][e] * c8[u][e];
+                    const float dAbar = wave_sum(d);
+                    a[i] = attn[((int64_t)bh * S + i) * N + j];
+                    dA[i] = (dAbar - dl[i]) * rinv[i] + (dA_ext ? dA_ext[((int64_t)bh * S + i) * N + j] : 0.f);
+                    tsum += a[i] * dA[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXS; ++i) {
+                if (i < S) {
+                    const float ds = a[i] * (dA[i] - tsum);
+                    if (lane == 0) ds_out[((int64_t)bh * S + i) * N + j] = ds;
+                    const float w = ds * scale;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) dq[i][e] += w * c8[u][e];
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < MAXS; ++i) if (i < S) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) sm_q[wave - 1][i][lane * EPL + e] = dq[i][e];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int64_t pb = (int64_t)bh * nchunks + chunk;
+#pragma unroll
+        for (int i = 0; i < MAXS; ++i) if (i < S) {
+            float* dst = ws_q + (pb * S + i) * D + lane * EPL;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                dst[e] = dq[i][e] + sm_q[0][i][lane * EPL + e] + sm_q[1][i][lane * EPL + e] + sm_q[2][i][lane * EPL + e];
+        }
+    }
+}
+
+template <typename T>
+__global__ void slotf_bwd_finish_kernel(const float* __restrict__ ws_q, T* __restrict__ dqp, int S, int h, int D, int nchunks) {
+    const int bh = blockIdx.x / S, i = blockIdx.x % S, b = bh / h, hh = bh % h;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < nchunks; ++c) s += ws_q[(((int64_t)bh * nchunks + c) * S + i) * D + d];
+        dqp[((int64_t)b * S + i) * h * D + hh * D + d] = from_f32<T>(s);
+    }
+}
+
+// Operands of the deferred context gradient of L stacked layers that share the context rows:
+//   dc[b, j, :] = sum over k = (l, w, hh, i) of coef[b][k][j] * vec[b][k][:]
+//     w = 0: coef = A_l[i,j] / rsum_l[i]   vec = dz_l[b,i,hh,:]        (from z = sum_j Abar c_j)
+//     w = 1: coef = scale * ds_l[i,j]      vec = q'_l[b,i,hh,:]        (from sim = scale q' . c_j)
+// i.e. one [N, K] x [K, D] product per clip (K = 2 L h S), run as a batched GEMM by the caller.  coef rows are padded to Np tokens (zeros).
+template <typename T>
+__global__ __launch_bounds__(256) void slotf_pack_kernel(const float* __restrict__ attn_stack, const float* __restrict__ rsum_stack,
+                                                         const float* __restrict__ ds_stack, const T* __restrict__ dz_stack,
+                                                         const T* __restrict__ qp_stack, T* __restrict__ coef, T* __restrict__ vec,
+                                                         int L, int B, int S, int N, int Np, int h, int D, float scale) {
+    const int K = 2 * L * h * S;
+    const int b = blockIdx.y, k = blockIdx.x;
+    const int i = k % S, hh = (k / S) % h, w = (k / (S * h)) % 2, l = k / (2 * S * h);
+    const int64_t row = ((int64_t)l * B * h + (int64_t)b * h + hh) * S + i;         // row of the [L, B*h, S, N] stacks
+    T* crow = coef + ((int64_t)b * K + k) * Np;
+    if (w == 0) {
+        const float rinv = 1.0f / rsum_stack[row];
+        for (int j = threadIdx.x; j < Np; j += 256) crow[j] = from_f32<T>(j < N ? attn_stack[row * N + j] * rinv : 0.f);
+    } else {
+        for (int j = threadIdx.x; j < Np; j += 256) crow[j] = from_f32<T>(j < N ? ds_stack[row * N + j] * scale : 0.f);
+    }
+    const T* src = (w == 0 ? dz_stack : qp_stack) + (((int64_t)l * B + b) * S + i) * h * D + (int64_t)hh * D;
+    T* vrow = vec + ((int64_t)b * K + k) * D;
+    for (int d = threadIdx.x; d < D; d += 256) vrow[d] = src[d];
+}
+
 }  // namespace
 
 extern "C" int64_t devias_slot_attn_workspace_bytes(int32_t B, int32_t S, int32_t N, int32_t h, int32_t dh) {
@@ -408,5 +675,96 @@ extern "C" int devias_slot_attn_kv_grad(const void* q_stack, const void* do_stac
         hipLaunchKernelGGL((slot_kv_grad_kernel<float>), grid, block, 0, st, (const float*)q_stack, (const float*)do_stack, ds_stack,
                            attn_stack, rsum_stack, (float*)dkv, L, B, S, N, h, scale);
     DEVIAS_CHECK_LAUNCH("devias_slot_attn_kv_grad");
+    return DEVIAS_OK;
+}
+
+
+// ---- folded form ----------------------------------------------------------------------------------------------------------------------------
+extern "C" int64_t devias_slotf_workspace_bytes(int32_t B, int32_t S, int32_t N, int32_t h, int32_t D) {
+    int nchunks = cdiv(N, TCH);
+    return (int64_t)B * h * nchunks * S * (D + 1) * 4 + 64;
+}
+
+#define SLOTF_CHECKS(name)                                                                                                  \
+    DEVIAS_REQUIRE(D == 384 || D == 512 || D == 768 || D == 1024, name ": context dim must be 384, 512, 768 or 1024, got %d", D); \
+    DEVIAS_REQUIRE(S >= 1 && S <= 4, name ": 1 <= num_latents <= 4 in the folded form, got %d", S);                          \
+    DEVIAS_REQUIRE(B > 0 && N > 0 && h > 0 && (int64_t)B * h <= 65535, name ": bad B/N/h");                                 \
+    DEVIAS_REQUIRE(dtype == DEVIAS_BF16 || dtype == DEVIAS_F32, name ": bad dtype %d", dtype)
+
+#define SLOTF_DISPATCH(KERNEL, TT, ...)                                                                  \
+    do {                                                                                                 \
+        if (S <= 2) {                                                                                    \
+            if (D == 384) hipLaunchKernelGGL((KERNEL<TT, 2, 6>), grid, block, 0, st, __VA_ARGS__);       \
+            else if (D == 512) hipLaunchKernelGGL((KERNEL<TT, 2, 8>), grid, block, 0, st, __VA_ARGS__);  \
+            else if (D == 768) hipLaunchKernelGGL((KERNEL<TT, 2, 12>), grid, block, 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<TT, 2, 16>), grid, block, 0, st, __VA_ARGS__);               \
+        } else {                                                                                         \
+            if (D == 384) hipLaunchKernelGGL((KERNEL<TT, 4, 6>), grid, block, 0, st, __VA_ARGS__);       \
+            else if (D == 512) hipLaunchKernelGGL((KERNEL<TT, 4, 8>), grid, block, 0, st, __VA_ARGS__);  \
+            else if (D == 768) hipLaunchKernelGGL((KERNEL<TT, 4, 12>), grid, block, 0, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<TT, 4, 16>), grid, block, 0, st, __VA_ARGS__);               \
+        }                                                                                                \
+    } while (0)
+
+extern "C" int devias_slotf_fwd(const void* qp, const void* ctx, float* attn, float* rsum, void* z, int32_t B, int32_t S, int32_t N,
+                                int32_t h, int32_t D, float scale, int32_t dtype, float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SLOTF_CHECKS("devias_slotf_fwd");
+    DEVIAS_REQUIRE(qp && ctx && attn && rsum && z && ws, "devias_slotf_fwd: null pointer");
+    DEVIAS_REQUIRE(aligned16(qp) && aligned16(ctx) && aligned16(z) && aligned16(ws), "devias_slotf_fwd: unaligned pointer");
+    const int nchunks = cdiv(N, TCH);
+    float* ws_r = ws;
+    float* ws_z = ws + (((int64_t)B * h * nchunks * S + 3) & ~(int64_t)3);
+    dim3 grid(nchunks, B * h), block(256);
+    if (dtype == DEVIAS_BF16) {
+        SLOTF_DISPATCH(slotf_fwd_kernel, bf16, (const bf16*)qp, (const bf16*)ctx, attn, ws_r, ws_z, S, N, h, scale);
+        DEVIAS_CHECK_LAUNCH("devias_slotf_fwd");
+        hipLaunchKernelGGL((slotf_fwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws_r, ws_z, rsum, (bf16*)z, S, h, D, nchunks);
+    } else {
+        SLOTF_DISPATCH(slotf_fwd_kernel, float, (const float*)qp, (const float*)ctx, attn, ws_r, ws_z, S, N, h, scale);
+        DEVIAS_CHECK_LAUNCH("devias_slotf_fwd");
+        hipLaunchKernelGGL((slotf_fwd_finish_kernel<float>), dim3(B * h * S), dim3(256), 0, st, ws_r, ws_z, rsum, (float*)z, S, h, D, nchunks);
+    }
+    DEVIAS_CHECK_LAUNCH("devias_slotf_fwd(finish)");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_slotf_bwd(const void* ctx, const float* attn, const float* rsum, const void* z, const void* dz,
+                                const float* d_attn_ext, void* dqp, float* ds, int32_t B, int32_t S, int32_t N, int32_t h, int32_t D,
+                                float scale, int32_t dtype, float* ws, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    SLOTF_CHECKS("devias_slotf_bwd");
+    DEVIAS_REQUIRE(ctx && attn && rsum && z && dz && dqp && ds && ws, "devias_slotf_bwd: null pointer");
+    DEVIAS_REQUIRE(aligned16(ctx) && aligned16(z) && aligned16(dz) && aligned16(dqp) && aligned16(ws), "devias_slotf_bwd: unaligned pointer");
+    const int nchunks = cdiv(N, TCH);
+    dim3 grid(nchunks, B * h), block(256);
+    if (dtype == DEVIAS_BF16) {
+        SLOTF_DISPATCH(slotf_bwd_kernel, bf16, (const bf16*)ctx, attn, rsum, (const bf16*)z, (const bf16*)dz, d_attn_ext, ds, ws, S, N, h, scale);
+        DEVIAS_CHECK_LAUNCH("devias_slotf_bwd");
+        hipLaunchKernelGGL((slotf_bwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws, (bf16*)dqp, S, h, D, nchunks);
+    } else {
+        SLOTF_DISPATCH(slotf_bwd_kernel, float, (const float*)ctx, attn, rsum, (const float*)z, (const float*)dz, d_attn_ext, ds, ws, S, N, h, scale);
+        DEVIAS_CHECK_LAUNCH("devias_slotf_bwd");
+        hipLaunchKernelGGL((slotf_bwd_finish_kernel<float>), dim3(B * h * S), dim3(256), 0, st, ws, (float*)dqp, S, h, D, nchunks);
+    }
+    DEVIAS_CHECK_LAUNCH("devias_slotf_bwd(finish)");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_slotf_pack(const float* attn_stack, const float* rsum_stack, const float* ds_stack, const void* dz_stack,
+                                 const void* qp_stack, void* coef, void* vec, int32_t L, int32_t B, int32_t S, int32_t N, int32_t Np,
+                                 int32_t h, int32_t D, float scale, int32_t dtype, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(attn_stack && rsum_stack && ds_stack && dz_stack && qp_stack && coef && vec, "devias_slotf_pack: null pointer");
+    DEVIAS_REQUIRE(L >= 1 && B > 0 && B <= 65535 && S >= 1 && N > 0 && Np >= N && h > 0 && D > 0, "devias_slotf_pack: bad dims");
+    DEVIAS_REQUIRE(dtype == DEVIAS_BF16 || dtype == DEVIAS_F32, "devias_slotf_pack: bad dtype %d", dtype);
+    dim3 grid(2 * L * h * S, B), block(256);
+    if (dtype == DEVIAS_BF16)
+        hipLaunchKernelGGL((slotf_pack_kernel<bf16>), grid, block, 0, st, attn_stack, rsum_stack, ds_stack, (const bf16*)dz_stack,
+                           (const bf16*)qp_stack, (bf16*)coef, (bf16*)vec, L, B, S, N, Np, h, D, scale);
+    else
+        hipLaunchKernelGGL((slotf_pack_kernel<float>), grid, block, 0, st, attn_stack, rsum_stack, ds_stack, (const float*)dz_stack,
+                           (const float*)qp_stack, (float*)coef, (float*)vec, L, B, S, N, Np, h, D, scale);
+    DEVIAS_CHECK_LAUNCH("devias_slotf_pack");
     return DEVIAS_OK;
 }

@@ -457,6 +457,159 @@ class AggBlockFn(Function):
         return (dx, dnorm_w, dnorm_b, dlatents, dlast_w, dlast_b, None, *flat)
 
 
+# ---- folded aggregation block -------------------------------------------------------------------------------------------------------------
+# sim = scale (Wk_h^T q) . c_j and o = Wv_h sum_j Abar c_j: the to_k / to_v projections move to the slot side (composite D x D weights per head,
+# built once per forward), the per-layer stream is the context c [M, D] instead of K|V [M, 2*h*512], and the K|V GEMM + its dgrad + wgrad vanish
+# (csrc/slot_attn.hip "folded form").  Same parameters, same outputs, same gradients; summation order differs (fp32 round-off).
+_AGG_FOLD = _os.environ.get("DEVIAS_AGG_FOLD", "1") != "0"
+
+
+def _composites(P, heads, dh, D, cdt):
+    """Wqk [h*D, D] (Wqk_h = Wk_h^T Wq_h) and Wov [D, h*D] (Wov_h = Wo_h Wv_h) in the compute dtype, + the operands for their backward"""
+    Wq, Wk, Wv, Wo = (_WCACHE.get(P[k], cdt) for k in ("to_q", "to_k", "to_v", "to_out_w"))
+    inner = heads * dh
+    Wqk = torch.empty((heads * D, D), dtype=cdt, device=Wq.device)
+    ops.gemm_batched(Wk, Wq, Wqk, D, D, dh, lda=D, ldb=D, ldc=D, stride_a=dh * D, stride_b=dh * D, stride_c=D * D, batch=heads,
+                     trans_a=True, trans_b=True)
+    Wov = torch.empty((D, heads * D), dtype=cdt, device=Wq.device)
+    ops.gemm_batched(Wo, Wv, Wov, D, D, dh, lda=inner, ldb=D, ldc=heads * D, stride_a=dh, stride_b=dh * D, stride_c=D, batch=heads,
+                     trans_b=True)
+    return Wqk, Wov, (Wq, Wk, Wv, Wo)
+
+
+def _composite_grads(dWqk, dWov, W4, heads, dh, D, cdt):
+    """gradients of to_q / to_k / to_v / to_out.weight (fp32) from those of the composites (fp32 accumulators over the layers)"""
+    Wq, Wk, Wv, Wo = W4
+    inner = heads * dh
+    dev = Wq.device
+    gqk = dWqk if cdt == torch.float32 else ops.cast(dWqk, cdt)
+    gov = dWov if cdt == torch.float32 else ops.cast(dWov, cdt)
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)          # noqa: E731
+    dWq, dWk, dWv, dWo = f(inner, D), f(inner, D), f(inner, D), f(D, inner)
+    ops.gemm_batched(Wk, gqk, dWq, dh, D, D, lda=D, ldb=D, ldc=D, stride_a=dh * D, stride_b=D * D, stride_c=dh * D, batch=heads, trans_b=True)
+    ops.gemm_batched(Wq, gqk, dWk, dh, D, D, lda=D, ldb=D, ldc=D, stride_a=dh * D, stride_b=D * D, stride_c=dh * D, batch=heads)
+    ops.gemm_batched(gov, Wv, dWo, D, dh, D, lda=heads * D, ldb=D, ldc=inner, stride_a=D, stride_b=dh * D, stride_c=dh, batch=heads)
+    ops.gemm_batched(Wo, gov, dWv, dh, D, D, lda=inner, ldb=heads * D, ldc=D, stride_a=dh, stride_b=D, stride_c=dh * D, batch=heads,
+                     trans_a=True, trans_b=True)
+    return dWq, dWk, dWv, dWo
+
+
+class AggBlockFoldFn(Function):
+    """encoder output -> final LN -> AggregationBlock (folded slot attention) -> (slots [B*S, D], attn [B*h, S, N] fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, latents, last_w, last_b, meta, *layer_params):
+        B, N, S, depth, tied, heads, dh, eps_enc, eps_agg, cdt = meta
+        nset = 1 if tied else depth
+        assert len(layer_params) == nset * len(_LAYER_KEYS)
+        LP = [dict(zip(_LAYER_KEYS, layer_params[i * 15:(i + 1) * 15])) for i in range(nset)]
+        scale = dh ** -0.5
+        dev = x.device
+        D = x.shape[1]
+        feats, m0, r0 = ops.layernorm_fwd(x, _f32(norm_w), _f32(norm_b), eps_enc)        # modeling_slot.py:373
+        sets = []
+        for P in LP:                                                                      # context LayerNorm + composite weights, once per weight set
+            c, mc, rc = ops.layernorm_fwd(feats, _f32(P["ctx_w"]), _f32(P["ctx_b"]), eps_agg)
+            Wqk, Wov, W4 = _composites(P, heads, dh, D, cdt)
+            sets.append((c, mc, rc, Wqk, Wov, W4))
+        xs = ops.rows_broadcast(_f32(latents), B * S, cdt)                                # agg_block.py:112-114
+        qp_stack = torch.empty((depth, B * S, heads * D), dtype=cdt, device=dev)
+        attn_stack = torch.empty((depth, B * heads, S, N), dtype=torch.float32, device=dev)
+        rsum_stack = torch.empty((depth, B * heads, S), dtype=torch.float32, device=dev)
+        layers = []
+        for l in range(depth):
+            si = 0 if tied else l
+            P = LP[si]
+            c, _, _, Wqk, Wov, _ = sets[si]
+            W1, W2 = (_WCACHE.get(P[k], cdt) for k in ("ff0_w", "ff3_w"))
+            qn, mq, rq = ops.layernorm_fwd(xs, _f32(P["norm_w"]), _f32(P["norm_b"]), eps_agg)
+            qp = ops.gemm(qn, Wqk, out=qp_stack[l])
+            _, _, z = ops.slotf_fwd(qp, c, B, S, N, heads, D, scale, attn_out=attn_stack[l], rsum_out=rsum_stack[l])
+            xs1 = ops.gemm(z, Wov, bias=_f32(P["to_out_b"]), res=xs)
+            f, mf, rf = ops.layernorm_fwd(xs1, _f32(P["ffn_w"]), _f32(P["ffn_b"]), eps_agg)
+            fpre = torch.empty((B * S, W1.shape[0]), dtype=cdt, device=dev)
+            fact = ops.gemm(f, W1, bias=_f32(P["ff0_b"]), act=ACT_GELU, aux_out=fpre)
+            xs2 = ops.gemm(fact, W2, bias=_f32(P["ff3_b"]), res=xs1)
+            layers.append((xs, mq, rq, qn, z, xs1, mf, rf, f, fpre, fact, W1, W2))
+            xs = xs2
+        slots, ml, rl = ops.layernorm_fwd(xs, _f32(last_w), _f32(last_b), eps_agg)
+        ctx.meta = meta
+        ctx.saved = (x, m0, r0, feats, sets, layers, qp_stack, attn_stack, rsum_stack, xs, ml, rl,
+                     _f32(norm_w), _f32(last_w), [{k: _f32(P[k]) for k in ("norm_w", "ctx_w", "ffn_w")} for P in LP])
+        return slots, attn_stack[depth - 1]
+
+    @staticmethod
+    def backward(ctx, dslots, dattn):
+        B, N, S, depth, tied, heads, dh, eps_enc, eps_agg, cdt = ctx.meta
+        (x, m0, r0, feats, sets, layers, qp_stack, attn_stack, rsum_stack, xs_last, ml, rl, norm_w, last_w, LNW) = ctx.saved
+        ctx.saved = None
+        nset = 1 if tied else depth
+        scale = dh ** -0.5
+        dev = x.device
+        D = x.shape[1]
+        G = [dict() for _ in range(nset)]        # gradient accumulators per distinct weight set
+
+        def acc_w(si, key, dY, X):
+            if key in G[si]:
+                ops.wgrad(dY, X, out=G[si][key], beta=1.0)
+            else:
+                G[si][key] = ops.wgrad(dY, X)
+
+        def acc_b(si, key, dY):
+            if key in G[si]:
+                ops.colsum(dY, out=G[si][key], beta=1.0)
+            else:
+                G[si][key] = ops.colsum(dY)
+
+        def ln_bwd(si, kw, kb, dy, xin, gamma, mean, rstd, dres):
+            if kw in G[si]:
+                dxo, _, _ = ops.layernorm_bwd(dy, xin, gamma, mean, rstd, dres=dres, dgamma=G[si][kw], dbeta=G[si][kb], beta_acc=1.0)
+            else:
+                dxo, G[si][kw], G[si][kb] = ops.layernorm_bwd(dy, xin, gamma, mean, rstd, dres=dres)
+            return dxo
+
+        dxs, dlast_w, dlast_b = ops.layernorm_bwd(dslots.contiguous(), xs_last, last_w, ml, rl)
+        dz_stack = torch.empty((depth, B * S, heads * D), dtype=cdt, device=dev)
+        ds_stack = torch.empty((depth, B * heads, S, N), dtype=torch.float32, device=dev)
+        dattn_ext = dattn.contiguous() if dattn is not None else None
+        for l in reversed(range(depth)):
+            si = 0 if tied else l
+            (xs_in, mq, rq, qn, z, xs1, mf, rf, f, fpre, fact, W1, W2) = layers[l]
+            c, _, _, Wqk, Wov, _ = sets[si]
+            # feed-forward: xs2 = xs1 + W2 gelu(W1 LN(xs1) + b1) + b2
+            dfpre = ops.gemm(dxs, W2, trans_b=True, act=ACT_DGELU, aux_in=fpre)
+            acc_w(si, "ff3_w", dxs, fact); acc_b(si, "ff3_b", dxs)
+            df = ops.gemm(dfpre, W1, trans_b=True)
+            acc_w(si, "ff0_w", dfpre, f); acc_b(si, "ff0_b", dfpre)
+            dxs1 = ln_bwd(si, "ffn_w", "ffn_b", df, xs1, LNW[si]["ffn_w"], mf, rf, dxs)
+            # cross attention: xs1 = xs + Wov z + bo
+            dz = ops.gemm(dxs1, Wov, trans_b=True, out=dz_stack[l])
+            acc_w(si, "Wov", dxs1, z); acc_b(si, "to_out_b", dxs1)
+            dqp, _ = ops.slotf_bwd(c, attn_stack[l], rsum_stack[l], z, dz, dattn_ext if l == depth - 1 else None,
+                                   B, S, N, heads, D, scale, ds_out=ds_stack[l])
+            dqn = ops.gemm(dqp, Wqk, trans_b=True)
+            acc_w(si, "Wqk", dqp, qn)
+            dxs = ln_bwd(si, "norm_w", "norm_b", dqn, xs_in, LNW[si]["norm_w"], mq, rq, dxs1)
+        dlatents = ops.rows_reduce_mod(dxs, S)
+        # deferred context gradient: one pass per distinct context over all the layers that used it; composite -> parameter gradients
+        dfeats = None
+        for si in range(nset):
+            c, mc, rc, Wqk, Wov, W4 = sets[si]
+            sl = slice(0, depth) if tied else slice(si, si + 1)
+            nl = depth if tied else 1
+            dc = ops.slotf_context_grad(attn_stack[sl], rsum_stack[sl], ds_stack[sl], dz_stack[sl], qp_stack[sl], nl, B, S, N, heads, D, scale)
+            G[si]["to_q"], G[si]["to_k"], G[si]["to_v"], G[si]["to_out_w"] = _composite_grads(G[si].pop("Wqk"), G[si].pop("Wov"), W4, heads, dh, D, cdt)
+            dfeats_i, G[si]["ctx_w"], G[si]["ctx_b"] = ops.layernorm_bwd(dc, feats, LNW[si]["ctx_w"], mc, rc, dres=dfeats)
+            dfeats = dfeats_i
+        dxs = torch.empty((x.shape[1],), dtype=torch.float32, device=dev)
+        dx, dnorm_w, dnorm_b = ops.layernorm_bwd(dfeats, x, norm_w, m0, r0, dx_colsum=dxs)
+        _publish_colsum(dx, dxs)
+        flat = []
+        for si in range(nset):
+            flat += [G[si][k] for k in _LAYER_KEYS]
+        return (dx, dnorm_w, dnorm_b, dlatents, dlast_w, dlast_b, None, *flat)
+
+
 class HeadFn(Function):
     """slots -> (slots_head = head(slots), mask_predictions = MaskPredictor(slots))  (modeling_slot.py:392-393, 209-216)"""
 
@@ -774,8 +927,9 @@ class VisionTransformer(nn.Module):
         ab = self.agg_block
         S = ab.num_latents
         meta = (B, N, S, ab.depth, ab.weight_tie_layers, ab.heads, ab.dim_head, self.norm.eps, ab.last_layer[0].eps, cdt)
-        slots, attn = AggBlockFn.apply(h, self.norm.weight, self.norm.bias, ab.latents, ab.last_layer[0].weight,
-                                       ab.last_layer[0].bias, meta, *ab.layer_params())
+        fold = _AGG_FOLD and S <= 4 and D in (384, 512, 768, 1024)
+        slots, attn = (AggBlockFoldFn if fold else AggBlockFn).apply(h, self.norm.weight, self.norm.bias, ab.latents, ab.last_layer[0].weight,
+                                                                      ab.last_layer[0].bias, meta, *ab.layer_params())
         if self.slot_matching_method == 'hard_select':
             raise NotImplementedError("only slot_matching_method='matching' is on the DEVIAS training path "
                                       "(the reference's hard_select branch returns empty lists, modeling_slot.py:388)")

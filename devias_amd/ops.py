@@ -336,6 +336,73 @@ def slot_attn_kv_grad(q_stack, do_stack, ds_stack, attn_stack, rsum_stack, L, B,
     return dkv
 
 
+def gemm_batched(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, *, lda: int, ldb: int, ldc: int,
+                 stride_a: int, stride_b: int, stride_c: int, batch: int, trans_a: bool = False, trans_b: bool = False,
+                 a_off: int = 0, b_off: int = 0, c_off: int = 0) -> torch.Tensor:
+    """`batch` independent C_i[M,N] = op(A_i) @ op(B_i) in one launch (devias_gemm with batch > 1): problem i reads A + a_off + i*stride_a ...
+    (element offsets / strides into the given tensors, which only supply base pointers and dtypes).  C may be fp32 with bf16 operands."""
+    _chk(A, "gemm_batched.A"); _chk(B, "gemm_batched.B", A.dtype); _chk(C, "gemm_batched.C")
+    if C.dtype not in (A.dtype, torch.float32):
+        raise TypeError("gemm_batched: C must have the operand dtype or float32")
+    a = _lib.GemmArgs()
+    es, ec = A.element_size(), C.element_size()
+    a.A, a.B, a.C = A.data_ptr() + a_off * es, B.data_ptr() + b_off * es, C.data_ptr() + c_off * ec
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldb, a.ldc = lda, ldb, ldc
+    a.trans_a, a.trans_b = int(trans_a), int(trans_b)
+    a.dtype = dt_code(A.dtype)
+    a.c_f32 = int(C.dtype == torch.float32)
+    a.split_k = 1
+    a.batch, a.stride_a, a.stride_b, a.stride_c = batch, stride_a, stride_b, stride_c
+    _lib.check(_lib.load().devias_gemm(ctypes.byref(a), _stream()), "devias_gemm(batched)")
+    return C
+
+
+def slotf_fwd(qp, ctx, B, S, N, h, D, scale, attn_out=None, rsum_out=None):
+    """folded slot attention forward (devias_slotf_fwd): qp [B*S, h*D], ctx [B*N, D] -> attn fp32 [B*h,S,N], rsum fp32 [B*h,S], z [B*S, h*D]"""
+    _chk(qp, "slotf_fwd.qp"); _chk(ctx, "slotf_fwd.ctx", qp.dtype)
+    dev = qp.device
+    attn = attn_out if attn_out is not None else torch.empty((B * h, S, N), dtype=torch.float32, device=dev)
+    rsum = rsum_out if rsum_out is not None else torch.empty((B * h, S), dtype=torch.float32, device=dev)
+    z = torch.empty((B * S, h * D), dtype=qp.dtype, device=dev)
+    ws = workspace(_lib.load().devias_slotf_workspace_bytes(B, S, N, h, D), dev)
+    _lib.check(_lib.load().devias_slotf_fwd(qp.data_ptr(), ctx.data_ptr(), attn.data_ptr(), rsum.data_ptr(), z.data_ptr(), B, S, N, h, D,
+                                            scale, dt_code(qp.dtype), ws.data_ptr(), _stream()), "devias_slotf_fwd")
+    return attn, rsum, z
+
+
+def slotf_bwd(ctx, attn, rsum, z, dz, d_attn_ext, B, S, N, h, D, scale, ds_out=None):
+    _chk(ctx, "slotf_bwd.ctx"); _chk(z, "slotf_bwd.z", ctx.dtype); _chk(dz, "slotf_bwd.dz", ctx.dtype)
+    dev = ctx.device
+    dqp = torch.empty((B * S, h * D), dtype=ctx.dtype, device=dev)
+    ds = ds_out if ds_out is not None else torch.empty((B * h, S, N), dtype=torch.float32, device=dev)
+    if d_attn_ext is not None:
+        _chk(d_attn_ext, "slotf_bwd.d_attn_ext", torch.float32)
+    ws = workspace(_lib.load().devias_slotf_workspace_bytes(B, S, N, h, D), dev)
+    _lib.check(_lib.load().devias_slotf_bwd(ctx.data_ptr(), attn.data_ptr(), rsum.data_ptr(), z.data_ptr(), dz.data_ptr(), _p(d_attn_ext),
+                                            dqp.data_ptr(), ds.data_ptr(), B, S, N, h, D, scale, dt_code(ctx.dtype), ws.data_ptr(), _stream()),
+               "devias_slotf_bwd")
+    return dqp, ds
+
+
+def slotf_context_grad(attn_stack, rsum_stack, ds_stack, dz_stack, qp_stack, L, B, S, N, h, D, scale):
+    """dc [B*N, D] of L stacked folded layers that share the context rows: devias_slotf_pack + one batched [N,K] x [K,D] GEMM per clip"""
+    for t, n in ((attn_stack, "attn_stack"), (rsum_stack, "rsum_stack"), (ds_stack, "ds_stack"), (dz_stack, "dz_stack"), (qp_stack, "qp_stack")):
+        _chk(t, "slotf_context_grad." + n)
+    dt, dev = qp_stack.dtype, qp_stack.device
+    K = 2 * L * h * S
+    Np = (N + 7) // 8 * 8
+    coef = torch.empty((B, K, Np), dtype=dt, device=dev)
+    vec = torch.empty((B, K, D), dtype=dt, device=dev)
+    _lib.check(_lib.load().devias_slotf_pack(attn_stack.data_ptr(), rsum_stack.data_ptr(), ds_stack.data_ptr(), dz_stack.data_ptr(),
+                                             qp_stack.data_ptr(), coef.data_ptr(), vec.data_ptr(), L, B, S, N, Np, h, D, scale, dt_code(dt),
+                                             _stream()), "devias_slotf_pack")
+    dc = torch.empty((B * N, D), dtype=dt, device=dev)
+    gemm_batched(coef, vec, dc, N, D, K, lda=Np, ldb=D, ldc=D, stride_a=K * Np, stride_b=K * D, stride_c=N * D, batch=B,
+                 trans_a=True, trans_b=True)
+    return dc
+
+
 def slot_select(slots_head: torch.Tensor, B: int, S: int, nb: int) -> torch.Tensor:
     _chk(slots_head, "slot_select.slots_head")
     C = slots_head.shape[-1]

@@ -104,6 +104,10 @@ typedef struct {
     const float* row_scale;   /* optional fp32 [ceil(M / rows_per_scale)]: (acc + bias, act) *= row_scale[m / rows_per_scale] BEFORE the residual
                                  add -- timm drop_path (stochastic depth, modeling_slot.py:36-47,150-151): 0 or 1/keep per sample */
     int32_t rows_per_scale;
+    int32_t batch;            /* > 1: `batch` independent problems of the same shape in one launch; problem i uses A + i*stride_a, B + i*stride_b,
+                                 C + i*stride_c (element strides).  bias / activation epilogues only (no split_k, res, aux, colsum).  Used for the
+                                 per-head composite slot-attention weights and the per-clip context gradient of the folded slot attention. */
+    int64_t stride_a, stride_b, stride_c;
 } devias_gemm_args;
 int devias_gemm(const devias_gemm_args* args, void* stream);
 /* bytes of workspace devias_gemm needs for the given split_k (0 when split_k <= 1) */
@@ -192,6 +196,25 @@ int devias_slot_attn_kv_grad(const void* q_stack, const void* do_stack, const fl
                              const float* rsum_stack, void* dkv, int32_t L, int32_t B, int32_t S, int32_t N,
                              int32_t h, int32_t dh, float scale, int32_t dtype, void* stream);
 int64_t devias_slot_attn_workspace_bytes(int32_t B, int32_t S, int32_t N, int32_t h, int32_t dh);
+
+/* Folded slot cross-attention (same reference lines as devias_slot_attn_*: agg_block/attention.py:120-141): the to_k / to_v projections are
+ * folded into the slot side, sim = scale * (Wk_h^T q) . c_j and o = Wv_h (sum_j Abar c_j), so the kernels stream the context rows
+ * c = LayerNorm_ctx(features) [B*N, D] once per layer instead of K|V [B*N, 2*h*512], and no [M,D]x[D,2*h*512] GEMM exists.
+ *   qp  T [B*S, h*D]  = LN(x_s) Wqk^T,  Wqk_h = Wk_h^T Wq_h  (composite weights built by the caller with batched devias_gemm)
+ *   z   T [B*S, h*D]  = sum_j Abar[b,h,s,j] c[b,j,:]   (out = z Wov^T + b_o, Wov_h = Wo_h Wv_h)
+ *   attn fp32 [B*h, S, N] (softmax over the slot axis, the tensor the reference returns), rsum fp32 [B*h, S] = sum_j attn + 1e-7
+ * backward: dqp T [B*S, h*D], ds fp32 [B*h, S, N]; d_attn_ext (optional) = gradient arriving on the returned attention (last layer).
+ * devias_slotf_pack builds, for L stacked layers sharing the context, coef T [B][K][Np] and vec T [B][K][D] (K = 2*L*h*S, Np >= N, zero padded)
+ * such that the context gradient of clip b is coef[b]^T vec[b]  ([N,K] x [K,D]: one batched devias_gemm).  S <= 4, D in {384,512,768,1024}. */
+int devias_slotf_fwd(const void* qp, const void* ctx, float* attn, float* rsum, void* z, int32_t B, int32_t S, int32_t N,
+                     int32_t h, int32_t D, float scale, int32_t dtype, float* ws, void* stream);
+int devias_slotf_bwd(const void* ctx, const float* attn, const float* rsum, const void* z, const void* dz,
+                     const float* d_attn_ext, void* dqp, float* ds, int32_t B, int32_t S, int32_t N, int32_t h, int32_t D,
+                     float scale, int32_t dtype, float* ws, void* stream);
+int devias_slotf_pack(const float* attn_stack, const float* rsum_stack, const float* ds_stack, const void* dz_stack,
+                      const void* qp_stack, void* coef, void* vec, int32_t L, int32_t B, int32_t S, int32_t N, int32_t Np,
+                      int32_t h, int32_t D, float scale, int32_t dtype, void* stream);
+int64_t devias_slotf_workspace_bytes(int32_t B, int32_t S, int32_t N, int32_t h, int32_t D);
 
 /* ---------------------------------------------------------------------------------------------------
  * Slot selection (modeling_slot.py:395-406): p = softmax(slots_head); i_act[b] = argmax_s max_{c<nb} p[b,s,c];

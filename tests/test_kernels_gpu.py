@@ -542,3 +542,60 @@ def test_mhsa_bwd_single_pass_full_size_under_load(attn_options):
     o.set_option("attn_bwd", 0)
     two = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale)
     assert rel(ref.float(), two.float()) < 1.5e-2
+
+
+# ------------------------------------------------------------------------------------------------ folded slot attention
+def _slotf_ref(qp, c, B, S, N, h, D, scale):
+    q = qp.reshape(B, S, h, D).permute(0, 2, 1, 3)                    # [B,h,S,D]
+    sim = torch.einsum("bhsd,bnd->bhsn", q, c.reshape(B, N, D)) * scale
+    A = sim.softmax(dim=2)
+    r = A.sum(-1, keepdim=True) + 1e-7
+    z = torch.einsum("bhsn,bnd->bhsd", A / r, c.reshape(B, N, D)).permute(0, 2, 1, 3).reshape(B * S, h * D)
+    return A.reshape(B * h, S, N), r.reshape(B * h, S), z
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,S,N,h,D", [(2, 2, 100, 4, 768), (1, 4, 784, 2, 384), (3, 3, 65, 1, 1024), (2, 2, 196, 4, 512)])
+def test_slot_attention_folded(dtype, B, S, N, h, D):
+    """devias_slotf_fwd / _bwd / _pack + the batched context-gradient GEMM against autograd of the folded formula (fp32 torch), including
+    the gradient arriving on the returned attention; ragged token counts (N % 8 != 0 -> padded coefficient rows, scalar GEMM path)"""
+    o = ops()
+    scale = 512 ** -0.5
+    qp = rnd(B * S, h * D, dtype=dtype, seed=60)
+    c = rnd(B * N, D, dtype=dtype, seed=61)
+    A, r, z = o.slotf_fwd(qp, c, B, S, N, h, D, scale)
+    qr, cr = qp.float().clone().requires_grad_(True), c.float().clone().requires_grad_(True)
+    Ar, rr, zr = _slotf_ref(qr, cr, B, S, N, h, D, scale)
+    assert rel(A, Ar) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert rel(r, rr) < 1e-4 and rel(z.float(), zr) < (2e-5 if dtype == torch.float32 else 2e-2)
+    dz = rnd(B * S, h * D, dtype=dtype, seed=62)
+    dA = rnd(B * h, S, N, seed=63) * 0.01
+    (zr * dz.float()).sum().add((Ar * dA).sum()).backward()
+    dqp, ds = o.slotf_bwd(c, A, r, z, dz, dA, B, S, N, h, D, scale)
+    assert rel(dqp.float(), qr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    dc = o.slotf_context_grad(A.unsqueeze(0).contiguous(), r.unsqueeze(0).contiguous(), ds.unsqueeze(0).contiguous(),
+                              dz.unsqueeze(0).contiguous(), qp.unsqueeze(0).contiguous(), 1, B, S, N, h, D, scale)
+    assert rel(dc.float(), cr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_batched_layouts(dtype):
+    """batch > 1 launches of devias_gemm (128x128 kernel, blockIdx.z): the four strided shapes the folded slot attention uses"""
+    o = ops()
+    h, dh, D = 4, 512, 384
+    Wq, Wk, Wv = (rnd(h * dh, D, dtype=dtype, scale=0.05, seed=70 + i) for i in range(3))
+    Wo = rnd(D, h * dh, dtype=dtype, scale=0.05, seed=73)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    Wqk = torch.empty(h * D, D, dtype=dtype, device=DEV)
+    o.gemm_batched(Wk, Wq, Wqk, D, D, dh, lda=D, ldb=D, ldc=D, stride_a=dh * D, stride_b=dh * D, stride_c=D * D, batch=h, trans_a=True, trans_b=True)
+    ref = torch.cat([Wk.float()[i * dh:(i + 1) * dh].t() @ Wq.float()[i * dh:(i + 1) * dh] for i in range(h)])
+    assert rel(Wqk.float(), ref) < tol
+    Wov = torch.empty(D, h * D, dtype=dtype, device=DEV)
+    o.gemm_batched(Wo, Wv, Wov, D, D, dh, lda=h * dh, ldb=D, ldc=h * D, stride_a=dh, stride_b=dh * D, stride_c=D, batch=h, trans_b=True)
+    ref = torch.cat([Wo.float()[:, i * dh:(i + 1) * dh] @ Wv.float()[i * dh:(i + 1) * dh] for i in range(h)], dim=1)
+    assert rel(Wov.float(), ref) < tol
+    g = rnd(h * D, D, dtype=dtype, seed=74)
+    dWk = torch.empty(h * dh, D, dtype=torch.float32, device=DEV)
+    o.gemm_batched(Wq, g, dWk, dh, D, D, lda=D, ldb=D, ldc=D, stride_a=dh * D, stride_b=D * D, stride_c=dh * D, batch=h)
+    ref = torch.cat([Wq.float()[i * dh:(i + 1) * dh] @ g.float()[i * D:(i + 1) * D].t() for i in range(h)])
+    assert rel(dWk, ref) < tol
