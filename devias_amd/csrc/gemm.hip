@@ -1271,7 +1271,10 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         const int ta = a->trans_a, tb = a->trans_b;
         const int nt = p.tiles_m * p.tiles_n;
         const int gp = kn.ncu & ~7;
-        if (kn.persistent && !ta && split == 1 && !p.c_f32 && p.epi_swap && gp >= 8 && nt > gp) {
+        // persistent form: measured per shape at M = 50176 (tools/gemm_block_shapes.py, same box): NT qkv 226 -> 205 us, fc1 (bias only) 278 -> 250,
+        // the other NT shapes unchanged; the k-strided-B (dgrad) shapes of the step are 2-3 % SLOWER in it (dfc1 257 -> 263, dqkv 197 -> 204,
+        // dfc2+dGELU 408 -> 415) -> option gemm_persistent: 1 = NT only (default), 2 = NT and NN, 0 = never
+        if (kn.persistent && (!tb || kn.persistent >= 2) && !ta && split == 1 && !p.c_f32 && p.epi_swap && gp >= 8 && nt > gp) {
             dim3 grid(gp), block(NT2);
             if (!tb) hipLaunchKernelGGL((gemm256p_kernel<false>), grid, block, 0, st, p);
             else hipLaunchKernelGGL((gemm256p_kernel<true>), grid, block, 0, st, p);

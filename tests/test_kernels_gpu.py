@@ -424,7 +424,7 @@ def test_gemm_persistent_kernel(tb, epi, M, N, K, gemm_options):
         kw = dict(act=ACT_DGELU, aux_in=pre); ref = ref * dg
     outs = {}
     for mode in ("p", "0", "0s"):                          # persistent; one tile per workgroup, register-transposed epilogue; LDS-staged epilogue
-        o.set_option("gemm_persistent", 1 if mode == "p" else 0)
+        o.set_option("gemm_persistent", 2 if mode == "p" else 0)      # 2: persistent for both B layouts
         o.set_option("gemm_epi", 0 if mode.endswith("s") else 1)
         kw2 = dict(kw)
         if epi == "gelu_aux":
@@ -461,7 +461,7 @@ def test_gemm_persistent_kernel_repeatable(gemm_options):
     o.set_option("gemm_persistent", 0)
     ref_nt = o.gemm(A, W, bias=bias, res=res)
     ref_nn = o.gemm(A, Wt, trans_b=True)
-    o.set_option("gemm_persistent", 1)
+    o.set_option("gemm_persistent", 2)
     junk = torch.empty(64 << 20, device=DEV)
     side = torch.cuda.Stream()
     for it in range(30):
