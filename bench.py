@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary full-step number (teacher fwd + AdamW)")
+    ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce (N > 1)")
     return ap.parse_args()
 
 
@@ -105,14 +106,14 @@ def dominant_kernel_probe(args, device):
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * M * 4 * D * D
     es = 2 if dt == torch.bfloat16 else 4
-    probe = {"name": "gemm256_kernel<NT> 256x256x64 LDS-DMA: fc1 forward of the encoder block (bias + GELU + saved pre-activation)",
+    probe = {"name": "gemm256p_kernel<NT> persistent 256x256x64 LDS-DMA: fc1 forward of the encoder block (bias + GELU + saved pre-activation)",
              "flop_per_launch": fl, "avg_ms": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
              "algorithmic_bytes": (M * D + 4 * D * D + 2 * M * 4 * D) * es}
     if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
-        # HBM-side bytes per launch from the committed PMC passes of this same launch (profiles/r1_pmc: 2*FETCH_SIZE + WRITE_SIZE,
+        # HBM-side bytes per launch from the committed PMC passes of this same launch (profiles/r2_pmc: 2*FETCH_SIZE + WRITE_SIZE,
         # the gfx950 FETCH_SIZE correction applied)
-        probe["traffic"] = 1.098e9
-        probe["traffic_source"] = "profiles/r1_pmc/README.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        probe["traffic"] = 1.0795e9
+        probe["traffic_source"] = "profiles/r2_pmc/README.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     return probe
 
 
@@ -141,7 +142,8 @@ def main():
     fg196, fgN = (t.to(device) for t in synth.fg_masks(B, N, (args.img_size // 16) ** 2, seed=1000, first=first))
     crit = TrainLoss(scene_criterion="KL", num_action_classes=400, slot_matching_method="matching", scene_loss_weight=4000,
                      mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0, sync_loss_dict=False)
-    sync = GradSync(model) if world > 1 else None
+    comm_dtype = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
+    sync = GradSync(model, comm_dtype=comm_dtype) if world > 1 else None
 
     def step():
         for p in model.parameters():
@@ -164,6 +166,7 @@ def main():
     for _ in range(args.steps):
         loss = step()
     e1.record()
+    host_enqueue = time.perf_counter() - t0          # host time to ENQUEUE the K steps (the device is still running): launch-bound check
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -229,9 +232,11 @@ def main():
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"slot-{args.model} 16-patch {args.frames}x{args.img_size}^2 ({N} tokens), S=2 slots, tied agg depth 8, "
-                               f"B={B} clips/GPU, student fwd + matching loss + bwd" + (" + RCCL grad all-reduce (fp32, 64 MiB buckets)" if world > 1 else ""),
+                               f"B={B} clips/GPU, student fwd + matching loss + bwd" + (f" + RCCL grad all-reduce ({args.comm_dtype} wire format, 64 MiB fp32 buckets, side stream)" if world > 1 else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
-                   "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False},
+                   "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
+                   "kernels": "persistent 256x256 GEMM (NT), two-kernel MFMA attention backward, folded slot cross-attention (K/V projections on the slot side)"},
+        "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
         "device_ms_per_step": dev_ms / args.steps, "final_loss": loss_value, "peak_mem_gib": peak_mem,
     }
     if ach is not None:

@@ -112,3 +112,31 @@ def test_synth_is_deterministic_and_dyadic():
     m196, mN = synth.fg_masks(2, 50)
     assert torch.equal(m196 * 256, (m196 * 256).round()) and torch.equal(mN.half().float(), mN)   # fp16-exact (SURVEY §8c caveat 1)
     assert torch.equal(synth.video(2, 2, 32, seed=1000, first=3)[0], synth.video(1, 2, 32, seed=1000, first=3)[0])
+
+
+def test_gemm_debug_build_compiles(tmp_path):
+    """the timing-ablation stamps / sentinels of gemm.hip exist only under -DDEVIAS_GEMM_DEBUG: that build must keep
+    compiling for gfx950, and the production object must not contain the s_memrealtime stamps"""
+    import shutil
+    import subprocess
+    from devias_amd import build as b
+    if not os.path.exists(b.HIPCC):
+        pytest.skip("hipcc not available")
+    src = os.path.join(b.CSRC, "gemm.hip")
+    out = tmp_path / "gemm_debug.s"
+    cmd = [b.HIPCC] + b.FLAGS + ["-DDEVIAS_GEMM_DEBUG", "-S", "--cuda-device-only", src, "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    dbg = out.read_text()
+    assert "s_memrealtime" in dbg
+    # production build: every stamp sits inside an #ifdef DEVIAS_GEMM_DEBUG block of the source
+    depth, bad = 0, []
+    for ln, line in enumerate(open(src), 1):
+        t = line.strip()
+        if t.startswith("#ifdef DEVIAS_GEMM_DEBUG"):
+            depth += 1
+        elif t.startswith("#endif") and depth:
+            depth -= 1
+        elif "s_memrealtime" in line and depth == 0 and not t.startswith("//"):
+            bad.append(ln)
+    assert not bad, bad

@@ -15,12 +15,18 @@ bias = torch.zeros(4 * D, device=dev)
 pre = torch.empty(M, 4 * D, device=dev, dtype=bf)
 qkv = torch.randn(M, 3 * D, device=dev).to(bf)
 g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+qp = (torch.randn(B * 2, 4 * D, device=dev) * 0.5).to(bf)
 for it in range(3):
     o.gemm(x, w1, bias=bias, act=o.ACT_GELU, aux_out=pre)            # fc1 forward (gemm256, NT)
     o.gemm(dy, w1, trans_b=True)                                       # fc1 dgrad   (gemm_ss, NN)
     o.wgrad(dy, x)                                                     # fc1 wgrad   (gemm_ss, TN + split-K reduce)
     out, lse = o.mhsa_fwd(qkv, B, N, H, 0.125)
     o.mhsa_bwd(qkv, out, out, lse, B, N, H, 0.125)
+    o.set_option("attn_bwd", 1)
+    o.mhsa_bwd(qkv, out, out, lse, B, N, H, 0.125)                     # single-pass backward (opt-in path)
+    o.set_option("attn_bwd", 0)
     y, mean, rstd = o.layernorm_fwd(x, g, b, 1e-6)
     o.layernorm_bwd(y, x, g, mean, rstd, dres=x)
+    A, r, z = o.slotf_fwd(qp, x, B, 2, N, 4, D, 512 ** -0.5)           # folded slot attention, one layer
+    o.slotf_bwd(x, A, r, z, qp, None, B, 2, N, 4, D, 512 ** -0.5)
 torch.cuda.synchronize()
