@@ -10,6 +10,7 @@
 //   * the K/V gradients of ALL weight-tied layers are produced by ONE pass at the end (devias_slot_attn_kv_grad) from
 //     the tiny per-layer ds / A / q / dO tensors, instead of a read-modify-write of the [B,N,2,h*dh] buffer per layer.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -589,6 +590,197 @@ __global__ __launch_bounds__(256) void slotf_pack_kernel(const float* __restrict
     for (int d = threadIdx.x; d < D; d += 256) vrow[d] = src[d];
 }
 
+// =========================================================================================================
+// Folded form on the matrix cores (bf16): the two reductions of a layer are skinny GEMMs with R = h*S <= 16 slot-head rows,
+//   sim^T [tokens x R] = C [tokens x D] Q'^T [D x R]        and        Z^T [D x R] = C^T [D x tokens] A^T [tokens x R]
+// (backward: dAbar^T = C dZ^T and dQ'^T = C^T (scale dS)^T), so the per-token work that the kernels above do in VALU dot products and
+// wave reductions (they are VALU-bound: ~120 vector instructions per token and head) becomes 24 MFMAs per 32-token tile and wave.
+//   workgroup = one clip x TCHM tokens, 4 waves; wave w owns the context columns [w*D/4, (w+1)*D/4): it stages ITS column slice of the
+//   32-token tile into its own LDS region (LDS-DMA, transposed-read image blocks of [32 tokens][64 cols]) and uses it for both products:
+//   as the K-split of the first (partial sim, exchanged through LDS and summed by every wave in a fixed order) and as the output-row
+//   slice of the second.  The accumulator tile of the first product -- lane = slot-head row, 4 tokens per register quad -- is, packed to
+//   bf16, directly the B operand of the second (same k-permutation trick as the encoder attention kernels).  Softmax over the slot
+//   axis = S adjacent lanes.  Partials per workgroup in the layout of the VALU kernels (same finish kernels).
+// =========================================================================================================
+enum { TCHM = 128 };                                   // tokens per workgroup (4 tiles of 32)
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+typedef __attribute__((address_space(3))) bf16x4* lds_b4ptr;
+
+__device__ __forceinline__ int sm_tr_off(int row, int col) {        // [rows][64 cols] bf16 image, 32-byte windows XOR ((row >> 1) & 3)
+    return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + (col & 15) * 2;
+}
+// row fragment: lane holds img[row = base + (lane & 15)][32*ks + 8*(lane >> 4) .. +8]
+__device__ __forceinline__ bf16x8 sm_frag_rows(const char* img, int base, int ks, int lane) {
+    const int row = base + (lane & 15);
+    return *reinterpret_cast<const bf16x8*>(img + sm_tr_off(row, 32 * ks + 8 * (lane >> 4)));
+}
+// transposed fragment over the 32 rows: lane holds img[row = 16*(j >> 2) + 4g + (j & 3)][col = cbase + (lane & 15)], j = 0..7
+__device__ __forceinline__ bf16x8 sm_frag_tr(const char* img, int cbase, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    const int r0 = 4 * g + (c >> 2), col = cbase + 4 * (c & 3);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4ptr)(img + sm_tr_off(r0, col)));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4ptr)(img + sm_tr_off(r0 + 16, col)));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+__device__ __forceinline__ f32x4 sm_mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// NB = 64-column blocks per wave (D = 256 * NB): 3 for ViT-B (768), 4 for ViT-L (1024), 2 for D = 512
+template <int NB, bool BWD>
+__global__ __launch_bounds__(256) void slotm_kernel(const bf16* __restrict__ rowsrc,   // forward: q' [B*S, h*D]; backward: dz [B*S, h*D]
+                                                    const bf16* __restrict__ ctx, float* __restrict__ attn,      // forward: written; backward: read
+                                                    const float* __restrict__ rsum, const bf16* __restrict__ z, const float* __restrict__ dA_ext,
+                                                    float* __restrict__ ds_out, float* __restrict__ ws_r, float* __restrict__ ws_z,
+                                                    int S, int N, int h, float scale) {
+    constexpr int D = 256 * NB, WD = 64 * NB;          // context dim, columns per wave
+    __shared__ __attribute__((aligned(16))) char smem[4 * NB * 4096 + 4 * 2048 + 256];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* myimg = smem + wave * NB * 4096;             // this wave's [32 tokens][WD cols] slice: NB blocks of [32][64]
+    float* xch = reinterpret_cast<float*>(smem + 4 * NB * 4096);                 // [4 waves][2 subtiles][64 lanes][4] partial sim
+    float* s_dl = reinterpret_cast<float*>(smem + 4 * NB * 4096 + 4 * 2048);     // [4 waves][16] partial delta (backward)
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int R = h * S;
+    const int hh = c / S, si = c - hh * S;             // this lane's slot-head row: rho = c = hh * S + si (valid while c < R)
+    const bool rvalid = c < R;
+    // ---- this lane's row operand (q' or dz), its wave's column slice: element k of k-step (blk, ks): rows[rho][wave*WD + 64*blk + 32*ks + 8g + k] ----
+    bf16x8 rowf[NB][2];
+    float dl = 0.f, rinv = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int64_t off = ((int64_t)b * S + si) * h * D + (int64_t)hh * D + wave * WD + 64 * blk + 32 * ks + 8 * g;
+            bf16x8 v = {};
+            if (rvalid) v = *reinterpret_cast<const bf16x8*>(rowsrc + off);
+            rowf[blk][ks] = v;
+            if constexpr (BWD) {
+                if (rvalid) {
+                    const bf16x8 zz = *reinterpret_cast<const bf16x8*>(z + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dl += (float)v[e] * (float)zz[e];
+                }
+            }
+        }
+    if constexpr (BWD) {                               // delta[rho] = dz[rho] . z[rho]: over this lane's k-groups, then over the waves (fixed order)
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        if (g == 0) s_dl[wave * 16 + c] = dl;
+        __syncthreads();
+        dl = s_dl[c] + s_dl[16 + c] + s_dl[32 + c] + s_dl[48 + c];
+        rinv = rvalid ? 1.0f / rsum[((int64_t)b * h + hh) * S + si] : 0.f;
+    }
+    f32x4 zacc[NB * 4];                                // Z^T / dQ'^T slice: rows d = wave*WD + 16*dt + 4g + r, col rho = c
+#pragma unroll
+    for (int i = 0; i < NB * 4; ++i) zacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rs = 0.f;
+    const int j0 = chunk * TCHM, j1 = min(N, j0 + TCHM);
+    const bf16* cbase = ctx + (int64_t)b * N * D + wave * WD;
+    for (int t0 = j0; t0 < j1; t0 += 32) {
+        // ---- stage this wave's slice of the tile: NB blocks x 4 LDS-DMA instructions (8 rows x 128 B each); rows past N re-read row N-1 ----
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + (lane >> 3), slot = lane & 7;
+                const int chunk16 = (((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1);
+                const bf16* src = cbase + (int64_t)min(t0 + row, N - 1) * D + 64 * blk + chunk16 * 8;
+                __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(myimg + blk * 4096 + i * 1024), 16, 0, 0);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- partial sim^T over this wave's columns: acc[sub] = tokens 16*sub + 4g + r (rows) x rho c (col) -----------------------------------
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+                    acc[sub] = sm_mfma(sm_frag_rows(myimg + blk * 4096, 16 * sub, ks, lane), rowf[blk][ks], acc[sub]);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) *reinterpret_cast<f32x4*>(xch + ((wave * 2 + sub) * 64 + lane) * 4) = acc[sub];
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(xch + ((0 * 2 + sub) * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(xch + ((w * 2 + sub) * 64 + lane) * 4);
+            acc[sub] = t;
+        }
+        // ---- per token: softmax over the slot axis (S adjacent lanes) / its backward -----------------------------------------------------
+        bf16x8 bop;                                    // B operand of the second product: k = token (16*(j >> 2) + 4g + (j & 3)), col = rho
+        float vals[8];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int tok = t0 + 16 * sub + 4 * g;     // first of this lane's 4 tokens
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, e4 = {0.f, 0.f, 0.f, 0.f};
+            const int64_t arow = (((int64_t)b * h + hh) * S + si) * N;
+            if constexpr (BWD) {
+                if (rvalid) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (tok + r < j1) {
+                            a4[r] = attn[arow + tok + r];
+                            if (dA_ext) e4[r] = dA_ext[arow + tok + r];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v;
+                if constexpr (!BWD) {
+                    float sv = rvalid ? acc[sub][r] * scale : -INFINITY;
+                    float mx = sv;
+                    for (int o = 1; o < S; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));          // S is 1, 2 or 4: lanes of one head are aligned
+                    float ev = rvalid ? expf(sv - mx) : 0.f;
+                    float den = ev;
+                    for (int o = 1; o < S; o <<= 1) den += __shfl_xor(den, o, 64);
+                    v = (rvalid && tok + r < j1) ? ev / den : 0.f;
+                    rs += v;
+                } else {
+                    const float dA = (acc[sub][r] - dl) * rinv + e4[r];
+                    float tsum = a4[r] * dA;
+                    for (int o = 1; o < S; o <<= 1) tsum += __shfl_xor(tsum, o, 64);
+                    v = (rvalid && tok + r < j1) ? a4[r] * (dA - tsum) : 0.f;
+                }
+                vals[4 * sub + r] = v;
+            }
+            // ---- attention (forward) / dS (backward) rows: one wave per subtile writes them -----------------------------------------------
+            if (rvalid && wave == sub) {
+                float* dst = (BWD ? ds_out : attn) + arow + tok;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (tok + r < j1) dst[r] = vals[4 * sub + r];
+            }
+        }
+        if constexpr (BWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vals[e] *= scale;
+        }
+        bop = bf16x8{(bf16)vals[0], (bf16)vals[1], (bf16)vals[2], (bf16)vals[3], (bf16)vals[4], (bf16)vals[5], (bf16)vals[6], (bf16)vals[7]};
+        // ---- Z^T / dQ'^T slice += C^T (this wave's columns) x bop ---------------------------------------------------------------------------
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                zacc[blk * 4 + dt] = sm_mfma(sm_frag_tr(myimg + blk * 4096, 16 * dt, lane), bop, zacc[blk * 4 + dt]);
+        __syncthreads();                               // the exchange buffer is free again (the images are private to the wave)
+    }
+    // ---- partials of this workgroup, in the layout the finish kernels expect ---------------------------------------------------------------------
+    if (rvalid) {
+        const int64_t pb = ((int64_t)b * h + hh) * nchunks + chunk;
+        if constexpr (!BWD) {
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            if (wave == 0 && g == 0) ws_r[pb * S + si] = rs;
+        }
+        float* dst = ws_z + (pb * S + si) * D + wave * WD + 4 * g;
+#pragma unroll
+        for (int i = 0; i < NB * 4; ++i) *reinterpret_cast<f32x4*>(dst + 16 * i) = zacc[i];
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t devias_slot_attn_workspace_bytes(int32_t B, int32_t S, int32_t N, int32_t h, int32_t dh) {
@@ -685,6 +877,12 @@ extern "C" int64_t devias_slotf_workspace_bytes(int32_t B, int32_t S, int32_t N,
     return (int64_t)B * h * nchunks * S * (D + 1) * 4 + 64;
 }
 
+// the matrix-core kernels: bf16, h * S <= 16 slot-head rows, S a power of two (softmax across S aligned adjacent lanes), D = 256 * {2, 3, 4}
+static bool slotm_ok(int B, int S, int h, int D, int dtype) {
+    static const int on = [] { const char* e = getenv("DEVIAS_SLOT_MFMA"); return e ? atoi(e) : 1; }();
+    return on && dtype == DEVIAS_BF16 && h * S <= 16 && (S == 1 || S == 2 || S == 4) && (D == 512 || D == 768 || D == 1024) && B <= 65535;
+}
+
 #define SLOTF_CHECKS(name)                                                                                                  \
     DEVIAS_REQUIRE(D == 384 || D == 512 || D == 768 || D == 1024, name ": context dim must be 384, 512, 768 or 1024, got %d", D); \
     DEVIAS_REQUIRE(S >= 1 && S <= 4, name ": 1 <= num_latents <= 4 in the folded form, got %d", S);                          \
@@ -712,9 +910,21 @@ extern "C" int devias_slotf_fwd(const void* qp, const void* ctx, float* attn, fl
     SLOTF_CHECKS("devias_slotf_fwd");
     DEVIAS_REQUIRE(qp && ctx && attn && rsum && z && ws, "devias_slotf_fwd: null pointer");
     DEVIAS_REQUIRE(aligned16(qp) && aligned16(ctx) && aligned16(z) && aligned16(ws), "devias_slotf_fwd: unaligned pointer");
-    const int nchunks = cdiv(N, TCH);
+    const bool mfma = slotm_ok(B, S, h, D, dtype);
+    const int nchunks = mfma ? cdiv(N, TCHM) : cdiv(N, TCH);
     float* ws_r = ws;
     float* ws_z = ws + (((int64_t)B * h * nchunks * S + 3) & ~(int64_t)3);
+    if (mfma) {
+        dim3 gm(nchunks, B);
+#define SLOTM_F(NB_) hipLaunchKernelGGL((slotm_kernel<NB_, false>), gm, dim3(256), 0, st, (const bf16*)qp, (const bf16*)ctx, attn, (const float*)nullptr, \
+                                          (const bf16*)nullptr, (const float*)nullptr, (float*)nullptr, ws_r, ws_z, S, N, h, scale)
+        if (D == 512) SLOTM_F(2); else if (D == 768) SLOTM_F(3); else SLOTM_F(4);
+#undef SLOTM_F
+        DEVIAS_CHECK_LAUNCH("devias_slotf_fwd(mfma)");
+        hipLaunchKernelGGL((slotf_fwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws_r, ws_z, rsum, (bf16*)z, S, h, D, nchunks);
+        DEVIAS_CHECK_LAUNCH("devias_slotf_fwd(finish)");
+        return DEVIAS_OK;
+    }
     dim3 grid(nchunks, B * h), block(256);
     if (dtype == DEVIAS_BF16) {
         SLOTF_DISPATCH(slotf_fwd_kernel, bf16, (const bf16*)qp, (const bf16*)ctx, attn, ws_r, ws_z, S, N, h, scale);
@@ -736,7 +946,19 @@ extern "C" int devias_slotf_bwd(const void* ctx, const float* attn, const float*
     SLOTF_CHECKS("devias_slotf_bwd");
     DEVIAS_REQUIRE(ctx && attn && rsum && z && dz && dqp && ds && ws, "devias_slotf_bwd: null pointer");
     DEVIAS_REQUIRE(aligned16(ctx) && aligned16(z) && aligned16(dz) && aligned16(dqp) && aligned16(ws), "devias_slotf_bwd: unaligned pointer");
-    const int nchunks = cdiv(N, TCH);
+    const bool mfma = slotm_ok(B, S, h, D, dtype);
+    const int nchunks = mfma ? cdiv(N, TCHM) : cdiv(N, TCH);
+    if (mfma) {
+        dim3 gm(nchunks, B);
+#define SLOTM_B(NB_) hipLaunchKernelGGL((slotm_kernel<NB_, true>), gm, dim3(256), 0, st, (const bf16*)dz, (const bf16*)ctx, const_cast<float*>(attn), rsum, \
+                                          (const bf16*)z, d_attn_ext, ds, (float*)nullptr, ws, S, N, h, scale)
+        if (D == 512) SLOTM_B(2); else if (D == 768) SLOTM_B(3); else SLOTM_B(4);
+#undef SLOTM_B
+        DEVIAS_CHECK_LAUNCH("devias_slotf_bwd(mfma)");
+        hipLaunchKernelGGL((slotf_bwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws, (bf16*)dqp, S, h, D, nchunks);
+        DEVIAS_CHECK_LAUNCH("devias_slotf_bwd(finish)");
+        return DEVIAS_OK;
+    }
     dim3 grid(nchunks, B * h), block(256);
     if (dtype == DEVIAS_BF16) {
         SLOTF_DISPATCH(slotf_bwd_kernel, bf16, (const bf16*)ctx, attn, rsum, (const bf16*)z, (const bf16*)dz, d_attn_ext, ds, ws, S, N, h, scale);

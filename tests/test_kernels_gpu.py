@@ -555,7 +555,8 @@ def _slotf_ref(qp, c, B, S, N, h, D, scale):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,S,N,h,D", [(2, 2, 100, 4, 768), (1, 4, 784, 2, 384), (3, 3, 65, 1, 1024), (2, 2, 196, 4, 512)])
+@pytest.mark.parametrize("B,S,N,h,D", [(2, 2, 100, 4, 768), (1, 4, 784, 2, 384), (3, 3, 65, 1, 1024), (2, 2, 196, 4, 512), (2, 4, 300, 4, 1024),
+                                       (1, 2, 1568, 4, 768), (2, 1, 33, 4, 768)])
 def test_slot_attention_folded(dtype, B, S, N, h, D):
     """devias_slotf_fwd / _bwd / _pack + the batched context-gradient GEMM against autograd of the folded formula (fp32 torch), including
     the gradient arriving on the returned attention; ragged token counts (N % 8 != 0 -> padded coefficient rows, scalar GEMM path)"""
