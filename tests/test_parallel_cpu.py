@@ -293,12 +293,12 @@ def _slot_hip_grads(device, first_list, dtype="fp32", sync=None):
     return {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
 
 
-def _slot_nccl_worker(rank, world, port, q):
+def _slot_hip_worker(rank, world, port, q, backend):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     from devias_amd.parallel import GradSync, init_distributed_from_env
-    init_distributed_from_env(backend="nccl")
-    dev = torch.device("cuda", rank)
+    init_distributed_from_env(backend=backend)
+    dev = torch.device("cuda", rank % torch.cuda.device_count())       # gloo: both ranks may share the one GPU of the box
     torch.cuda.set_device(dev)
     g = _slot_hip_grads(dev, [2 * rank], sync=lambda m: GradSync(m, bucket_bytes=1 << 20))
     q.put((rank, {n: v.numpy() for n, v in g.items()}))
@@ -308,15 +308,18 @@ def _slot_nccl_worker(rank, world, port, q):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
-def test_slot_model_two_ranks_rccl_equals_chunked_single_gpu():
-    """SURVEY.md §8e on hardware: the HIP slot model on 2 GPUs (rank r <- clips [2r, 2r+2), bucketed RCCL all-reduce on the side stream, weight
-    gradients written straight into the buckets) == one GPU evaluating the two chunks in turn.  fp32 mode, 1e-5.  Needs >= 2 GPUs."""
-    if torch.cuda.device_count() < 2:
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_slot_model_two_ranks_equals_chunked_single_gpu(backend):
+    """SURVEY.md §8e on hardware: the HIP slot model in 2 processes (rank r <- clips [2r, 2r+2), bucketed all-reduce launched from the gradient
+    hooks on the side stream, encoder weight gradients written straight into the buckets) == one process evaluating the two chunks in turn.
+    fp32 mode, 1e-5.  'nccl' (RCCL over xGMI) needs >= 2 GPUs; 'gloo' runs the same code with both ranks on one GPU (collective through host
+    memory), so the whole data-parallel path except the transport is exercised on a 1-GPU box."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_slot_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_slot_hip_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))
@@ -328,7 +331,7 @@ def test_slot_model_two_ranks_rccl_equals_chunked_single_gpu():
     for n, v in ref.items():
         for rank in range(world):
             err = float((torch.from_numpy(res[rank][n]) - v).abs().max()) / max(float(v.abs().max()), 1e-4 * gmax)
-            assert err < 1e-5, (n, rank, err)
+            assert err < 1e-5, (backend, n, rank, err)
 
 
 @pytest.mark.gpu
