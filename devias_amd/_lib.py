@@ -47,6 +47,8 @@ PROTOTYPES = {
     "devias_version": (c_int, []),
     "devias_last_error": (c_char_p, []),
     "devias_device_info": (c_int, [c_int, POINTER(c_int64)]),
+    "devias_allreduce_bucket": (c_int, [_P, _P, _L, _I, _P]),
+    "devias_shutdown": (None, []),
     "devias_counter": (c_int64, [c_int32]),
     "devias_counters_reset": (None, []),
     "devias_set_option": (c_int, [c_char_p, c_int32]),

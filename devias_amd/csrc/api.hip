@@ -44,3 +44,36 @@ extern "C" int devias_device_info(int device, int64_t* out5) {
     out5[4] = arch;
     return DEVIAS_OK;
 }
+
+
+// ---- gradient-bucket all-reduce for hosts that own an RCCL communicator (SURVEY.md §8b minimum export set) ---------------------------------
+// The Python host of this repository reaches RCCL through torch.distributed (devias_amd/parallel.py); a C++ host passes its ncclComm_t here.
+// librccl is resolved at the first call (dlsym on the already-loaded image first -- inside a PyTorch process that is torch's bundled
+// librccl.so --, then dlopen("librccl.so")), so the library itself keeps its single link dependency on the HIP runtime.
+#include <dlfcn.h>
+typedef int (*devias_nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static devias_nccl_allreduce_fn resolve_allreduce() {
+    static devias_nccl_allreduce_fn fn = [] {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!sym) {
+            void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (h) sym = dlsym(h, "ncclAllReduce");
+        }
+        return (devias_nccl_allreduce_fn)sym;
+    }();
+    return fn;
+}
+extern "C" int devias_allreduce_bucket(void* nccl_comm, void* bucket, int64_t count, int32_t dtype, void* stream) {
+    if (!nccl_comm || !bucket || count <= 0) return devias_set_error(DEVIAS_EINVAL, "devias_allreduce_bucket: null communicator / bucket or empty bucket");
+    if (dtype != DEVIAS_F32 && dtype != DEVIAS_BF16) return devias_set_error(DEVIAS_EINVAL, "devias_allreduce_bucket: bad dtype %d", dtype);
+    devias_nccl_allreduce_fn fn = resolve_allreduce();
+    if (!fn) return devias_set_error(DEVIAS_EUNSUPPORTED, "devias_allreduce_bucket: ncclAllReduce not found (librccl.so is not loadable)");
+    const int nccl_dtype = dtype == DEVIAS_F32 ? 7 /* ncclFloat32 */ : 9 /* ncclBfloat16 */;
+    const int rc = fn(bucket, bucket, (size_t)count, nccl_dtype, 0 /* ncclSum */, nccl_comm, (hipStream_t)stream);
+    if (rc != 0) return devias_set_error(DEVIAS_ELAUNCH, "devias_allreduce_bucket: ncclAllReduce returned %d", rc);
+    return DEVIAS_OK;
+}
+
+// nothing persistent is allocated by the library; shutdown resets the launch counters (kept for hosts written against SURVEY.md §8b's export list)
+extern "C" void devias_shutdown(void) { devias_counters_reset(); }

@@ -66,6 +66,14 @@ void devias_counters_reset(void);
  * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_debug", "attn_cfg", "attn_xcd", "attn_bwd".  0 = ok, DEVIAS_EINVAL = unknown name. */
 int devias_set_option(const char* name, int32_t value);
 
+/* In-place SUM all-reduce of one flat gradient bucket over the caller's RCCL communicator (`nccl_comm` is an ncclComm_t; dtype DEVIAS_F32 or
+ * DEVIAS_BF16), enqueued on `stream`: the data-path collective of the step (DDP / DeepSpeed ZeRO-0 gradient all-reduce, run_slot_finetuning.py:552-563)
+ * for hosts that own a communicator.  (The Python host in this repository uses torch.distributed -- the same RCCL -- see devias_amd/parallel.py.)
+ * librccl is resolved at the first call; DEVIAS_EUNSUPPORTED if it cannot be found. */
+int devias_allreduce_bucket(void* nccl_comm, void* bucket, int64_t count, int32_t dtype, void* stream);
+/* The library allocates nothing persistent; resets the launch counters. */
+void devias_shutdown(void);
+
 /* fills: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes per block, [3]=wavefront size, [4]=gfx arch number (e.g. 950) */
 int devias_device_info(int device, int64_t* out5);
 

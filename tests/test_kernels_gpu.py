@@ -600,3 +600,41 @@ def test_gemm_batched_layouts(dtype):
     o.gemm_batched(Wq, g, dWk, dh, D, D, lda=D, ldb=D, ldc=D, stride_a=dh * D, stride_b=D * D, stride_c=dh * D, batch=h)
     ref = torch.cat([Wq.float()[i * dh:(i + 1) * dh] @ g.float()[i * D:(i + 1) * D].t() for i in range(h)])
     assert rel(dWk, ref) < tol
+
+
+def test_c_abi_allreduce_bucket_single_rank():
+    """devias_allreduce_bucket over a real RCCL communicator (one rank, created through ctypes on the librccl torch ships): the call path,
+    dtype mapping and stream handling of the C-ABI collective; a single-rank SUM leaves the bucket unchanged"""
+    import ctypes
+    import glob
+    import os
+    from devias_amd import _lib
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["/opt/rocm/lib/librccl.so"]
+    rccl = None
+    for c in cands:
+        try:
+            rccl = ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("librccl not loadable")
+    torch.cuda.set_device(0)
+    torch.zeros(1, device=DEV)                                   # HIP context
+    class UniqueId(ctypes.Structure):                             # ncclUniqueId is passed BY VALUE
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+        x = rnd(1 << 16, dtype=dt, seed=90)
+        ref = x.clone()
+        _lib.check(lib.devias_allreduce_bucket(comm, x.data_ptr(), x.numel(), code, st), "devias_allreduce_bucket")
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    rccl.ncclCommDestroy(comm)

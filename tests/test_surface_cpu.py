@@ -31,6 +31,9 @@ def test_library_exports_every_declared_symbol():
     assert all(lib.devias_counter(i) == 0 for i in _lib.COUNTERS.values()) and lib.devias_counter(999) == -1
     assert lib.devias_set_option(b"gemm_persistent", 1) == 0 and lib.devias_set_option(b"attn_xcd", 1) == 0
     assert lib.devias_set_option(b"no_such_option", 1) == -1 and b"no_such_option" in lib.devias_last_error()
+    # the C-ABI collective validates its arguments before touching RCCL
+    assert lib.devias_allreduce_bucket(None, None, 0, 0, None) == -1 and b"devias_allreduce_bucket" in lib.devias_last_error()
+    lib.devias_shutdown()
 
 
 def test_weight_cache_invalidation_logic(monkeypatch):
