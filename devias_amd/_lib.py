@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdevias_amd.so")
+LIB_PATH = os.environ.get("DEVIAS_LIB_PATH") or os.path.join(_HERE, "libdevias_amd.so")     # (override: ablation builds of tools/)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4, 5
@@ -33,6 +33,7 @@ class GemmArgs(Structure):
         ("colsum", c_void_p), ("colsum_beta", c_float),
         ("row_scale", c_void_p), ("rows_per_scale", c_int32),
         ("batch", c_int32), ("stride_a", c_int64), ("stride_b", c_int64), ("stride_c", c_int64),
+        ("sk_ws", c_void_p), ("sk_ws_bytes", c_int64),
     ]
 
 
@@ -54,6 +55,8 @@ PROTOTYPES = {
     "devias_set_option": (c_int, [c_char_p, c_int32]),
     "devias_gemm": (c_int, [POINTER(GemmArgs), _P]),
     "devias_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
+    "devias_gemm_streamk_workspace_bytes": (c_int64, []),
+    "devias_gemm_streamk_error_offset": (c_int64, []),
     "devias_cast": (c_int, [_P, _I, _P, _I, _L, _P]),
     "devias_patch_im2col": (c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "devias_colsum": (c_int, [_P, _I, _I, _I, _I, _P, _F, _P, _P]),
@@ -92,7 +95,7 @@ PROTOTYPES = {
     "devias_fame_mix": (c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
 }
 COUNTERS = {"gemm128_f32": 0, "gemm128_bf16": 1, "gemm_ss": 2, "gemm256": 3, "gemm256p": 4, "splitk_reduce": 5,
-            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10}     # DEVIAS_CNT_*
+            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10, "gemm_sk": 11}     # DEVIAS_CNT_*
 OPT_CHUNK = 16384          # DEVIAS_OPT_CHUNK
 OPT_TENSOR_BYTES = 64      # sizeof(devias_opt_tensor)
 

@@ -12,6 +12,8 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <atomic>
 
 namespace {
 
@@ -32,9 +34,11 @@ struct GemmP {
     int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
     int epi_swap;         // 1 = register-transposed epilogue (epilogue_swap), 0 = LDS-staged (epilogue_staged)
     int debug;            // timing ablations, compiled in only with -DDEVIAS_GEMM_DEBUG (option "gemm_debug"): 1 = one K-tile, 2 = no epilogue,
-                          // 4 = no LDS-DMA after tile 0, 8 = s_memrealtime stamps into ws, 64 = epilogue without its global stores
+                          // 4 = no LDS-DMA after tile 0, 8 = s_memrealtime stamps into ws, 64 = epilogue without its C stores,
+                          // 128 = without its pre-activation stores, 256 = without the GELU / dGELU polynomial
     int epi_vm;           // persistent kernel: VMEM operations every wave is guaranteed to issue in one epilogue (counted vmcnt)
     int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
+    float* sk_part; unsigned long long* sk_flag; unsigned long long sk_epoch;   // stream-K kernel: partial slots, flags (+ error word), this launch's tag
 };
 
 #ifdef DEVIAS_GEMM_DEBUG
@@ -285,13 +289,38 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
 // a 16-byte bf16 piece; one store instruction then writes 16 rows x 64 contiguous bytes.  Measured (tools/exp/store_bw.hip) that
 // pattern stores at 24.8 GB/s per CU vs 26.0 for whole 128-B lines, and the LDS round trip it removes cost more than the stores
 // (qkv shape: staging + arithmetic 35 us, stores 23 us of a 58 us epilogue).
-template <int NI>
+// DEFER (persistent kernels): the stores of the output (and of the saved pre-activation) are issued from inline asm, and the rows the
+// epilogue reads are ALL requested up front.  The compiler's wait insertion then never sees a pending store: with visible stores it
+// drains the whole memory pipeline before the next tile's first LDS-DMA / MFMA (measured: the store burst of every tile was exposed);
+// this way the burst drains under the next K-iteration's 64 MFMAs per wave.  (Waits the compiler computes for its own loads are counted
+// in issue order; asm stores issued after such a load only make them stricter, never too weak.)
+__device__ __forceinline__ void store16_asm(const void* sbase, uint32_t voff, u32x4 data) {
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(data), "s"(sbase) : "memory");
+}
+// SIDE: which rows the epilogue reads, as a compile-time fact (-1 = decided at run time): 0 none, 1 residual, 2 saved pre-activation of
+// dGELU / dReLU.  The persistent kernels need it: a load whose use sits behind a different run-time condition than its issue looks
+// "possibly still pending" to the compiler's wait insertion at the K loop's head, which then drains the memory pipeline every iteration.
+template <int NI, bool DEFER = false, int SIDE = -1>
 __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4], int mrow0, int ncol0, int z, int lane) {
     const int lm = lane & 15, g = lane >> 4;
+    const uint32_t col2 = (uint32_t)(16 * (g & 1) + 8 * (g >> 1)) * 2;
+    const uint32_t vo_c = (uint32_t)lm * (uint32_t)p.ldc * 2 + col2, vo_x = (uint32_t)lm * (uint32_t)p.ld_aux * 2 + col2;
+    constexpr bool BIAS_ON = !(DEFER && SIDE == 2), CS_ON = !(DEFER && SIDE == 1);
     f32x4 bias4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias4[j] = (BIAS_ON && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // DEFER: the stochastic-depth row scales as two SCALARS (rows_per_scale >= 16 * NI, host: the wave's rows span at most two samples);
+    // the register budget of the up-front row fetch also drops what the step never combines (host): bias with SIDE 2, column sums with SIDE 1
+    float rs_lo = 1.f, rs_hi = 1.f;
+    int rs_edge = 0;
+    if constexpr (DEFER) {
+        if (p.row_scale) {
+            const int r0 = mrow0 / p.rows_per_scale, rl = (p.M - 1) / p.rows_per_scale;
+            rs_lo = p.row_scale[r0]; rs_hi = p.row_scale[r0 < rl ? r0 + 1 : rl];
+            rs_edge = (r0 + 1) * p.rows_per_scale;
+        }
+    }
     const bf16* res = reinterpret_cast<const bf16*>(p.res);
     const bf16* aux_in = reinterpret_cast<const bf16*>(p.aux_in);
     bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
@@ -301,15 +330,17 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs[pr][e] = 0.f;
     // the rows the epilogue reads (residual, or the saved pre-activation of dGELU / dReLU) are fetched PF pieces ahead of their use
-    constexpr int PF = 4;
-    const bf16* side = res ? res : aux_in;
-    const int side_ld = res ? p.ldr : p.ld_aux;
-    const bool side_on = side != nullptr && p.split_k == 1;
+    constexpr int PF = DEFER ? 2 * NI : 4;
+    const bool has_res = SIDE == 1 ? true : (SIDE == -1 ? res != nullptr : false);
+    const bool dact = SIDE == 2 ? true : (SIDE == -1 ? (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) : false);
+    const bf16* side = has_res ? res : aux_in;
+    const int side_ld = has_res ? p.ldr : p.ld_aux;
+    const bool side_on = SIDE > 0 ? true : (SIDE == 0 ? false : (side != nullptr && p.split_k == 1));
     bf16x8 sbuf[PF];
     auto side_load = [&](int n) -> bf16x8 {
         const int i = n >> 1, pr = n & 1;
         int m = mrow0 + i * 16 + lm;
-        if (res && p.res_mod > 0) m %= p.res_mod;
+        if (has_res && p.res_mod > 0) m %= p.res_mod;
         return *reinterpret_cast<const bf16x8*>(side + (int64_t)m * side_ld + ncol0 + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1));
     };
     if (side_on) {
@@ -332,21 +363,41 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                 v[4 + r] = __uint_as_float(sw[1]);
             }
             const int ncol = ncol0 + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1);
-            if (p.split_k > 1) {
+            if (!DEFER && p.split_k > 1) {
                 float* w = p.ws + ((int64_t)z * p.M + m) * p.N + ncol;
                 *reinterpret_cast<f32x4*>(w) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(w + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 continue;
             }
-            if (p.act == DEVIAS_ACT_GELU) {
+            if (dact) {
+                const bf16x8 a8 = has_res ? *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)m * p.ld_aux + ncol) : side8;
+                if (p.act == DEVIAS_ACT_DGELU) {
+                    if (GDBG(256)) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= (float)a8[e];
+                    } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 d = dgelu_fast2(f32x2{(float)a8[e], (float)a8[e + 1]});
+                        v[e] *= d[0]; v[e + 1] *= d[1];
+                    }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)a8[e] > 0.f ? v[e] : 0.f;
+                }
+            } else if (p.act == DEVIAS_ACT_GELU) {
                 if (aux_out) {
                     bf16x8 pre = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                    *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
+                    if constexpr (DEFER) store16_asm(aux_out + (int64_t)(mrow0 + i * 16) * p.ld_aux + ncol0 + 32 * pr, vo_x, *reinterpret_cast<const u32x4*>(&pre));
+                    else if (!GDBG(128) || v[0] == 12345.678f) *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
                 }
+                if (!GDBG(256)) {
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const f32x2 y = gelu_fast2(f32x2{v[e], v[e + 1]});
                     v[e] = y[0]; v[e + 1] = y[1];
+                }
                 }
             } else if (p.act == DEVIAS_ACT_RELU) {
 #pragma unroll
@@ -354,34 +405,22 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
             } else if (p.act == DEVIAS_ACT_SIGMOID) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
-            } else if (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) {
-                const bf16x8 a8 = res ? *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)m * p.ld_aux + ncol) : side8;
-                if (p.act == DEVIAS_ACT_DGELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const f32x2 d = dgelu_fast2(f32x2{(float)a8[e], (float)a8[e + 1]});
-                        v[e] *= d[0]; v[e + 1] *= d[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (float)a8[e] > 0.f ? v[e] : 0.f;
-                }
             }
             if (p.row_scale) {
-                const float rs = p.row_scale[m / p.rows_per_scale];
+                const float rs = DEFER ? (m >= rs_edge ? rs_hi : rs_lo) : p.row_scale[m / p.rows_per_scale];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= rs;
             }
-            if (res) {
+            if (has_res) {
                 const bf16x8 r8 = side8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
             }
-            if (p.colsum_part) {
+            if (CS_ON && p.colsum_part) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) cs[pr][e] += v[e];
             }
-            if (p.c_f32) {
+            if (!DEFER && p.c_f32) {
                 float* C = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + ncol;
                 f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
                 if (p.beta != 0.f) {
@@ -392,12 +431,13 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                 *reinterpret_cast<f32x4*>(C + 4) = o1;
             } else {
                 bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                if (!GDBG(64) || v[0] == 12345.678f)
+                if constexpr (DEFER) store16_asm(reinterpret_cast<const bf16*>(p.C) + (int64_t)(mrow0 + i * 16) * p.ldc + ncol0 + 32 * pr, vo_c, *reinterpret_cast<const u32x4*>(&o));
+                else if (!GDBG(64) || v[0] == 12345.678f)
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
             }
         }
     }
-    if (p.colsum_part && p.split_k == 1) {
+    if (CS_ON && p.colsum_part && p.split_k == 1) {
         // the 16 lanes of a group (same g, rows lm = 0..15) own the same columns: fold them in a fixed order
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
@@ -870,7 +910,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
 // Tile order: XCD x (block ids congruent to x mod 8) owns the same contiguous range of logical tiles as in xcd_remap; its G/8 workgroups
 // stride through it together, so at any moment an XCD works on ~32 consecutive tiles (operand panels shared in its L2).
 // =====================================================================================================================
-template <bool TB>
+template <bool TB, int SIDE>
 __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -906,11 +946,27 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DEVIAS_GEMM_DEBUG
+    // gemm_debug & 8: thread 0 logs (100 MHz clock << 4 | code) into ws + 64 * blockIdx.x: 1 = first K-tile of a tile about to be multiplied,
+    // 2 = K loop done, 3 = epilogue done (stores issued), 4 = first K-iteration of the next tile done (its wait passed)
+    int nlog = 0;
+    auto stamp = [&](int code) {
+        if (GDBG(8) && tid == 0 && nlog < 64) {
+            const unsigned long long v = (__builtin_amdgcn_s_memrealtime() << 4) | (unsigned long long)code;
+            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)nlog * 8), "v"(v), "s"(reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 64) : "memory");
+        }
+        ++nlog;
+    };
+#define PSTAMP(c) stamp(c)
+#else
+#define PSTAMP(c)
+#endif
     // ONE flat loop over the K-tile stream (ring stage = g & 1); the wait for K-tile g + 1 sits at the END of iteration g so that the loop has
     // no first-iteration special case (a peeled copy is where the compiler re-inserts full vmcnt drains)
     for (int g = 0, kt = 0;; ++g) {
         __builtin_amdgcn_s_barrier();                      // K-tile g has landed for every wave, and everyone is done reading stage (g + 1) & 1
         asm volatile("" ::: "memory");
+        if (kt == 0) PSTAMP(1);
         char* cur = smem + (g & 1) * STAGE2;
         char* nxt = smem + ((g + 1) & 1) * STAGE2;
         // source of K-tile g + 1: this tile's next one, or the next tile's first; at the very end a harmless re-read
@@ -927,14 +983,17 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
         if (same) {
             ++kt;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA for K-tile g + 1 has landed
+            if (kt == 1) PSTAMP(4);
             continue;
         }
+        PSTAMP(2);
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
-        epilogue_swap<8>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
+        epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
         if (!has_next) break;
         // the epilogue issued >= 16 stores per wave AFTER the DMA of the next tile's first K-tile: wait for the DMA only, the stores drain under the next MFMAs
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        PSTAMP(3);
         kt = 0;
         li = ln; m0 = m0n; n0 = n0n;
         ln = li + stride;
@@ -946,6 +1005,191 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing re-read must land before the LDS is released
+}
+
+
+// =====================================================================================================================
+// Stream-K form of the persistent 256 x 256 kernel (gemm256sk_kernel).  Two things bound the data-parallel kernels at the step's shapes:
+// tile-count quantisation (588 tiles on 256 CUs = 3 rounds for 2.3 rounds of work) and the epilogue store bursts -- every CU finishes
+// its tile at the same moment, 256 x (128..256 KiB) hit HBM together while the matrix cores idle, then HBM idles for a whole K loop.
+// Here each XCD group (G/8 workgroups, one per CU) owns the same contiguous tile range as in gemm256p_kernel, but only its first
+// rounds are handed out whole: the LAST sk = W + (cnt mod W) tiles (W = G/8; all of them when cnt < 2 W) are cut along K into W equal
+// contiguous ranges of K-iterations, one per workgroup -- every workgroup does the same number of K-iterations (+-1).  A range covers,
+// in this processing order:
+//   1. the HEAD fragment [0, e) of the tile its end falls into -> the fp32 accumulators go to this workgroup's partial slot, flag published;
+//   2. one whole tile (of the stream-K region, or its first data-parallel tile);
+//   3. the TAIL fragment [b, nk) of the tile its start falls into: the accumulators are INITIALISED from the partial the previous
+//      workgroup (j - 1) published as its first item -- more than a tile's time ago, so the wait is a formality -- and the tile's MFMA
+//      chain is the unsplit one, continued: results are bitwise those of the data-parallel kernels, run to run and kernel to kernel;
+//      (third, not last: at the very end all 256 workgroups would fetch their 256 KiB partials in the same microseconds)
+//   4. the remaining whole tiles: stream-K region, then data-parallel tiles (j, j + W, ...).
+// Head fragments have different lengths, so the workgroups of a group are at different phases of their tiles for the rest of the
+// launch: the store bursts interleave with other CUs' K loops instead of piling up.
+// Hand-off (MI355X_MICROARCH.md, "hand-offs measured with sc1 loads", row 1): 16-byte sc1 stores of the partial by every wave; each
+// wave's next two K-loop waits drain them (vmcnt counts in issue order); after the second workgroup barrier that follows, ONE lane
+// publishes the launch's epoch (a process-wide 64-bit counter: no reset pass, stale memory cannot match) with an agent-scope store;
+// the consumer polls with agent-scope loads (one lane, bounded: 2 s, then the error word is set instead of hanging), workgroup
+// barrier, 16-byte sc1 loads.  A waiter only ever waits for a LOWER workgroup id (dispatched earlier), whose publishing item is its first.
+// =====================================================================================================================
+enum { SK_SLOT_BYTES = 262144, SK_MAX_ITEMS = 128 };
+// the launch's tag, re-read from the scalar kernel arguments where it is needed (kept in a VGPR pair across the K loop it gets spilled)
+__device__ __forceinline__ unsigned long long epoch_here(const GemmP& p) {
+    unsigned lo = (unsigned)p.sk_epoch, hi = (unsigned)(p.sk_epoch >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool TB, int SIDE>
+__global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2 + SK_MAX_ITEMS * 16];   // operand ring + this workgroup's item list (ONE LDS object:
+                                                                                        // a second one makes the compiler fence every LDS read behind the in-flight LDS-DMA)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / 64;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    const int xcd = blockIdx.x & 7, W = gridDim.x >> 3, j = blockIdx.x >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int cnt = q + (xcd < r ? 1 : 0);                 // >= W (host)
+    const int sk = cnt >= 2 * W ? W + cnt % W : cnt;       // tiles of the stream-K region: the last sk of the range
+    const int skb = cnt - sk, dp_rounds = skb / W;
+    const int64_t S0 = (int64_t)j * sk * nk / W, S1 = (int64_t)(j + 1) * sk * nk / W;
+    const int b = (int)(S0 % nk), tile_t = (int)(S0 / nk);
+    const int e = (int)(S1 % nk), tile_h = (int)(S1 / nk);
+    const int first_full = (int)((S0 + nk - 1) / nk), nfull = (int)(S1 / nk) - first_full;
+    const int has_head = e > 0 ? 1 : 0, has_tail = b > 0 ? 1 : 0;
+    const int nitems = has_head + nfull + dp_rounds + has_tail;                // <= SK_MAX_ITEMS (host)
+    // the item list of this workgroup, built once by its first threads: {m0, n0, first K-tile, end K-tile | kind << 24};
+    // kind 0 = whole tile, 1 = head fragment -> publish, 2 = tail fragment <- partial.  The loop keeps only the current item in scalars.
+    int4* item_tab = reinterpret_cast<int4*>(smem + 2 * STAGE2);
+    if (tid < nitems) {
+        const int n = tid;
+        int t, kb = 0, ke = nk, kind = 0;
+        const int pos_tail = has_head + ((nfull + dp_rounds) > 0 ? 1 : 0);
+        if (n < has_head) { t = skb + tile_h; ke = e; kind = 1; }
+        else if (has_tail && n == pos_tail) { t = skb + tile_t; kb = b; kind = 2; }
+        else {
+            const int w = n - has_head - ((has_tail && n > pos_tail) ? 1 : 0);    // index among the whole tiles: stream-K region first, then j, j + W, ...
+            t = w < nfull ? skb + first_full + w : j + W * (w - nfull);
+        }
+        int tm, tn;
+        tile_coords(base + t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        item_tab[n] = int4{tm * T2, tn * T2, kb, ke | (kind << 24)};
+    }
+    __syncthreads();
+    auto item = [&](int n, int& m0, int& n0, int& kb, int& ke, int& kind) {
+        const int4 it = item_tab[n];
+        m0 = __builtin_amdgcn_readfirstlane(it.x); n0 = __builtin_amdgcn_readfirstlane(it.y);
+        kb = __builtin_amdgcn_readfirstlane(it.z);
+        const int w = __builtin_amdgcn_readfirstlane(it.w);
+        ke = w & 0xffffff; kind = w >> 24;
+    };
+    int m0, n0, kb, ke, kind;
+    item(0, m0, n0, kb, ke, kind);
+    glds_tile<false>(A, p.lda, m0, kb * 64, smem, wave, lane);
+    glds_tile<TB>(B, p.ldb, n0, kb * 64, smem + 32768, wave, lane);
+    int ni = 1;                                            // index of the next item
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int pub = 0;                                           // > 0: workgroup barriers left before this workgroup's partial may be published
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int g = 0, kt = kb;; ++g) {
+        __builtin_amdgcn_s_barrier();                      // K-tile g has landed for every wave, and everyone is done reading stage (g + 1) & 1
+        asm volatile("" ::: "memory");
+        if (pub > 0) {                                     // (pub is wave-uniform: scalar)
+            pub = __builtin_amdgcn_readfirstlane(pub - 1);
+            if (pub == 0 && tid == 0) __hip_atomic_store(p.sk_flag + blockIdx.x, epoch_here(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        char* cur = smem + (g & 1) * STAGE2;
+        char* nxt = smem + ((g + 1) & 1) * STAGE2;
+        // source of K-tile g + 1: this item's next one, or the next item's first; at the very end a harmless re-read
+        const bool same = kt + 1 < ke;
+        const bool has_next = ni < nitems;
+        int am = m0, bn = n0, kn = (same ? kt + 1 : kt) * 64;
+        if (!same && has_next) {                           // (one LDS read per item)
+            const int4 it = item_tab[ni];
+            am = __builtin_amdgcn_readfirstlane(it.x); bn = __builtin_amdgcn_readfirstlane(it.y);
+            kn = __builtin_amdgcn_readfirstlane(it.z) * 64;
+        }
+        if constexpr (!TB) {
+            ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane, wm, wn);
+        } else {
+            glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane);
+            glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane);
+            ktile_generic<false, true>(acc, cur, lane, wm, wn);
+        }
+        if (same) {
+            ++kt;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA for K-tile g + 1 has landed
+            continue;
+        }
+        if (kind == 1) {
+            // head fragment: the fp32 accumulators, fragment order (1 KiB per instruction), write-through
+            const char* slot = reinterpret_cast<const char*>(p.sk_part) + (int64_t)blockIdx.x * SK_SLOT_BYTES + wave * 32768;
+            uint32_t vb = (uint32_t)lane * 16;
+            asm volatile("" : "+v"(vb));                   // opaque: the 32 store offsets are computed here, not hoisted out of the K loop as 32 live registers
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(vb + (uint32_t)(i * 4 + jj) * 1024), "v"(*reinterpret_cast<const u32x4*>(&acc[i][jj])),
+                                 "s"(slot) : "memory");
+            pub = 2;
+        } else {
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));               // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
+            epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
+        }
+        if (!has_next) break;
+        // >= 16 stores per wave were issued AFTER the DMA of the next item's first K-tile: wait for the DMA only, the stores drain under the next MFMAs
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        item(ni, m0, n0, kb, ke, kind);
+        kt = kb;
+        ++ni;
+        if (kind == 2) {
+            // tail fragment: continue the chain the previous workgroup of this group started (its slot, its flag)
+            if (tid == 0) {
+                const unsigned long long* f = p.sk_flag + (blockIdx.x - 8);
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                const unsigned long long want = epoch_here(p);
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {       // 2 s of the 100 MHz counter: flag it, do not hang
+                        __hip_atomic_store(p.sk_flag + gridDim.x, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.sk_part) + (int64_t)(blockIdx.x - 8) * SK_SLOT_BYTES, 0, SK_SLOT_BYTES, 0x00020000);
+            uint32_t vb = (uint32_t)lane * 16;
+            asm volatile("" : "+v"(vb));                   // opaque, as above
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vb, (wave * 32 + i * 4 + jj) * 1024, 16);
+                    acc[i][jj] = *reinterpret_cast<const f32x4*>(&v);
+                }
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // (once per workgroup: also drains the previous tile's stores)
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing re-read must land before the LDS is released; partial stores are drained
+    if (pub > 0) {                                         // (a head fragment followed by fewer than two K-iterations)
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.sk_flag + blockIdx.x, epoch_here(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 
@@ -1128,6 +1372,22 @@ extern "C" int64_t devias_gemm_workspace_bytes(int32_t M, int32_t N, int32_t spl
     return split_k > 1 ? (int64_t)split_k * M * N * 4 : 0;
 }
 
+// partial slots (one 256 x 256 fp32 tile per workgroup of the stream-K grid) + one 64-bit flag per workgroup + the error word
+extern "C" int64_t devias_gemm_streamk_workspace_bytes(void) {
+    int dev = 0, n = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    const int64_t g = n & ~7;
+    return g * SK_SLOT_BYTES + ((g + 1) * 8 + 255) / 256 * 256;
+}
+extern "C" int64_t devias_gemm_streamk_error_offset(void) {
+    int dev = 0, n = 256;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    const int64_t g = n & ~7;
+    return g * SK_SLOT_BYTES + g * 8;
+}
+
 // ---- process-wide options: read from the environment ONCE, changeable at run time through devias_set_option (tests, A/B tools) --------
 namespace {
 struct GemmKnobs {
@@ -1135,7 +1395,11 @@ struct GemmKnobs {
     int use256;        // "gemm256"         DEVIAS_GEMM256       0 disables the 256x256 kernels
     int use_ss;        // "gemm_ss"         DEVIAS_GEMM_SS       -1 = measured policy, 0 = never, 1 = prefer the single-stage 256x128 kernel for k-strided layouts
     int group_m;       // "gemm_groupm"     DEVIAS_GEMM_GROUPM   0 = measured policy, > 0 forces the rasterisation group height
-    int persistent;    // "gemm_persistent" DEVIAS_GEMM_PERSIST  1 = persistent 256x256 kernel where it applies (default), 0 = one tile per workgroup
+    int persistent;    // "gemm_persistent" DEVIAS_GEMM_PERSIST  != 0: persistent 256x256 kernel where it applies (default), 0 = one tile per workgroup
+    int streamk;       // "gemm_streamk"    DEVIAS_GEMM_SK       stream-K form of the persistent kernel (needs args.sk_ws): 0 = never, 1 = by policy (default),
+                       //                                        3 = wherever it can run (tests)
+    int sk_eff;        // "gemm_sk_eff"     DEVIAS_GEMM_SK_EFF   policy: tiles / (rounds * workgroups) below this many percent (default 80) ...
+    int sk_mink;       // "gemm_sk_mink"    DEVIAS_GEMM_SK_MINK  ... and at least this many K-tiles per output tile (default 32)
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
     int ncu;
 };
@@ -1148,6 +1412,9 @@ GemmKnobs& knobs() {
         x.use_ss = env_int("DEVIAS_GEMM_SS", -1);
         x.group_m = env_int("DEVIAS_GEMM_GROUPM", 0);
         x.persistent = env_int("DEVIAS_GEMM_PERSIST", 1);
+        x.streamk = env_int("DEVIAS_GEMM_SK", 1);
+        x.sk_eff = env_int("DEVIAS_GEMM_SK_EFF", 80);
+        x.sk_mink = env_int("DEVIAS_GEMM_SK_MINK", 32);
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
@@ -1166,6 +1433,9 @@ int devias_gemm_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_ss")) k.use_ss = value;
     else if (!strcmp(name, "gemm_groupm")) k.group_m = value;
     else if (!strcmp(name, "gemm_persistent")) k.persistent = value;
+    else if (!strcmp(name, "gemm_streamk")) k.streamk = value;
+    else if (!strcmp(name, "gemm_sk_eff")) k.sk_eff = value;
+    else if (!strcmp(name, "gemm_sk_mink")) k.sk_mink = value;
     else if (!strcmp(name, "gemm_debug")) k.debug = value;
     else return 0;
     return 1;
@@ -1227,6 +1497,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     p.epi_swap = kn.epi_swap;
     p.epi_vm = 16;
     p.nt_a = 0;
+    p.sk_part = nullptr; p.sk_flag = nullptr; p.sk_epoch = 0;
     // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
     // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
     p.group_m = kn.group_m > 0 ? kn.group_m : ((!a->trans_a && a->N >= 2048) ? 8 : 1);
@@ -1271,13 +1542,36 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         const int ta = a->trans_a, tb = a->trans_b;
         const int nt = p.tiles_m * p.tiles_n;
         const int gp = kn.ncu & ~7;
-        // persistent form: measured per shape at M = 50176 (tools/gemm_block_shapes.py, same box): NT qkv 226 -> 205 us, fc1 (bias only) 278 -> 250,
-        // the other NT shapes unchanged; the k-strided-B (dgrad) shapes of the step are 2-3 % SLOWER in it (dfc1 257 -> 263, dqkv 197 -> 204,
-        // dfc2+dGELU 408 -> 415) -> option gemm_persistent: 1 = NT only (default), 2 = NT and NN, 0 = never
-        if (kn.persistent && (!tb || kn.persistent >= 2) && !ta && split == 1 && !p.c_f32 && p.epi_swap && gp >= 8 && nt > gp) {
+        // persistent form (more than one round of tiles, no split-K, bf16 output): measured per shape at M = 50176 (tools/gemm_block_shapes.py, same
+        // box, one-tile-per-workgroup -> persistent): qkv 226 -> 204 us, fc1 278 -> 243, dfc2 + dGELU + colsum 415 -> 349, dfc2 plain 275 -> 248,
+        // dproj 81 -> 72; the long-K dgrad shapes unchanged (dfc1 252, dqkv 192)
+        const bool dact = a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU;
+        const int side = a->res ? 1 : (dact ? 2 : 0);      // rows the epilogue reads: a compile-time fact of the persistent kernels
+        const bool pers_ok = !ta && split == 1 && !p.c_f32 && p.epi_swap && gp >= 8 && !(a->res && dact) && (!tb ? side != 2 : side != 1) &&
+                             (!a->row_scale || p.rows_per_scale >= 128) && !(side == 2 && a->bias) && !(side == 1 && a->colsum) &&
+                             !(side != 0 && a->aux_out);
+#define PERS_LAUNCH(KERNEL) do { \
+            if (!tb) { if (side == 0) hipLaunchKernelGGL((KERNEL<false, 0>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<false, 1>), grid, block, 0, st, p); } \
+            else { if (side == 0) hipLaunchKernelGGL((KERNEL<true, 0>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<true, 2>), grid, block, 0, st, p); } } while (0)
+        // stream-K form: the caller lent a partial-slot workspace, every XCD group has at least one tile per workgroup, and the tile count is
+        // not a multiple of the grid (otherwise it degenerates to the persistent kernel's schedule)
+        // stream-K form: the caller lent a partial-slot workspace, every XCD group has at least one tile per workgroup, and (policy, measured at
+        // M = 50176 with tools/gemm_block_shapes.py) whole rounds would idle more than (100 - sk_eff) % of the chip while K is long enough to
+        // amortise the hand-off (one 256 KiB partial written and read per workgroup, ~8 us): fc2 275 -> 263 us, dfc1 252 -> 239, dqkv 192 -> 183;
+        // at K = 768 the same 588-tile grids lose (proj 92 -> 100, dproj 72 -> 80), and grids with < 10 % quantisation loss always lose
+        const bool sk_policy = kn.streamk >= 3 || ((int64_t)nt * 100 < (int64_t)cdiv(nt, gp) * gp * kn.sk_eff && a->K >= 64 * kn.sk_mink);
+        if (pers_ok && kn.streamk && a->sk_ws && aligned16(a->sk_ws) && a->sk_ws_bytes >= devias_gemm_streamk_workspace_bytes() &&
+            (nt >> 3) >= (gp >> 3) && nt % gp != 0 && sk_policy && ((nt >> 3) + 1) / (gp >> 3) + 4 <= SK_MAX_ITEMS) {
+            static std::atomic<unsigned long long> epoch{((unsigned long long)time(nullptr) << 24) | 1ull};
+            p.sk_part = reinterpret_cast<float*>(a->sk_ws);
+            p.sk_flag = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a->sk_ws) + (int64_t)gp * SK_SLOT_BYTES);
+            p.sk_epoch = ++epoch;
             dim3 grid(gp), block(NT2);
-            if (!tb) hipLaunchKernelGGL((gemm256p_kernel<false>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((gemm256p_kernel<true>), grid, block, 0, st, p);
+            PERS_LAUNCH(gemm256sk_kernel);
+            devias_count(DEVIAS_CNT_GEMM_SK);
+        } else if (kn.persistent && pers_ok && nt > gp) {
+            dim3 grid(gp), block(NT2);
+            PERS_LAUNCH(gemm256p_kernel);
             devias_count(DEVIAS_CNT_GEMM256P);
         } else {
             dim3 grid(nt, p.split_k), block(NT2);

@@ -58,12 +58,13 @@ const char* devias_last_error(void);
 #define DEVIAS_CNT_MHSA_BWD_BF16 7   /* MFMA backward, two kernels (dQ; dK/dV) */
 #define DEVIAS_CNT_MHSA_FWD_F32 8    /* VALU parity kernels */
 #define DEVIAS_CNT_MHSA_BWD_F32 9
+#define DEVIAS_CNT_GEMM_SK 11        /* 256x256 persistent kernel, stream-K schedule */
 #define DEVIAS_CNT_MHSA_BWD_FUSED 10 /* MFMA backward, single pass (dQ by ordered hand-off) */
 #define DEVIAS_CNT_MAX 16
 int64_t devias_counter(int32_t id);          /* -1 for an unknown id */
 void devias_counters_reset(void);
 /* Process-wide integer options (initialised once from the DEVIAS_* environment variables of the same meaning): "gemm_epi",
- * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_debug", "attn_cfg", "attn_xcd", "attn_bwd".  0 = ok, DEVIAS_EINVAL = unknown name. */
+ * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_streamk", "gemm_sk_eff", "gemm_sk_mink", "gemm_debug", "attn_cfg", "attn_xcd", "attn_bwd".  0 = ok, DEVIAS_EINVAL = unknown name. */
 int devias_set_option(const char* name, int32_t value);
 
 /* In-place SUM all-reduce of one flat gradient bucket over the caller's RCCL communicator (`nccl_comm` is an ncclComm_t; dtype DEVIAS_F32 or
@@ -116,8 +117,16 @@ typedef struct {
                                  C + i*stride_c (element strides).  bias / activation epilogues only (no split_k, res, aux, colsum).  Used for the
                                  per-head composite slot-attention weights and the per-clip context gradient of the folded slot attention. */
     int64_t stride_a, stride_b, stride_c;
+    void* sk_ws;              /* optional scratch of devias_gemm_streamk_workspace_bytes() bytes (16-byte aligned), private to launches of this stream:
+                                 lets large bf16 GEMMs run the stream-K schedule (balanced K-iterations per CU, bitwise the same results).  Contents
+                                 need no initialisation; the 64-bit word at devias_gemm_streamk_error_offset() is set non-zero if a hand-off
+                                 ever timed out (2 s; never observed -- the result of that launch is then invalid) */
+    int64_t sk_ws_bytes;
 } devias_gemm_args;
 int devias_gemm(const devias_gemm_args* args, void* stream);
+int64_t devias_gemm_streamk_workspace_bytes(void);
+/* byte offset, inside sk_ws, of the 64-bit hand-off error word (zero it once after allocating the scratch if you want to read it) */
+int64_t devias_gemm_streamk_error_offset(void);
 /* bytes of workspace devias_gemm needs for the given split_k (0 when split_k <= 1) */
 int64_t devias_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 

@@ -388,18 +388,27 @@ def gemm_options():
     """restores the process-wide kernel-selection options a test changes"""
     o = ops()
     yield o
-    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1)):
+    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 1)):
         o.set_option(k, v)
+
+
+def _persistent_serves(tb, epi):
+    """the persistent kernels are compiled per kind of row the epilogue reads: none / residual for B k-contiguous (forward GEMMs),
+    none / saved pre-activation for B k-strided (dgrad GEMMs); anything else runs the one-tile-per-workgroup kernel"""
+    return epi in (("bias", "plain", "gelu_aux", "dgelu_colsum") if tb else ("bias", "plain", "gelu_aux", "res", "res_rowscale"))
 
 
 @pytest.mark.parametrize("tb", [False, True])
 @pytest.mark.parametrize("epi", ["bias", "res", "gelu_aux", "dgelu_colsum", "plain", "res_rowscale"])
-@pytest.mark.parametrize("M,N,K", [(256 * 70, 1024, 128), (256 * 300, 256, 320), (256 * 99, 768, 768), (256 * 131, 512, 64)])
-def test_gemm_persistent_kernel(tb, epi, M, N, K, gemm_options):
-    """gemm256p_kernel (persistent: K-tile stream across tile boundaries, epilogue stores left in flight behind a counted vmcnt)
+@pytest.mark.parametrize("M,N,K", [(256 * 70, 1024, 128), (256 * 300, 256, 320), (256 * 99, 768, 768), (256 * 131, 512, 64),
+                                   (256 * 196, 768, 448), (256 * 196, 2304, 192)])
+def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
+    """gemm256p_kernel (persistent: K-tile stream across tile boundaries, asm-issued epilogue stores left in flight) and gemm256sk_kernel
+    (the same with the stream-K schedule: split tiles handed from one workgroup to the next as fp32 partials, the chain continued)
     against the fp32 op on the bf16-rounded inputs; the same call through the one-tile-per-workgroup kernel, with both epilogues,
-    must agree BITWISE (same MFMA order, same fp32 epilogue arithmetic).  Tile counts are not multiples of the CU count, K covers
-    one to twelve K-tiles, and the counters assert which kernel served each call."""
+    must agree BITWISE (same MFMA order, same fp32 epilogue arithmetic).  Tile counts are not multiples of the CU count (all-stream-K
+    ranges and ranges with 1 and 5 data-parallel rounds), K covers one to twelve K-tiles, and the counters assert which kernel
+    served each call."""
     o = gemm_options
     from devias_amd._lib import ACT_DGELU, ACT_GELU
     A = rnd(M, K, dtype=torch.bfloat16, seed=1)
@@ -423,8 +432,10 @@ def test_gemm_persistent_kernel(tb, epi, M, N, K, gemm_options):
         dg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
         kw = dict(act=ACT_DGELU, aux_in=pre); ref = ref * dg
     outs = {}
-    for mode in ("p", "0", "0s"):                          # persistent; one tile per workgroup, register-transposed epilogue; LDS-staged epilogue
-        o.set_option("gemm_persistent", 2 if mode == "p" else 0)      # 2: persistent for both B layouts
+    serves = _persistent_serves(tb, epi)
+    for mode in ("sk", "p", "0", "0s"):     # stream-K; persistent; one tile per workgroup with the register-transposed / the LDS-staged epilogue
+        o.set_option("gemm_streamk", 3 if mode == "sk" else 0)
+        o.set_option("gemm_persistent", 1 if mode in ("sk", "p") else 0)
         o.set_option("gemm_epi", 0 if mode.endswith("s") else 1)
         kw2 = dict(kw)
         if epi == "gelu_aux":
@@ -435,41 +446,64 @@ def test_gemm_persistent_kernel(tb, epi, M, N, K, gemm_options):
         c = o.gemm(A, B, trans_b=tb, **kw2)
         torch.cuda.synchronize()
         cnt = o.counters()
-        assert (cnt["gemm256p"], cnt["gemm256"]) == ((1, 0) if mode == "p" else (0, 1)), (mode, cnt)
+        want = {"sk": (1, 0, 0), "p": (0, 1, 0)}.get(mode if serves else "0", (0, 0, 1))
+        assert (cnt["gemm_sk"], cnt["gemm256p"], cnt["gemm256"]) == want, (mode, cnt)
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
-    c, aux, cs = outs["p"]
+    assert o.streamk_timeouts() == 0
+    c, aux, cs = outs["0"]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]
-    assert torch.equal(c, outs["0"][0]) and torch.equal(c, outs["0s"][0])
+    for mode in ("sk", "p", "0s"):
+        assert torch.equal(c, outs[mode][0]), mode
     if aux is not None:
-        assert torch.equal(aux, outs["0s"][1])
-        assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16] and torch.equal(aux, outs["0"][1])
+        assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16]
+        for mode in ("sk", "p", "0s"):
+            assert torch.equal(aux, outs[mode][1]), mode
     if cs is not None:
         assert rel(cs, c.float().sum(0)) < 1e-2                 # sums the fp32 values before bf16 rounding
-        assert rel(cs, outs["0"][2]) < 1e-5 and rel(cs, outs["0s"][2]) < 1e-5
+        for mode in ("sk", "p", "0s"):
+            assert rel(cs, outs[mode][2]) < 1e-5, mode
 
 
-def test_gemm_persistent_kernel_repeatable(gemm_options):
-    """the persistent kernel's hand-placed waits (counted vmcnt behind the epilogue stores, raw barriers) are a race surface: the
-    same launch repeated 30 times under a concurrent memory-bound stream must give bitwise identical results every time"""
+def test_gemm_persistent_kernels_repeatable(gemm_options):
+    """the persistent kernels' hand-placed waits (asm-issued stores behind counted vmcnt, raw barriers) and the stream-K hand-off
+    (write-through partials, flag after two drained waits) are a race surface: the same launches repeated 30 times under a concurrent
+    memory-bound stream must give bitwise the results of the one-tile-per-workgroup kernel every time, in both schedules"""
     o = gemm_options
-    M, N, K = 256 * 196, 768, 768
-    A = rnd(M, K, dtype=torch.bfloat16, seed=11)
-    W = rnd(N, K, dtype=torch.bfloat16, scale=0.05, seed=12)
-    Wt = rnd(K, N, dtype=torch.bfloat16, scale=0.05, seed=13)
-    bias = rnd(N, seed=14)
-    res = rnd(M, N, dtype=torch.bfloat16, seed=15)
+    from devias_amd._lib import ACT_DGELU, ACT_GELU
+    M, D = 256 * 196, 768
+    A = rnd(M, D, dtype=torch.bfloat16, seed=11)
+    W = rnd(D, D, dtype=torch.bfloat16, scale=0.05, seed=12)
+    W1 = rnd(4 * D, D, dtype=torch.bfloat16, scale=0.05, seed=16)
+    W2t = rnd(D, 4 * D, dtype=torch.bfloat16, scale=0.05, seed=13)        # dgrad of fc2: dy [M, D] @ W2 [D, 4D]
+    bias, bias1 = rnd(D, seed=14), rnd(4 * D, seed=17)
+    res = rnd(M, D, dtype=torch.bfloat16, seed=15)
+    pre = rnd(M, 4 * D, dtype=torch.bfloat16, seed=18)
+
+    def run():
+        aux = torch.empty(M, 4 * D, dtype=torch.bfloat16, device=DEV)
+        cs = torch.zeros(4 * D, device=DEV)
+        return (o.gemm(A, W, bias=bias, res=res), o.gemm(A, W1, bias=bias1, act=ACT_GELU, aux_out=aux), aux,
+                o.gemm(A, W2t, trans_b=True, act=ACT_DGELU, aux_in=pre, colsum=cs), o.gemm(A, W.t().contiguous(), trans_b=True), cs)
+
     o.set_option("gemm_persistent", 0)
-    ref_nt = o.gemm(A, W, bias=bias, res=res)
-    ref_nn = o.gemm(A, Wt, trans_b=True)
-    o.set_option("gemm_persistent", 2)
+    ref = run()
     junk = torch.empty(64 << 20, device=DEV)
     side = torch.cuda.Stream()
-    for it in range(30):
-        with torch.cuda.stream(side):
-            junk.add_(1.0)                                # uneven memory load next to the GEMM
-        assert torch.equal(o.gemm(A, W, bias=bias, res=res), ref_nt), it
-        assert torch.equal(o.gemm(A, Wt, trans_b=True), ref_nn), it
-    torch.cuda.synchronize()
+    for sk in (0, 3):
+        o.set_option("gemm_persistent", 1)
+        o.set_option("gemm_streamk", sk)                  # 3: stream-K whatever the quantisation loss
+        o.counters(reset=True)
+        for it in range(30):
+            with torch.cuda.stream(side):
+                junk.add_(1.0)                            # uneven memory load next to the GEMMs
+            got = run()
+            for a, b in zip(got[:5], ref[:5]):
+                assert torch.equal(a, b), (sk, it)
+            assert rel(got[5], ref[5]) < 1e-5
+        torch.cuda.synchronize()
+        cnt = o.counters()
+        assert (cnt["gemm_sk"], cnt["gemm256p"]) == ((120, 0) if sk else (0, 120)), cnt
+    assert o.streamk_timeouts() == 0
 
 
 # ------------------------------------------------------------------------------------------------ single-pass attention backward

@@ -1,0 +1,49 @@
+"""Per-tile timeline of the persistent 256 x 256 GEMM kernel (debug build, gemm_debug = 8): where a tile's time goes between the K loop, the
+epilogue, and the first K-iteration of the next tile (which has to wait for the epilogue's stores: vmcnt completes in issue order).
+Usage: python tools/gemm_pstamps.py [fc1|fc1g|proj|qkv]   (needs tools/exp/libdevias_amd_dbg.so: python tools/gemm_epi_ablate.py --rebuild)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["DEVIAS_LIB_PATH"] = os.path.join(ROOT, "tools", "exp", "libdevias_amd_dbg.so")
+import ctypes, torch, numpy as np
+from devias_amd import ops as o, _lib
+which = sys.argv[1] if len(sys.argv) > 1 else "fc1"
+M = 50176
+N, K = {"fc1": (3072, 768), "fc1g": (3072, 768), "proj": (768, 768), "qkv": (2304, 768), "fc2": (768, 3072)}[which]
+a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+bias = torch.randn(N, device="cuda") * 0.1
+out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+res = torch.randn(M, N, device="cuda").bfloat16()
+ws = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
+o.set_option("gemm_streamk", 0); o.set_option("gemm_persistent", 2); o.set_option("gemm_debug", 8)
+def call():
+    g = _lib.GemmArgs()
+    g.A, g.B, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K = M, N, K; g.lda, g.ldb, g.ldc = K, K, N
+    g.dtype = 1; g.split_k = 1; g.ws = ws.data_ptr(); g.bias = bias.data_ptr()
+    if which == "fc1g":
+        g.act = 1; g.aux_out = aux.data_ptr(); g.ld_aux = N
+    if which in ("proj", "fc2"):
+        g.res = res.data_ptr(); g.ldr = N
+    _lib.check(_lib.load().devias_gemm(ctypes.byref(g), torch.cuda.current_stream().cuda_stream), "gemm")
+for _ in range(3): call()
+torch.cuda.synchronize()
+assert o.counters()["gemm256p"] >= 3
+d = ws.cpu().numpy().reshape(256, 64)
+t = (d >> 4) / 100.0; code = d & 15
+kl, ep, first, steady = [], [], [], []
+t0 = t[:, 0].min()
+for b in range(256):
+    ev = [(t[b, i], code[b, i]) for i in range(64) if code[b, i] != 0]
+    for i in range(len(ev) - 1):
+        (ta, ca), (tb, cb) = ev[i], ev[i + 1]
+        if (ca, cb) == (1, 4): first.append(tb - ta)
+        if (ca, cb) == (4, 2): steady.append(tb - ta)
+        if (ca, cb) == (2, 3): ep.append(tb - ta)
+nk = K // 64
+span = (t.max() - t0)
+print(f"{which}: N={N} K={K}  kernel span {span:.1f} us, tiles/WG max {int((code == 2).sum(1).max())}")
+print(f"  first K-iteration of a tile (incl. wait for the previous tile's stores): med {np.median(first):.2f}  p90 {np.percentile(first, 90):.2f} us")
+print(f"  remaining {nk - 1} K-iterations: med {np.median(steady):.2f} us  -> {np.median(steady) / max(nk - 1, 1):.3f} us per iteration")
+print(f"  epilogue (K loop done -> stores issued, next tile's first K-tile landed): med {np.median(ep):.2f}  p90 {np.percentile(ep, 90):.2f} us")
