@@ -750,7 +750,10 @@ __device__ __forceinline__ void plain_fence(bf16x8 (&f)[N]) {
 // ---- one K-tile (64 deep) of the 256 x 256 tile: 64 MFMAs per wave ---------------------------------------------------------------------
 // NT layout, order pinned by hand: 16 steps of 4 MFMAs (one A row-tile x 4 B column-tiles); the 8 LDS-DMA instructions of the NEXT K-tile
 // (source origins a_next / b_next = first row of the tile at the K-tile's first k; nullptr = nothing to load) go one per step over the
-// first 8 steps, fragment reads run two steps ahead of their use.
+// first 8 steps, fragment reads run two steps ahead of their use.  Measured and NOT adopted (profiles/r2e_gemm_kloop_experiments.txt):
+// issuing the 8 LDS-DMA instructions 2 / 4 / 8 per step (+0.4 ... +1.3 % block time), and a rotated schedule with the workgroup barrier
+// after step 12 and the next K-tile's first fragments preloaded under the last 16 MFMAs (fc1 +-0 %, qkv -5 %, 28 more registers).  The K
+// loop runs at 1.55 us per K-tile = 70 % of its MFMA bound at the clock the CUs hold under this load (1.9 GHz, tools/gemm_pstamps.py).
 __device__ __forceinline__ void ktile_nt_pinned(f32x4 (&acc)[8][4], const char* cur, char* nxt, const bf16* a_next, int lda,
                                                 const bf16* b_next, int ldb, int wave, int lane, int wm, int wn) {
     const char* sA = cur; const char* sB = cur + 32768;
@@ -952,7 +955,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     int nlog = 0;
     auto stamp = [&](int code) {
         if (GDBG(8) && tid == 0 && nlog < 64) {
-            const unsigned long long v = (__builtin_amdgcn_s_memrealtime() << 4) | (unsigned long long)code;
+            // codes >= 8 log the SHADER clock counter instead (s_memtime): with the matching 100 MHz stamps that gives the clock the CU really runs at
+            const unsigned long long v = ((code >= 8 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime()) << 4) | (unsigned long long)code;
             asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)nlog * 8), "v"(v), "s"(reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 64) : "memory");
         }
         ++nlog;
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     for (int g = 0, kt = 0;; ++g) {
         __builtin_amdgcn_s_barrier();                      // K-tile g has landed for every wave, and everyone is done reading stage (g + 1) & 1
         asm volatile("" ::: "memory");
-        if (kt == 0) PSTAMP(1);
+        if (kt == 0) { PSTAMP(1); PSTAMP(9); }
         char* cur = smem + (g & 1) * STAGE2;
         char* nxt = smem + ((g + 1) & 1) * STAGE2;
         // source of K-tile g + 1: this tile's next one, or the next tile's first; at the very end a harmless re-read
@@ -986,7 +990,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             if (kt == 1) PSTAMP(4);
             continue;
         }
-        PSTAMP(2);
+        PSTAMP(2); PSTAMP(10);
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
         epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);

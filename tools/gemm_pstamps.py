@@ -4,7 +4,7 @@ Usage: python tools/gemm_pstamps.py [fc1|fc1g|proj|qkv]   (needs tools/exp/libde
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["DEVIAS_LIB_PATH"] = os.path.join(ROOT, "tools", "exp", "libdevias_amd_dbg.so")
+os.environ.setdefault("DEVIAS_LIB_PATH", os.path.join(ROOT, "tools", "exp", "libdevias_amd_dbg.so"))
 import ctypes, torch, numpy as np
 from devias_amd import ops as o, _lib
 which = sys.argv[1] if len(sys.argv) > 1 else "fc1"
@@ -32,10 +32,15 @@ torch.cuda.synchronize()
 assert o.counters()["gemm256p"] >= 3
 d = ws.cpu().numpy().reshape(256, 64)
 t = (d >> 4) / 100.0; code = d & 15
-kl, ep, first, steady = [], [], [], []
+kl, ep, first, steady, clk = [], [], [], [], []
 t0 = t[:, 0].min()
 for b in range(256):
-    ev = [(t[b, i], code[b, i]) for i in range(64) if code[b, i] != 0]
+    raw = [(int(d[b, i] >> 4), int(code[b, i])) for i in range(64) if code[b, i] != 0]
+    # shader-clock pairs (codes 9 -> 10) against the 100 MHz pairs (1 -> 2) of the same K loop
+    r1 = [v for v, c in raw if c == 1]; r2 = [v for v, c in raw if c == 2]; c9 = [v for v, c in raw if c == 9]; c10 = [v for v, c in raw if c == 10]
+    for i in range(min(len(r1), len(r2), len(c9), len(c10))):
+        if r2[i] > r1[i]: clk.append((c10[i] - c9[i]) / (r2[i] - r1[i]) * 100.0)
+    ev = [(t[b, i], code[b, i]) for i in range(64) if code[b, i] not in (0, 9, 10)]
     for i in range(len(ev) - 1):
         (ta, ca), (tb, cb) = ev[i], ev[i + 1]
         if (ca, cb) == (1, 4): first.append(tb - ta)
@@ -46,4 +51,5 @@ span = (t.max() - t0)
 print(f"{which}: N={N} K={K}  kernel span {span:.1f} us, tiles/WG max {int((code == 2).sum(1).max())}")
 print(f"  first K-iteration of a tile (incl. wait for the previous tile's stores): med {np.median(first):.2f}  p90 {np.percentile(first, 90):.2f} us")
 print(f"  remaining {nk - 1} K-iterations: med {np.median(steady):.2f} us  -> {np.median(steady) / max(nk - 1, 1):.3f} us per iteration")
+print(f"  shader clock during the K loops: med {np.median(clk):.0f} MHz (p10 {np.percentile(clk, 10):.0f}, p90 {np.percentile(clk, 90):.0f})")
 print(f"  epilogue (K loop done -> stores issued, next tile's first K-tile landed): med {np.median(ep):.2f}  p90 {np.percentile(ep, 90):.2f} us")
