@@ -84,7 +84,7 @@ def cpu_baseline(args):
 
 def dominant_kernel_probe(args, device):
     """Live HIP-event timing (on torch's current stream = the stream the kernels are launched on) of the dominant kernel
-    class, the 128x128 MFMA GEMM, on the fc1 shape of this workload."""
+    class, the persistent 256x256 MFMA GEMM, on the fc1 launch of this workload's encoder block."""
     from devias_amd import ops
     D = {"vit_base": 768, "vit_small": 384, "vit_large": 1024}[args.model]
     M = args.batch * (args.frames // 2) * (args.img_size // 16) ** 2
@@ -106,13 +106,13 @@ def dominant_kernel_probe(args, device):
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * M * 4 * D * D
     es = 2 if dt == torch.bfloat16 else 4
-    probe = {"name": "gemm256p_kernel<NT> persistent 256x256x64 LDS-DMA: fc1 forward of the encoder block (bias + GELU + saved pre-activation)",
+    probe = {"name": "gemm256p_kernel<false, 0> persistent 256x256x64 LDS-DMA: fc1 forward of the encoder block (bias + GELU + saved pre-activation)",
              "flop_per_launch": fl, "avg_ms": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
              "algorithmic_bytes": (M * D + 4 * D * D + 2 * M * 4 * D) * es}
     if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
         # HBM-side bytes per launch from the committed PMC passes of this same launch (profiles/r2_pmc: 2*FETCH_SIZE + WRITE_SIZE,
         # the gfx950 FETCH_SIZE correction applied)
-        probe["traffic"] = 1.0795e9
+        probe["traffic"] = 1.0804e9
         probe["traffic_source"] = "profiles/r2_pmc/README.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     return probe
 
@@ -235,7 +235,7 @@ def main():
                                f"B={B} clips/GPU, student fwd + matching loss + bwd" + (f" + RCCL grad all-reduce ({args.comm_dtype} wire format, 64 MiB fp32 buckets, side stream)" if world > 1 else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
-                   "kernels": "persistent 256x256 GEMM (NT), two-kernel MFMA attention backward, folded slot cross-attention (K/V projections on the slot side)"},
+                   "kernels": "persistent 256x256 GEMM (forward + dgrad; stream-K schedule for fc2 / dfc1 / dqkv), two-kernel MFMA attention backward, folded slot cross-attention (K/V projections on the slot side)"},
         "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
         "device_ms_per_step": dev_ms / args.steps, "final_loss": loss_value, "peak_mem_gib": peak_mem,
     }
