@@ -193,6 +193,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void mhsa_fwd_bf16_kernel(const bf16*
                 rv.load(base + 2 * D, RS, (t + 1) * 64, N, tid);
             }
         }
+        // a wave whose 16*QT queries all lie beyond N (the last workgroup of a head at N = 1568: 3 of its 4 waves) has staged its share of the
+        // tile and takes part in the barrier; it leaves the matrix cores to the co-resident workgroups
+        if constexpr (DMA) { if (q0 >= N) continue; }
         // S^T tile: acc_s[kt][qt] holds keys 16kt + 4g + r (rows) x query c (col)
         f32x4 acc_s[4][QT];
 #pragma unroll
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
             rk.load(base + D, RS, (t + 1) * 64, N, tid);
             rv.load(base + 2 * D, RS, (t + 1) * 64, N, tid);
         }
+        if (q0 < N) {                         // (waves without a valid query only stage and synchronise: see the forward kernel)
         f32x4 acc_s[4][QT], acc_dp[4][QT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -395,6 +399,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) acc_dq[dt][qt] = mfma(kf, dsf[qt], acc_dq[dt][qt]);
             }
+        }
         }
         __syncthreads();
     }
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             if (tid < 64) rstat = r0 + tid < N ? lse_bh[r0 + tid] * LOG2E : INFINITY;
             else if (tid < 128) rstat = r0 + tid - 64 < N ? dl_bh[r0 + tid - 64] : 0.f;
         }
+        if (key0 < N) {                       // (waves without a valid key only stage and synchronise: see the forward kernel)
         // S and dP tiles: acc[qt][kt] holds queries 16qt + 4g + r (rows) x key c (col)
         f32x4 acc_s[4][2], acc_dp[4][2];
 #pragma unroll
@@ -517,6 +523,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
                     acc_dk[dt][kt] = mfma(qt_, dsf[kt], acc_dk[dt][kt]);
                 }
             }
+        }
         }
         __syncthreads();
     }
