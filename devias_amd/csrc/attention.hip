@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
                                                                const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
                                                                int N, int H, float scale, int xcd) {
-    __shared__ __attribute__((aligned(16))) char smem[16384];
+    __shared__ __attribute__((aligned(16))) char smem[32768];     // two stages of (K image | V image), filled by LDS-DMA one tile ahead
     char* imgKt = smem;            // K, one image for both uses: row reads (S^T = K Q^T) and transposed reads (dQ^T = K^T dS^T)
     char* imgV = smem + 8192;      // V rows   (dP^T = V dO^T)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -335,16 +335,20 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
         for (int j = 0; j < QT; ++j) acc_dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkv = (N + 63) / 64;
-    TileRegs<NW * 64> rk, rv;
-    rk.load(base + D, RS, 0, N, tid);
-    rv.load(base + 2 * D, RS, 0, N, tid);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    dma_tile<NW, true>(base + D, RS, 0, N, smem, wv, lane);
+    dma_tile<NW, false>(base + 2 * D, RS, 0, N, smem + 8192, wv, lane);
     for (int t = 0; t < nkv; ++t) {
-        rk.store_tr(imgKt, tid);
-        rv.store_rows(imgV, tid);
+        // one barrier per tile: tile t has landed for every wave, and everyone is done reading tile t-1's stage (rows past N re-read row N-1:
+        // finite data whose probabilities are exactly zero)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        imgKt = smem + (t & 1) * 16384;
+        imgV = imgKt + 8192;
         if (t + 1 < nkv) {
-            rk.load(base + D, RS, (t + 1) * 64, N, tid);
-            rv.load(base + 2 * D, RS, (t + 1) * 64, N, tid);
+            char* nxt = smem + ((t + 1) & 1) * 16384;
+            dma_tile<NW, true>(base + D, RS, (t + 1) * 64, N, nxt, wv, lane);
+            dma_tile<NW, false>(base + 2 * D, RS, (t + 1) * 64, N, nxt + 8192, wv, lane);
         }
         if (q0 < N) {                         // (waves without a valid query only stage and synchronise: see the forward kernel)
         f32x4 acc_s[4][QT], acc_dp[4][QT];
@@ -401,7 +405,6 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
             }
         }
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -418,11 +421,12 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
                                                                  bf16* __restrict__ dqkv, int N, int H, float scale, int xcd) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 512];
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 2 * 512];   // two stages of (Q image | dO image) filled by LDS-DMA one tile ahead, + their row statistics
     char* imgQt = smem;             // Q, one image: row reads (S = Q K^T) and transposed reads (dK^T = Q^T dS)
     char* imgOt = smem + 8192;      // dO, one image: row reads (dP = dO V^T) and transposed reads (dV^T = dO^T P)
-    float* s_lse = reinterpret_cast<float*>(smem + 16384);   // [64] log2-domain logsumexp (+inf for invalid rows)
-    float* s_dl = s_lse + 64;                                // [64] delta
+    float* s_stat = reinterpret_cast<float*>(smem + 32768);  // per stage: [64] log2-domain logsumexp (+inf for invalid rows) | [64] delta
+    const float* s_lse = s_stat;
+    const float* s_dl = s_stat + 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const HeadMap hm = head_map((N + 127) / 128, H, xcd >> 16, (xcd & 1) != 0);
     const int h = hm.h, b = hm.b;
@@ -452,23 +456,36 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
     const int nq = (N + 63) / 64;
     const float* lse_bh = lse + ((int64_t)b * H + h) * N;
     const float* dl_bh = delta + ((int64_t)b * H + h) * N;
-    TileRegs<256> rq, rdo;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    // row statistics of query tile r0 / 64 for thread tid < 128 (rows past N: p = exp2(-inf) = 0 whatever the re-read Q / dO rows hold)
+    auto stat_load = [&](int r0) -> float {
+        if (tid < 64) return r0 + tid < N ? lse_bh[r0 + tid] * LOG2E : INFINITY;
+        return r0 + tid - 64 < N ? dl_bh[r0 + tid - 64] : 0.f;
+    };
     float rstat = 0.f;
-    rq.load(base, RS, 0, N, tid);
-    rdo.load(dobase, D, 0, N, tid);
-    if (tid < 64) rstat = tid < N ? lse_bh[tid] * LOG2E : INFINITY;
-    else if (tid < 128) rstat = (tid - 64) < N ? dl_bh[tid - 64] : 0.f;
+    dma_tile<4, true>(base, RS, 0, N, smem, wv, lane);
+    dma_tile<4, true>(dobase, D, 0, N, smem + 8192, wv, lane);
+    if (tid < 128) {
+        s_stat[tid] = stat_load(0);
+        if (nq > 1) rstat = stat_load(64);      // always one tile ahead of the LDS copy
+    }
     for (int t = 0; t < nq; ++t) {
-        rq.store_tr(imgQt, tid);
-        rdo.store_tr(imgOt, tid);
-        if (tid < 128) s_lse[tid] = rstat;      // s_dl follows s_lse contiguously
+        // one barrier per tile: tile t (images by LDS-DMA, statistics by the ds_write below / above) is complete for every wave, and
+        // everyone is done reading tile t-1's stage
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        imgQt = smem + (t & 1) * 16384;
+        imgOt = imgQt + 8192;
+        s_lse = s_stat + (t & 1) * 128;
+        s_dl = s_lse + 64;
         if (t + 1 < nq) {
-            const int r0 = (t + 1) * 64;
-            rq.load(base, RS, r0, N, tid);
-            rdo.load(dobase, D, r0, N, tid);
-            if (tid < 64) rstat = r0 + tid < N ? lse_bh[r0 + tid] * LOG2E : INFINITY;
-            else if (tid < 128) rstat = r0 + tid - 64 < N ? dl_bh[r0 + tid - 64] : 0.f;
+            char* nxt = smem + ((t + 1) & 1) * 16384;
+            dma_tile<4, true>(base, RS, (t + 1) * 64, N, nxt, wv, lane);
+            dma_tile<4, true>(dobase, D, (t + 1) * 64, N, nxt + 8192, wv, lane);
+            if (tid < 128) {
+                s_stat[((t + 1) & 1) * 128 + tid] = rstat;
+                if (t + 2 < nq) rstat = stat_load((t + 2) * 64);
+            }
         }
         if (key0 < N) {                       // (waves without a valid key only stage and synchronise: see the forward kernel)
         // S and dP tiles: acc[qt][kt] holds queries 16qt + 4g + r (rows) x key c (col)
@@ -525,7 +542,6 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             }
         }
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
