@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DEVIAS_LIB_PATH") or os.path.join(_HERE, "libdevias_amd.so")     # (override: ablation builds of tools/)
 
 F32, BF16 = 0, 1
+ABI_VERSION = 140                # devias_version() of the library these prototypes describe
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4, 5
 
 
@@ -126,6 +127,8 @@ def load() -> ctypes.CDLL:
             raise DeviasLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.devias_version() < ABI_VERSION:         # an older build has a shorter devias_gemm_args: never call into it
+        raise DeviasLibraryError(f"{LIB_PATH} is ABI version {lib.devias_version()}, this binding needs {ABI_VERSION}; rebuild it (python -m devias_amd.build --force)")
     _lib = lib
     return lib
 

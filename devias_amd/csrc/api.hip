@@ -12,7 +12,7 @@ int devias_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int devias_version(void) { return 130; }   // 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options
+extern "C" int devias_version(void) { return 140; }   // 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options, 140: stream-K GEMM (args struct grew)
 
 // ---- launch counters: which kernel family served a call (tests assert that the measured kernels are the ones under test) ----
 #include <atomic>

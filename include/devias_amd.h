@@ -43,7 +43,8 @@ extern "C" {
 #define DEVIAS_ACT_DGELU 4     /* backward: v *= gelu'(aux_in) with aux_in = saved pre-activation */
 #define DEVIAS_ACT_DRELU 5     /* backward: v = aux_in > 0 ? v : 0 with aux_in = saved ReLU output */
 
-int devias_version(void);          /* 100 + additions: 110 = multi-tensor optimizer entry points, 120 = devias_fame_*, 130 = counters + options */
+int devias_version(void);          /* 100 + additions: 110 = multi-tensor optimizer entry points, 120 = devias_fame_*, 130 = counters + options,
+                                    140 = stream-K GEMM schedule (devias_gemm_args grew by sk_ws / sk_ws_bytes: recompile callers), devias_allreduce_bucket */
 const char* devias_last_error(void);
 /* Launch counters: one per kernel family, incremented by the host side of each entry point (process-wide, relaxed atomics).
  * Tests use them to ASSERT that the kernels a parity claim is made for are the kernels that ran (the reference has no analogue:
