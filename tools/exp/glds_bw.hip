@@ -6,7 +6,8 @@
 typedef __attribute__((address_space(3))) void* lds_p;
 typedef const __attribute__((address_space(1))) void* glb_p;
 
-template <int MODE>   // 0: row-strided (ld elements per row), 1: tile-contiguous (each 1 KiB instruction reads 1 KiB contiguous)
+template <int MODE>   // 0: row-strided (ld elements per row), 1: tile-contiguous (each 1 KiB instruction reads 1 KiB contiguous),
+                      // 2: row-strided in HALF lines (16 rows x 64 B per instruction: the 32-deep units of a four-slot ring)
 __global__ __launch_bounds__(512) void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, int ld, int nk, int tiles_n, int ntiles, float* out) {
     __shared__ __attribute__((aligned(16))) char smem[131072];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -22,7 +23,12 @@ __global__ __launch_bounds__(512) void k(const uint16_t* __restrict__ A, const u
                 for (int i = 0; i < 4; ++i) {
                     const int r8 = wave * 32 + i * 8;
                     const uint16_t *sa, *sb;
-                    if (MODE == 0) {
+                    if (MODE == 2) {
+                        // instruction i of 4: k-half i >> 1, rows (wave * 2 + (i & 1)) * 16 + (lane >> 2), 16-byte chunk lane & 3 of that half
+                        const int row = (wave * 2 + (i & 1)) * 16 + (lane >> 2), half = i >> 1;
+                        sa = A + (int64_t)(tm * 256 + row) * ld + kt * 64 + half * 32 + (lane & 3) * 8;
+                        sb = B + (int64_t)(tn * 256 + row) * ld + kt * 64 + half * 32 + (lane & 3) * 8;
+                    } else if (MODE == 0) {
                         const int row = r8 + (lane >> 3), chunk = (lane & 7) ^ (row & 7);
                         sa = A + (int64_t)(tm * 256 + row) * ld + kt * 64 + chunk * 8;
                         sb = B + (int64_t)(tn * 256 + row) * ld + kt * 64 + chunk * 8;
@@ -56,6 +62,7 @@ int main() {
     (void)hipMalloc(&A, (size_t)50176 * 3072 * 2); (void)hipMalloc(&B, (size_t)4096 * 3072 * 2); (void)hipMalloc(&out, 64);
     (void)hipMemset(A, 0, (size_t)50176 * 3072 * 2); (void)hipMemset(B, 0, (size_t)4096 * 3072 * 2);
     run<0>("row-strided qkv", A, B, 50176, 2304, 768, out);
+    run<2>("row-strided half lines qkv", A, B, 50176, 2304, 768, out);
     run<1>("tile-contiguous qkv", A, B, 50176, 2304, 768, out);
     run<0>("row-strided fc1", A, B, 50176, 3072, 768, out);
     run<1>("tile-contiguous fc1", A, B, 50176, 3072, 768, out);

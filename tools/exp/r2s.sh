@@ -1,0 +1,23 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2s; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+i=0
+for c in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_BUSY_CYCLES" "SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_MISC"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/p$i -- python3 $R/tools/pmc_gemm.py > /dev/null 2> $O/p$i.err
+done
+python3 - <<'PY'
+import csv, glob, collections, os, statistics as st
+O=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/r2s'
+res=collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(O+'/p*/*/*_counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k=r['Kernel_Name']
+        if 'gemm256p' not in k: continue
+        res[k][r['Counter_Name']].append(float(r['Counter_Value']))
+with open(O+'/summary.txt','w') as fo:
+    for k,v in res.items():
+        fo.write(k[:80]+'\n')
+        for c,vals in sorted(v.items()):
+            fo.write(f"   {c:32s} {st.median(vals):16.0f}\n")
+print(open(O+'/summary.txt').read())
+PY
