@@ -917,6 +917,9 @@ template <bool TB, int SIDE>
 __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef DEVIAS_GEMM_DEBUG
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
@@ -962,6 +965,10 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
         ++nlog;
     };
 #define PSTAMP(c) stamp(c)
+    if (GDBG(8) && tid == 0) {           // slot 63: the workgroup's entry time
+        const unsigned long long v = (t_entry << 4) | 7ull;
+        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)63 * 8), "v"(v), "s"(reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 64) : "memory");
+    }
 #else
 #define PSTAMP(c)
 #endif
@@ -1103,6 +1110,21 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
         for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
     int pub = 0;                                           // > 0: workgroup barriers left before this workgroup's partial may be published
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DEVIAS_GEMM_DEBUG
+    // gemm_debug & 8: thread 0 logs (100 MHz clock << 4 | code) into ws + 64 * blockIdx.x: 1 = an item's first K-tile about to be multiplied, 2 = its K loop done,
+    // 3 = epilogue / partial store issued, 5 = about to wait for the predecessor's partial, 6 = partial loaded
+    int nlog = 0;
+    auto sstamp = [&](int code) {
+        if (GDBG(8) && tid == 0 && nlog < 64) {
+            const unsigned long long v = (__builtin_amdgcn_s_memrealtime() << 4) | (unsigned long long)code;
+            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)nlog * 8), "v"(v), "s"(reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 64) : "memory");
+        }
+        ++nlog;
+    };
+#define SSTAMP(c) sstamp(c)
+#else
+#define SSTAMP(c)
+#endif
     for (int g = 0, kt = kb;; ++g) {
         __builtin_amdgcn_s_barrier();                      // K-tile g has landed for every wave, and everyone is done reading stage (g + 1) & 1
         asm volatile("" ::: "memory");
@@ -1110,6 +1132,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
             pub = __builtin_amdgcn_readfirstlane(pub - 1);
             if (pub == 0 && tid == 0) __hip_atomic_store(p.sk_flag + blockIdx.x, epoch_here(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (kt == kb) SSTAMP(1);
         char* cur = smem + (g & 1) * STAGE2;
         char* nxt = smem + ((g + 1) & 1) * STAGE2;
         // source of K-tile g + 1: this item's next one, or the next item's first; at the very end a harmless re-read
@@ -1133,6 +1156,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA for K-tile g + 1 has landed
             continue;
         }
+        SSTAMP(2);
         if (kind == 1) {
             // head fragment: the fp32 accumulators, fragment order (1 KiB per instruction), write-through
             const char* slot = reinterpret_cast<const char*>(p.sk_part) + (int64_t)blockIdx.x * SK_SLOT_BYTES + wave * 32768;
@@ -1150,6 +1174,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
             asm volatile("" : "+v"(lane_e));               // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
             epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
         }
+        SSTAMP(3);
         if (!has_next) break;
         // >= 16 stores per wave were issued AFTER the DMA of the next item's first K-tile: wait for the DMA only, the stores drain under the next MFMAs
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -1158,6 +1183,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
         ++ni;
         if (kind == 2) {
             // tail fragment: continue the chain the previous workgroup of this group started (its slot, its flag)
+            SSTAMP(5);
             if (tid == 0) {
                 const unsigned long long* f = p.sk_flag + (blockIdx.x - 8);
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1182,6 +1208,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
                     acc[i][jj] = *reinterpret_cast<const f32x4*>(&v);
                 }
             __builtin_amdgcn_s_waitcnt(0x0F70);            // (once per workgroup: also drains the previous tile's stores)
+            SSTAMP(6);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i)

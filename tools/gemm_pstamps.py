@@ -40,14 +40,21 @@ for b in range(256):
     r1 = [v for v, c in raw if c == 1]; r2 = [v for v, c in raw if c == 2]; c9 = [v for v, c in raw if c == 9]; c10 = [v for v, c in raw if c == 10]
     for i in range(min(len(r1), len(r2), len(c9), len(c10))):
         if r2[i] > r1[i]: clk.append((c10[i] - c9[i]) / (r2[i] - r1[i]) * 100.0)
-    ev = [(t[b, i], code[b, i]) for i in range(64) if code[b, i] not in (0, 9, 10)]
+    ev = [(t[b, i], code[b, i]) for i in range(63) if code[b, i] not in (0, 9, 10)]
     for i in range(len(ev) - 1):
         (ta, ca), (tb, cb) = ev[i], ev[i + 1]
         if (ca, cb) == (1, 4): first.append(tb - ta)
         if (ca, cb) == (4, 2): steady.append(tb - ta)
         if (ca, cb) == (2, 3): ep.append(tb - ta)
 nk = K // 64
-span = (t.max() - t0)
+ent = t[:, 63]; first_kt = np.array([t[b, 0] for b in range(256)]); last = np.array([max(t[b, i] for i in range(63) if code[b, i] not in (0, 9, 10)) for b in range(256)])
+span = (last.max() - t0)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): call()
+e1.record(); torch.cuda.synchronize()
+print(f"{which}: back-to-back launch time {e0.elapsed_time(e1) / 20 * 1e3:.1f} us;  workgroup entry spread {ent.max() - ent.min():.1f} us;  entry -> first K-tile multiplied: med {np.median(first_kt - ent):.2f} max {np.max(first_kt - ent):.2f} us;  "
+      f"first entry -> last epilogue issued {last.max() - ent.min():.1f} us")
 print(f"{which}: N={N} K={K}  kernel span {span:.1f} us, tiles/WG max {int((code == 2).sum(1).max())}")
 print(f"  first K-iteration of a tile (incl. wait for the previous tile's stores): med {np.median(first):.2f}  p90 {np.percentile(first, 90):.2f} us")
 print(f"  remaining {nk - 1} K-iterations: med {np.median(steady):.2f} us  -> {np.median(steady) / max(nk - 1, 1):.3f} us per iteration")
