@@ -984,12 +984,16 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
         const bool same = kt + 1 < nk;
         const int am = (same || !has_next) ? m0 : m0n, bn = (same || !has_next) ? n0 : n0n;
         const int kn = same ? (kt + 1) * 64 : (has_next ? 0 : kt * 64);
+        // the lane id is recomputed per K-tile (v_mbcnt) and made opaque: the per-lane LDS / LDS-DMA offsets derived from it are then cheap VALU work of
+        // every iteration instead of registers that stay live across the epilogue, whose register peak is the kernel's (-14 registers)
+        int lane_k = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_k));
         if constexpr (!TB) {
-            ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane, wm, wn);
+            ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
         } else {
-            glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane);
-            glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane);
-            ktile_generic<false, true>(acc, cur, lane, wm, wn);
+            glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
+            glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
+            ktile_generic<false, true>(acc, cur, lane_k, wm, wn);
         }
         if (same) {
             ++kt;
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             continue;
         }
         PSTAMP(2); PSTAMP(10);
-        int lane_e = lane;
+        int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
         epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
         if (!has_next) break;
@@ -1055,6 +1059,9 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2 + SK_MAX_ITEMS * 16];   // operand ring + this workgroup's item list (ONE LDS object:
                                                                                         // a second one makes the compiler fence every LDS read behind the in-flight LDS-DMA)
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef DEVIAS_GEMM_DEBUG
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
@@ -1122,6 +1129,10 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
         ++nlog;
     };
 #define SSTAMP(c) sstamp(c)
+    if (GDBG(8) && tid == 0) {           // slot 63: the workgroup's entry time
+        const unsigned long long v = (t_entry << 4) | 7ull;
+        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)63 * 8), "v"(v), "s"(reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 64) : "memory");
+    }
 #else
 #define SSTAMP(c)
 #endif
@@ -1130,7 +1141,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
         asm volatile("" ::: "memory");
         if (pub > 0) {                                     // (pub is wave-uniform: scalar)
             pub = __builtin_amdgcn_readfirstlane(pub - 1);
-            if (pub == 0 && tid == 0) __hip_atomic_store(p.sk_flag + blockIdx.x, epoch_here(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pub == 0 && (wave == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)) __hip_atomic_store(p.sk_flag + blockIdx.x, epoch_here(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (kt == kb) SSTAMP(1);
         char* cur = smem + (g & 1) * STAGE2;
@@ -1144,12 +1155,16 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
             am = __builtin_amdgcn_readfirstlane(it.x); bn = __builtin_amdgcn_readfirstlane(it.y);
             kn = __builtin_amdgcn_readfirstlane(it.z) * 64;
         }
+        // the lane id is recomputed per K-tile (v_mbcnt) and made opaque: the per-lane LDS / LDS-DMA offsets derived from it are then cheap VALU work of
+        // every iteration instead of registers that stay live across the epilogue, whose register peak is the kernel's
+        int lane_k = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_k));
         if constexpr (!TB) {
-            ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane, wm, wn);
+            ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
         } else {
-            glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane);
-            glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane);
-            ktile_generic<false, true>(acc, cur, lane, wm, wn);
+            glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
+            glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
+            ktile_generic<false, true>(acc, cur, lane_k, wm, wn);
         }
         if (same) {
             ++kt;
@@ -1160,7 +1175,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
         if (kind == 1) {
             // head fragment: the fp32 accumulators, fragment order (1 KiB per instruction), write-through
             const char* slot = reinterpret_cast<const char*>(p.sk_part) + (int64_t)blockIdx.x * SK_SLOT_BYTES + wave * 32768;
-            uint32_t vb = (uint32_t)lane * 16;
+            uint32_t vb = (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 16;
             asm volatile("" : "+v"(vb));                   // opaque: the 32 store offsets are computed here, not hoisted out of the K loop as 32 live registers
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -1170,8 +1185,9 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
                                  "s"(slot) : "memory");
             pub = 2;
         } else {
-            int lane_e = lane;
-            asm volatile("" : "+v"(lane_e));               // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
+            // the lane id is recomputed (v_mbcnt), not kept: neither it nor the epilogue's per-lane address arithmetic occupies registers across the K loop
+            int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane_e));
             epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
         }
         SSTAMP(3);
@@ -1184,7 +1200,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
         if (kind == 2) {
             // tail fragment: continue the chain the previous workgroup of this group started (its slot, its flag)
             SSTAMP(5);
-            if (tid == 0) {
+            if ((wave == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)) {
                 const unsigned long long* f = p.sk_flag + (blockIdx.x - 8);
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 const unsigned long long want = epoch_here(p);
@@ -1198,7 +1214,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
             }
             __syncthreads();
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.sk_part) + (int64_t)(blockIdx.x - 8) * SK_SLOT_BYTES, 0, SK_SLOT_BYTES, 0x00020000);
-            uint32_t vb = (uint32_t)lane * 16;
+            uint32_t vb = (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 16;
             asm volatile("" : "+v"(vb));                   // opaque, as above
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -1219,7 +1235,7 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing re-read must land before the LDS is released; partial stores are drained
     if (pub > 0) {                                         // (a head fragment followed by fewer than two K-iterations)
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(p.sk_flag + blockIdx.x, epoch_here(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((wave == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)) __hip_atomic_store(p.sk_flag + blockIdx.x, epoch_here(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

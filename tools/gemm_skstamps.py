@@ -30,7 +30,7 @@ t = (d >> 4) / 100.0; code = d & 15
 nk = K // 64
 kl, ep, waitp, loadp, span = [], [], [], [], []
 for b in range(256):
-    ev = [(t[b, i], int(code[b, i])) for i in range(64) if code[b, i] != 0]
+    ev = [(t[b, i], int(code[b, i])) for i in range(63) if code[b, i] != 0]
     if not ev: continue
     span.append(ev[-1][0] - ev[0][0])
     for i in range(len(ev) - 1):
@@ -39,6 +39,13 @@ for b in range(256):
         if (ca, cb) == (2, 3): ep.append(tb - ta)
         if (ca, cb) == (3, 5): waitp.append(tb - ta)
         if (ca, cb) == (5, 6): loadp.append(tb - ta)
+ent = t[:, 63]; first_kt = t[:, 0]; last = np.array([max(t[b, i] for i in range(63) if code[b, i] != 0) for b in range(256)])
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): call()
+e1.record(); torch.cuda.synchronize()
+print(f"{which}: back-to-back launch time {e0.elapsed_time(e1) / 20 * 1e3:.1f} us;  workgroup entry spread {ent.max() - ent.min():.1f} us;  entry -> first K-tile multiplied: med {np.median(first_kt - ent):.2f} max {np.max(first_kt - ent):.2f} us;  "
+      f"first entry -> last item finished {last.max() - ent.min():.1f} us")
 print(f"{which}: N={N} K={K}  per-workgroup span med {np.median(span):.1f} max {np.max(span):.1f} us")
 print(f"  item K loops: med {np.median(kl):.2f} us (whole tiles {nk} K-tiles -> {np.percentile(kl, 75) / nk:.3f} us per K-tile at p75)")
 print(f"  epilogue / partial store: med {np.median(ep):.2f}  p90 {np.percentile(ep, 90):.2f} us")
