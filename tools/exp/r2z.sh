@@ -1,5 +1,5 @@
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2z; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2zz; mkdir -p $O
 cd $R
 timeout 2400 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
