@@ -31,12 +31,10 @@ struct GemmP {
     const float* row_scale; int rows_per_scale;   // optional per-sample scale of (acc+bias, act) before the residual (stochastic depth)
     float* colsum_part;   // optional: per-(wave row-tile) partial column sums of the stored output, [M / (16*NI)][N]
     int group_m;          // tile rasterisation: GM row-tiles per group (m fastest inside a group); 1 = n fastest
-    int nt_a;             // LDS-DMA cache policy of the A operand (aux bits), experiments
     int epi_swap;         // 1 = register-transposed epilogue (epilogue_swap), 0 = LDS-staged (epilogue_staged)
     int debug;            // timing ablations, compiled in only with -DDEVIAS_GEMM_DEBUG (option "gemm_debug"): 1 = one K-tile, 2 = no epilogue,
                           // 4 = no LDS-DMA after tile 0, 8 = s_memrealtime stamps into ws, 64 = epilogue without its C stores,
                           // 128 = without its pre-activation stores, 256 = without the GELU / dGELU polynomial
-    int epi_vm;           // persistent kernel: VMEM operations every wave is guaranteed to issue in one epilogue (counted vmcnt)
     int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
     float* sk_part; unsigned long long* sk_flag; unsigned long long sk_epoch;   // stream-K kernel: partial slots, flags (+ error word), this launch's tag
 };
@@ -909,7 +907,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
 // last K-tile of the current one is multiplied, so its fetch (an HBM / L2 round trip that nothing hides in the one-tile-per-workgroup
 // kernel) lands under those MFMAs and the register-only epilogue (epilogue_swap).  The epilogue's stores are left in flight:
 // the wait at the top of the next tile's first K-tile is a COUNTED vmcnt that covers the LDS-DMA only (vmcnt is in issue order and
-// every wave issues >= p.epi_vm (16) stores after the DMA), so the output drains under the next tile's MFMAs.
+// every wave issues >= 16 stores after the DMA), so the output drains under the next tile's MFMAs.
 // Tile order: XCD x (block ids congruent to x mod 8) owns the same contiguous range of logical tiles as in xcd_remap; its G/8 workgroups
 // stride through it together, so at any moment an XCD works on ~32 consecutive tiles (operand panels shared in its L2).
 // =====================================================================================================================
@@ -1542,8 +1540,6 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
                        "devias_gemm: batched launches support bias / activation epilogues only (no split-K, residual, aux, colsum)");
     p.debug = kn.debug;
     p.epi_swap = kn.epi_swap;
-    p.epi_vm = 16;
-    p.nt_a = 0;
     p.sk_part = nullptr; p.sk_flag = nullptr; p.sk_epoch = 0;
     // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
     // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
