@@ -12,4 +12,5 @@ b1 = torch.randn(F, device="cuda") * 0.1
 for _ in range(3):
     o.gemm(x, W1, bias=b1)                      # gemm256p_kernel<false, 0>: B k-contiguous (pinned K-tile)
     o.gemm(g, W2, trans_b=True)                 # gemm256p_kernel<true, 0>: B k-strided (transposing LDS reads)
+    o.wgrad(g, x)                               # gemm256_kernel<true, true>: both operands k-strided, split-K
 torch.cuda.synchronize()
