@@ -160,13 +160,16 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    from devias_amd import _lib as _dl
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _dl.CALLS[0] = 0
     t0 = time.perf_counter()
     e0.record()
     for _ in range(args.steps):
         loss = step()
     e1.record()
     host_enqueue = time.perf_counter() - t0          # host time to ENQUEUE the K steps (the device is still running): launch-bound check
+    lib_calls = _dl.CALLS[0] / args.steps              # host -> library compute calls per step (one per fused region and direction)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -236,7 +239,7 @@ def main():
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
                    "kernels": "persistent 256x256 GEMM (forward + dgrad; stream-K schedule for fc2 / dfc1 / dqkv), two-kernel MFMA attention backward, folded slot cross-attention (K/V projections on the slot side)"},
-        "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
+        "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "host_library_calls_per_step": lib_calls,
         "device_ms_per_step": dev_ms / args.steps, "final_loss": loss_value, "peak_mem_gib": peak_mem,
     }
     if ach is not None:

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DEVIAS_LIB_PATH") or os.path.join(_HERE, "libdevias_amd.so")     # (override: ablation builds of tools/)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 140                # devias_version() of the library these prototypes describe
+ABI_VERSION = 150                # devias_version() of the library these prototypes describe
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4, 5
 
 
@@ -41,6 +41,54 @@ class GemmArgs(Structure):
 class LossDims(Structure):
     _fields_ = [(n, c_int32) for n in ("B", "S", "C", "nb", "ns", "D", "G", "N", "nh")] + \
                [("w_scene", c_float), ("w_mask_pred", c_float), ("w_mask_distill", c_float), ("dtype", c_int32)]
+
+
+_FP = POINTER(c_float)
+
+
+class BlockArgs(Structure):          # devias_block_args
+    _fields_ = [(n, c_int32) for n in ("B", "N", "D", "H", "hidden", "dtype")] + [("eps", c_float)] + \
+               [(n, c_void_p) for n in ("n1w", "n1b", "n2w", "n2b", "Wqkv", "Wp", "W1", "W2", "qkv_bias", "pb", "b1", "b2", "ds1", "ds2", "save", "ws")] + \
+               [("ws_bytes", c_int64), ("sk_ws", c_void_p), ("sk_ws_bytes", c_int64)]
+
+
+class BlockGrads(Structure):         # devias_block_grads
+    _fields_ = [(n, c_void_p) for n in ("dn1w", "dn1b", "dWqkv", "dbqkv", "dWp", "dbp", "dn2w", "dn2b", "dW1", "db1", "dW2", "db2", "dx_colsum")] + \
+               [("db2_done", c_int32)]
+
+
+class HeadArgs(Structure):           # devias_head_args
+    _fields_ = [(n, c_int32) for n in ("R", "D", "C", "h1", "h2", "G", "dtype")] + \
+               [(n, c_void_p) for n in ("Wh", "W0", "W2", "W4", "bh", "b0", "b2", "b4", "ws")] + [("ws_bytes", c_int64)]
+
+
+class HeadGrads(Structure):          # devias_head_grads
+    _fields_ = [(n, c_void_p) for n in ("dWh", "dbh", "dW0", "db0", "dW2", "db2", "dW4", "db4")]
+
+
+AGG_MAX_DEPTH = 16                   # DEVIAS_AGG_MAX_DEPTH
+AGG_PARAM_FIELDS = ("Wq", "Wk", "Wv", "Wo", "W1", "W2", "bo", "norm_w", "norm_b", "ctx_w", "ctx_b", "b1", "b2", "ffn_w", "ffn_b")
+AGG_GRAD_FIELDS = ("dWq", "dWk", "dWv", "dWo", "dbo", "dnorm_w", "dnorm_b", "dctx_w", "dctx_b", "dW1", "db1", "dW2", "db2", "dffn_w", "dffn_b")
+
+
+class AggLayerParams(Structure):     # devias_agg_layer_params
+    _fields_ = [(n, c_void_p) for n in AGG_PARAM_FIELDS]
+
+
+class AggLayerGrads(Structure):      # devias_agg_layer_grads
+    _fields_ = [(n, c_void_p) for n in AGG_GRAD_FIELDS]
+
+
+class AggArgs(Structure):            # devias_agg_args
+    _fields_ = [(n, c_int32) for n in ("B", "N", "S", "D", "depth", "tied", "heads", "dh", "ff", "dtype")] + \
+               [("eps_enc", c_float), ("eps_agg", c_float)] + \
+               [(n, c_void_p) for n in ("norm_w", "norm_b", "latents", "last_w", "last_b")] + \
+               [("sets", AggLayerParams * AGG_MAX_DEPTH), ("save", c_void_p), ("ws", c_void_p), ("ws_bytes", c_int64)]
+
+
+class AggGrads(Structure):           # devias_agg_grads
+    _fields_ = [(n, c_void_p) for n in ("dnorm_w", "dnorm_b", "dlatents", "dlast_w", "dlast_b", "dx_colsum")] + \
+               [("sets", AggLayerGrads * AGG_MAX_DEPTH)]
 
 
 # name -> (restype, argtypes); mirrors include/devias_amd.h one to one
@@ -94,6 +142,24 @@ PROTOTYPES = {
     "devias_fame_seg_refine": (c_int, [_P, _P, _I, _I, _I, _F, _P, _P]),
     "devias_fame_binarize_pool": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "devias_fame_mix": (c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "devias_range_push": (None, [c_char_p]),
+    "devias_range_pop": (None, []),
+    "devias_encoder_block_save_bytes": (c_int64, [_I, _I, _I, _I, _I, _I]),
+    "devias_encoder_block_scratch_bytes": (c_int64, [_I, _I, _I, _I, _I, _I]),
+    "devias_encoder_block_workspace_bytes": (c_int64, [_I, _I, _I, _I, _I, _I]),
+    "devias_encoder_block_fwd": (c_int, [POINTER(BlockArgs), _P, _P, _P]),
+    "devias_encoder_block_bwd": (c_int, [POINTER(BlockArgs), _P, _P, _P, POINTER(BlockGrads), _P, _L, _P]),
+    "devias_head_workspace_bytes": (c_int64, [_I, _I, _I, _I, _I, _I, _I]),
+    "devias_head_save_bytes": (c_int64, [_I, _I, _I, _I, _I]),
+    "devias_head_fwd": (c_int, [POINTER(HeadArgs), _P, _P, _P, _P, _P]),
+    "devias_head_bwd": (c_int, [POINTER(HeadArgs), _P, _P, _P, _P, _P, _P, POINTER(HeadGrads), _P]),
+    "devias_agg_block_save_bytes": (c_int64, [POINTER(AggArgs)]),
+    "devias_agg_block_scratch_bytes": (c_int64, [POINTER(AggArgs)]),
+    "devias_agg_block_workspace_bytes": (c_int64, [POINTER(AggArgs)]),
+    "devias_agg_block_fwd": (c_int, [POINTER(AggArgs), _P, _P, POINTER(c_void_p), _P]),
+    "devias_agg_block_bwd": (c_int, [POINTER(AggArgs), _P, _P, _P, _P, POINTER(AggGrads), _P, _L, _P]),
+    "devias_policy_small_m_split": (c_int32, [_I, _I, _I, _I]),
+    "devias_policy_wgrad_split": (c_int32, [_I, _I, _I, _I]),
 }
 COUNTERS = {"gemm128_f32": 0, "gemm128_bf16": 1, "gemm_ss": 2, "gemm256": 3, "gemm256p": 4, "splitk_reduce": 5,
             "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10, "gemm_sk": 11}     # DEVIAS_CNT_*
@@ -133,7 +199,11 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+CALLS = [0]                      # host -> library compute calls since the last reset (bench.py reports calls per step)
+
+
 def check(rc: int, what: str) -> None:
+    CALLS[0] += 1
     if rc != 0:
         msg = load().devias_last_error()
         raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

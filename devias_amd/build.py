@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdevias_amd.so")
-SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "layernorm.hip", "attention.hip", "slot_attn.hip", "loss.hip", "fame.hip"]
+SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "layernorm.hip", "attention.hip", "slot_attn.hip", "loss.hip", "fame.hip", "regions.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
          "-fno-gpu-rdc", "-mllvm", "-amdgpu-early-inline-all=true",
@@ -34,7 +34,7 @@ def _stale() -> bool:
 
 def _compile(src: str) -> str:
     obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "devias_amd.h")]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "roctx_shim.h"), os.path.join(HERE, "..", "include", "devias_amd.h")]
     if os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
         return obj
     cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]

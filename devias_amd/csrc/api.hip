@@ -12,7 +12,7 @@ int devias_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int devias_version(void) { return 140; }   // 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options, 140: stream-K GEMM (args struct grew)
+extern "C" int devias_version(void) { return 150; }   // 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options, 140: stream-K GEMM (args struct grew), 150: fused regions, roctx ranges
 
 // ---- launch counters: which kernel family served a call (tests assert that the measured kernels are the ones under test) ----
 #include <atomic>
@@ -77,3 +77,35 @@ extern "C" int devias_allreduce_bucket(void* nccl_comm, void* bucket, int64_t co
 
 // nothing persistent is allocated by the library; shutdown resets the launch counters (kept for hosts written against SURVEY.md §8b's export list)
 extern "C" void devias_shutdown(void) { devias_counters_reset(); }
+
+
+// ---- ROCTX ranges (roctx_shim.h) ------------------------------------------------------------------------------------------------------------
+#include "roctx_shim.h"
+#include <stdlib.h>
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+static roctx_push_fn g_roctx_push = nullptr;
+static roctx_pop_fn g_roctx_pop = nullptr;
+static int g_roctx_state = -1;          // -1 = not resolved yet, 0 = off, 1 = on
+static int roctx_resolve() {
+    const char* e = getenv("DEVIAS_ROCTX");
+    if (!e || atoi(e) == 0) return 0;
+    const char* libs[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+    for (const char* l : libs) {
+        void* h = dlopen(l, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) return 1;
+    }
+    return 0;
+}
+bool devias_roctx_enabled(void) {
+    if (g_roctx_state < 0) g_roctx_state = roctx_resolve();
+    return g_roctx_state == 1;
+}
+void devias_roctx_push(const char* name) { if (devias_roctx_enabled()) g_roctx_push(name); }
+void devias_roctx_pop(void) { if (devias_roctx_enabled()) g_roctx_pop(); }
+// for hosts (the Python engine marks the loss, the optimizer and whole steps with these)
+extern "C" void devias_range_push(const char* name) { devias_roctx_push(name ? name : "devias"); }
+extern "C" void devias_range_pop(void) { devias_roctx_pop(); }

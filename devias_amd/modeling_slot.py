@@ -107,6 +107,7 @@ class _WeightCache:
     def __init__(self):
         self._c = _WeakIdDict()                      # Parameter -> (stamp, compute-dtype copy)
         self._cat = _WeakIdDict()                    # first Parameter of a concatenation -> {ids of the others: (stamps, weakrefs, copy)}
+        self._qkvb = _WeakIdDict()                   # q_bias Parameter -> (stamps, weakref to v_bias, fp32 q_bias | 0 | v_bias)
         self.casts = 0                               # number of casts performed (tests)
 
     @staticmethod
@@ -149,41 +150,57 @@ _WCACHE = _WeightCache()
 
 # column sums of a residual-stream gradient, produced for free by the LayerNorm-backward kernel that wrote it and consumed by the
 # next backward region as the bias gradient of its last Linear.  The sum travels ON the gradient tensor object (autograd hands the
-# same object to the next node when there is a single consumer); if autograd had to build a new tensor (accumulation, hooks) the
-# attribute is simply absent and the column sum is recomputed -- a stale sum can never be picked up.
+# same object to the next node when there is a single consumer) together with the tensor's storage address and VERSION COUNTER at the
+# time of publication.  Two ways the sum could go stale are both caught: autograd builds a new tensor (hooks, out-of-place
+# accumulation): the attribute is absent; autograd accumulates a second consumer's gradient IN PLACE into the tagged tensor
+# (InputBuffer does that when the residual stream feeds two consumers): `_version` has moved.  In both cases the sum is recomputed.
 _COLSUM_STATS = {"hit": 0, "miss": 0}
 
 
 def _publish_colsum(dx: torch.Tensor, cs: torch.Tensor) -> None:
-    dx._devias_colsum = (cs, dx.data_ptr())
+    dx._devias_colsum = (cs, dx.data_ptr(), dx._version)
+
+
+def _peek_colsum(dy: torch.Tensor) -> Optional[torch.Tensor]:
+    """the published column sums of `dy` if they are still those of its current contents, else None (the tag is consumed either way)"""
+    tag = getattr(dy, "_devias_colsum", None)
+    if tag is None:
+        _COLSUM_STATS["miss"] += 1
+        return None
+    del dy._devias_colsum
+    cs, ptr, ver = tag
+    if ptr == dy.data_ptr() and ver == dy._version and cs.numel() == dy.shape[1] and cs.device == dy.device:
+        _COLSUM_STATS["hit"] += 1
+        return cs
+    _COLSUM_STATS["miss"] += 1
+    return None
 
 
 def _take_colsum(dy: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    tag = getattr(dy, "_devias_colsum", None)
-    if tag is not None:
-        del dy._devias_colsum
-        cs, ptr = tag
-        if ptr == dy.data_ptr() and cs.numel() == dy.shape[1] and cs.device == dy.device:
-            _COLSUM_STATS["hit"] += 1
-            if out is not None:
-                out.copy_(cs)
-                return out
-            return cs
-    _COLSUM_STATS["miss"] += 1
+    cs = _peek_colsum(dy)
+    if cs is not None:
+        if out is not None:
+            out.copy_(cs)
+            return out
+        return cs
     return ops.colsum(dy, out=out)
 
 
 # ---- gradient destinations ---------------------------------------------------------------------------------------------------------
 # A data-parallel gradient bucket (devias_amd.parallel.GradSync) registers, on every parameter, the fp32 view of its flat bucket
-# (`_devias_grad_out`).  When the parameter has no gradient yet, the weight-gradient kernels write straight into that view and return
-# it: autograd adopts the tensor as `.grad` without a copy, so a bucket is complete the moment its last kernel finishes (no pack pass).
+# (`_devias_grad_out`).  When the parameter has no gradient yet, the weight-gradient kernels write straight into that view and a FRESH
+# alias of it is returned to autograd: AccumulateGrad adopts a gradient tensor without copying only when nobody else holds a reference to
+# that tensor object (the registered view is held by GradSync and by the parameter attribute, so returning it would be cloned -- ADVICE r2).
+# A bucket is then complete the moment its last kernel finishes (no pack pass, no copy).
 def _gout(p: Optional[torch.Tensor], shape=None) -> Optional[torch.Tensor]:
     if p is None or p.grad is not None:
         return None                                   # accumulation (update_freq > 1, tied uses): autograd adds a fresh tensor in place
     v = getattr(p, "_devias_grad_out", None)
     if v is None:
         return None
-    return v if shape is None else v.view(shape)
+    if v.device != p.device:
+        raise RuntimeError("gradient bucket and parameter live on different devices: build GradSync AFTER model.to(device)")
+    return v.view(v.shape if shape is None else shape)
 
 
 # ---- weight-gradient side stream ------------------------------------------------------------------------------------
@@ -642,6 +659,266 @@ class HeadFn(Function):
 
 
 # =====================================================================================================
+# fused regions: ONE library call per region and direction (devias_encoder_block_* / devias_agg_block_* / devias_head_*)
+# =====================================================================================================
+# The kernel sequence of a region is issued by the library (csrc/regions.hip) -- the same launches in the same order as the per-kernel
+# Functions above, bitwise the same results (tests/test_regions_gpu.py) -- so a step costs ~40 Python -> library hops instead of ~750.
+# What backward needs lives in ONE arena tensor per region call, backward temporaries in a grow-only scratch buffer per stream, the
+# parameter gradients of a region in one flat fp32 tensor (or straight in the data-parallel gradient bucket views).
+import ctypes as _ct
+
+from . import _lib as _L
+
+_REGIONS = _os.environ.get("DEVIAS_REGIONS", "1") != "0"
+_scratch_bufs = {}
+
+
+def _scratch(nbytes: int, device) -> torch.Tensor:
+    """grow-only backward scratch per (device, stream): the temporaries of a region's backward are dead when its kernels have run, and the
+    kernels of one stream are ordered"""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
+    buf = _scratch_bufs.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _scratch_bufs.pop(key, None)
+        buf = _scratch_bufs[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return buf
+
+
+class _GradDest:
+    """fp32 gradient destinations of one region: a parameter whose gradient bucket view is free gets that view (a fresh alias, see _gout);
+    the others are carved out of ONE flat tensor"""
+
+    def __init__(self, items, device):
+        self.out = []
+        views = [(_gout(p, shape) if p is not None else None) for p, shape in items]
+        total = 0
+        for (p, shape), v in zip(items, views):
+            if v is None:
+                total += (math.prod(shape) + 63) // 64 * 64           # 256-byte aligned pieces
+        flat = torch.empty((total,), dtype=torch.float32, device=device) if total else None
+        off = 0
+        for (p, shape), v in zip(items, views):
+            if v is None:
+                n = math.prod(shape)
+                v = flat[off:off + n].view(shape)
+                off += (n + 63) // 64 * 64
+            self.out.append(v)
+
+    def ptrs(self):
+        return [t.data_ptr() for t in self.out]
+
+
+def _qkv_bias(qb: torch.Tensor, vb: torch.Tensor) -> torch.Tensor:
+    """fp32 [3D] = q_bias | zeros | v_bias (modeling_slot.py:97-99), rebuilt only when one of the two changed"""
+    stamp = (_WCACHE._stamp(qb), _WCACHE._stamp(vb))
+    hit = _WCACHE._qkvb.get(qb)
+    if hit is not None and hit[0] == stamp and hit[1]() is vb:
+        return hit[2]
+    t = torch.cat((_f32(qb), torch.zeros_like(_f32(vb)), _f32(vb))).contiguous()
+    _WCACHE._qkvb[qb] = (stamp, weakref.ref(vb), t)
+    return t
+
+
+class EncoderBlockRegionFn(Function):
+    """EncoderBlockFn as one devias_encoder_block_fwd / _bwd call (Block.forward, modeling_slot.py:142-152)"""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkvw, qb, vb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, meta, ds1=None, ds2=None):
+        B, N, H, eps, cdt = meta
+        lib = _L.load()
+        dev = x.device
+        D = x.shape[1]
+        hid = f1w.shape[0]
+        dt = ops.dt_code(cdt)
+        x = x.contiguous()
+        keep = [_f32(n1w), _f32(n1b), _f32(n2w), _f32(n2b)] + [_WCACHE.get(w, cdt) for w in (qkvw, pw, f1w, f2w)] + \
+               [_qkv_bias(qb, vb), _f32(pb), _f32(f1b), _f32(f2b)]
+        save = torch.empty((lib.devias_encoder_block_save_bytes(B, N, D, H, hid, dt),), dtype=torch.uint8, device=dev)
+        ws = ops.workspace(lib.devias_encoder_block_workspace_bytes(B, N, D, H, hid, dt), dev)
+        a = _L.BlockArgs()
+        a.B, a.N, a.D, a.H, a.hidden, a.dtype, a.eps = B, N, D, H, hid, dt, eps
+        (a.n1w, a.n1b, a.n2w, a.n2b, a.Wqkv, a.Wp, a.W1, a.W2, a.qkv_bias, a.pb, a.b1, a.b2) = [t.data_ptr() for t in keep]
+        a.ds1 = ds1.data_ptr() if ds1 is not None else None
+        a.ds2 = ds2.data_ptr() if ds2 is not None else None
+        a.save, a.ws, a.ws_bytes = save.data_ptr(), ws.data_ptr(), ws.numel() * 4
+        if cdt == torch.bfloat16:
+            sk = ops.streamk_workspace(dev)
+            a.sk_ws, a.sk_ws_bytes = sk.data_ptr(), sk.numel()
+        x2 = torch.empty_like(x)
+        _L.check(lib.devias_encoder_block_fwd(_ct.byref(a), x.data_ptr(), x2.data_ptr(), ops._stream()), "devias_encoder_block_fwd")
+        ctx.args = a
+        ctx.meta = meta
+        ctx.keep = (keep, save, ds1, ds2, x)
+        ctx.params = (n1w, n1b, qkvw, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        B, N, H, eps, cdt = ctx.meta
+        lib = _L.load()
+        a = ctx.args
+        keep, save, ds1, ds2, x = ctx.keep
+        (p_n1w, p_n1b, p_qkvw, p_pw, p_pb, p_n2w, p_n2b, p_f1w, p_f1b, p_f2w, p_f2b) = ctx.params
+        dev = x.device
+        D, hid = a.D, a.hidden
+        dx2 = dx2.contiguous()
+        ready = _peek_colsum(dx2) if ds2 is None else None          # colsum(dx2) = fc2 bias gradient, published by the next block's LayerNorm backward
+        b2_dst = _gout(p_f2b) if ready is not None else None
+        gd = _GradDest([(p_n1w, (D,)), (p_n1b, (D,)), (p_qkvw, (3 * D, D)), (None, (3 * D,)), (p_pw, (D, D)), (p_pb, (D,)), (p_n2w, (D,)), (p_n2b, (D,)),
+                        (p_f1w, (hid, D)), (p_f1b, (hid,)), (p_f2w, (D, hid)), (None if ready is not None else p_f2b, (1,) if ready is not None else (D,)),
+                        (None, (D,))], dev)
+        g = _L.BlockGrads()
+        (g.dn1w, g.dn1b, g.dWqkv, g.dbqkv, g.dWp, g.dbp, g.dn2w, g.dn2b, g.dW1, g.db1, g.dW2, g.db2, g.dx_colsum) = gd.ptrs()
+        g.db2_done = 1 if ready is not None else 0
+        ws = ops.workspace(a.ws_bytes, dev)                 # (the stream's workspace may have been re-allocated larger since forward)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        nscr = lib.devias_encoder_block_scratch_bytes(B, N, D, H, hid, a.dtype)
+        scr = _scratch(nscr, dev)
+        dx = torch.empty_like(x)
+        _L.check(lib.devias_encoder_block_bwd(_ct.byref(a), x.data_ptr(), dx2.data_ptr(), dx.data_ptr(), _ct.byref(g), scr.data_ptr(), scr.numel(), ops._stream()),
+                 "devias_encoder_block_bwd")
+        ctx.keep = ctx.args = None
+        (dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, dxs) = gd.out
+        if ready is not None:
+            db2 = ready if b2_dst is None else b2_dst.copy_(ready)
+        _publish_colsum(dx, dxs)
+        return (dx, dn1w, dn1b, dWqkv, dbqkv[:D], dbqkv[2 * D:], dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None)
+
+
+class HeadRegionFn(Function):
+    """HeadFn as one devias_head_fwd / _bwd call"""
+
+    @staticmethod
+    def forward(ctx, slots, hw, hb, w0, b0, w2, b2, w4, b4, cdt):
+        lib = _L.load()
+        dev = slots.device
+        slots = slots.contiguous()
+        R, D = slots.shape
+        C, h1, h2, G = hw.shape[0], w0.shape[0], w2.shape[0], w4.shape[0]
+        dt = ops.dt_code(cdt)
+        keep = [_WCACHE.get(w, cdt) for w in (hw, w0, w2, w4)] + [_f32(hb), _f32(b0), _f32(b2), _f32(b4)]
+        ws = ops.workspace(lib.devias_head_workspace_bytes(R, D, C, h1, h2, G, dt), dev)
+        a = _L.HeadArgs()
+        a.R, a.D, a.C, a.h1, a.h2, a.G, a.dtype = R, D, C, h1, h2, G, dt
+        (a.Wh, a.W0, a.W2, a.W4, a.bh, a.b0, a.b2, a.b4) = [t.data_ptr() for t in keep]
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        save = torch.empty((lib.devias_head_save_bytes(R, h1, h2, G, dt),), dtype=torch.uint8, device=dev)
+        Z = torch.empty((R, C), dtype=cdt, device=dev)
+        Mk = torch.empty((R, G), dtype=cdt, device=dev)
+        _L.check(lib.devias_head_fwd(_ct.byref(a), slots.data_ptr(), Z.data_ptr(), Mk.data_ptr(), save.data_ptr(), ops._stream()), "devias_head_fwd")
+        ctx.args = a
+        ctx.keep = (keep, save, slots, Mk)
+        ctx.params = (hw, hb, w0, b0, w2, b2, w4, b4)
+        return Z, Mk
+
+    @staticmethod
+    def backward(ctx, dZ, dM):
+        lib = _L.load()
+        a = ctx.args
+        keep, save, slots, Mk = ctx.keep
+        hw, hb, w0, b0, w2, b2, w4, b4 = ctx.params
+        dev = slots.device
+        dZ = dZ.contiguous() if dZ is not None else torch.zeros((a.R, a.C), dtype=slots.dtype, device=dev)
+        dM = dM.contiguous() if dM is not None else torch.zeros_like(Mk)
+        gd = _GradDest([(hw, tuple(hw.shape)), (hb, tuple(hb.shape)), (w0, tuple(w0.shape)), (b0, tuple(b0.shape)), (w2, tuple(w2.shape)), (b2, tuple(b2.shape)),
+                        (w4, tuple(w4.shape)), (b4, tuple(b4.shape))], dev)
+        g = _L.HeadGrads()
+        (g.dWh, g.dbh, g.dW0, g.db0, g.dW2, g.db2, g.dW4, g.db4) = gd.ptrs()
+        ws = ops.workspace(a.ws_bytes, dev)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        dslots = torch.empty_like(slots)
+        _L.check(lib.devias_head_bwd(_ct.byref(a), slots.data_ptr(), Mk.data_ptr(), save.data_ptr(), dZ.data_ptr(), dM.data_ptr(), dslots.data_ptr(),
+                                     _ct.byref(g), ops._stream()), "devias_head_bwd")
+        ctx.keep = ctx.args = None
+        return (dslots, *gd.out, None)
+
+
+_AGG_MATS = ("to_q", "to_k", "to_v", "to_out_w", "ff0_w", "ff3_w")                       # -> devias_agg_layer_params.Wq Wk Wv Wo W1 W2
+_AGG_VECS = ("to_out_b", "norm_w", "norm_b", "ctx_w", "ctx_b", "ff0_b", "ff3_b", "ffn_w", "ffn_b")   # -> bo norm_w norm_b ctx_w ctx_b b1 b2 ffn_w ffn_b
+# gradient order of devias_agg_layer_grads (dWq dWk dWv dWo dbo dnorm_w dnorm_b dctx_w dctx_b dW1 db1 dW2 db2 dffn_w dffn_b) in _LAYER_KEYS names
+_AGG_GRAD_KEYS = ("to_q", "to_k", "to_v", "to_out_w", "to_out_b", "norm_w", "norm_b", "ctx_w", "ctx_b", "ff0_w", "ff0_b", "ff3_w", "ff3_b", "ffn_w", "ffn_b")
+
+
+class AggBlockRegionFn(Function):
+    """AggBlockFoldFn as one devias_agg_block_fwd / _bwd call"""
+
+    @staticmethod
+    def forward(ctx, x, norm_w, norm_b, latents, last_w, last_b, meta, *layer_params):
+        B, N, S, depth, tied, heads, dh, eps_enc, eps_agg, cdt = meta
+        lib = _L.load()
+        dev = x.device
+        x = x.contiguous()
+        D = x.shape[1]
+        nset = 1 if tied else depth
+        assert len(layer_params) == nset * len(_LAYER_KEYS) and depth <= _L.AGG_MAX_DEPTH
+        LP = [dict(zip(_LAYER_KEYS, layer_params[i * 15:(i + 1) * 15])) for i in range(nset)]
+        dt = ops.dt_code(cdt)
+        a = _L.AggArgs()
+        a.B, a.N, a.S, a.D, a.depth, a.tied, a.heads, a.dh, a.ff, a.dtype = B, N, S, D, depth, int(bool(tied)), heads, dh, LP[0]["ff0_w"].shape[0], dt
+        a.eps_enc, a.eps_agg = eps_enc, eps_agg
+        keep = [_f32(norm_w), _f32(norm_b), _f32(latents), _f32(last_w), _f32(last_b)]
+        (a.norm_w, a.norm_b, a.latents, a.last_w, a.last_b) = [t.data_ptr() for t in keep]
+        for i, P in enumerate(LP):
+            mats = [_WCACHE.get(P[k], cdt) for k in _AGG_MATS]
+            vecs = [_f32(P[k]) for k in _AGG_VECS]
+            keep += mats + vecs
+            for f, t in zip(_L.AGG_PARAM_FIELDS, mats + vecs):
+                setattr(a.sets[i], f, t.data_ptr())
+        save = torch.empty((lib.devias_agg_block_save_bytes(_ct.byref(a)),), dtype=torch.uint8, device=dev)
+        a.save = save.data_ptr()
+        ws = ops.workspace(lib.devias_agg_block_workspace_bytes(_ct.byref(a)), dev)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        slots = torch.empty((B * S, D), dtype=cdt, device=dev)
+        attn_ptr = _ct.c_void_p()
+        _L.check(lib.devias_agg_block_fwd(_ct.byref(a), x.data_ptr(), slots.data_ptr(), _ct.byref(attn_ptr), ops._stream()), "devias_agg_block_fwd")
+        off = attn_ptr.value - save.data_ptr()
+        attn = save[off:off + B * heads * S * N * 4].view(torch.float32).view(B * heads, S, N)       # the last layer's slot softmax, inside the arena
+        ctx.args = a
+        ctx.meta = meta
+        ctx.keep = (keep, save, x)
+        ctx.params = (norm_w, norm_b, latents, last_w, last_b, LP)
+        return slots, attn
+
+    @staticmethod
+    def backward(ctx, dslots, dattn):
+        B, N, S, depth, tied, heads, dh, eps_enc, eps_agg, cdt = ctx.meta
+        lib = _L.load()
+        a = ctx.args
+        keep, save, x = ctx.keep
+        norm_w, norm_b, latents, last_w, last_b, LP = ctx.params
+        dev = x.device
+        D = a.D
+        nset = 1 if tied else depth
+        items = [(norm_w, (D,)), (norm_b, (D,)), (latents, tuple(latents.shape)), (last_w, (D,)), (last_b, (D,)), (None, (D,))]
+        for P in LP:
+            items += [(P[k], tuple(P[k].shape)) for k in _AGG_GRAD_KEYS]
+        gd = _GradDest(items, dev)
+        ptrs = gd.ptrs()
+        g = _L.AggGrads()
+        (g.dnorm_w, g.dnorm_b, g.dlatents, g.dlast_w, g.dlast_b, g.dx_colsum) = ptrs[:6]
+        for i in range(nset):
+            for f, ptr in zip(_L.AGG_GRAD_FIELDS, ptrs[6 + 15 * i:6 + 15 * (i + 1)]):
+                setattr(g.sets[i], f, ptr)
+        ws = ops.workspace(a.ws_bytes, dev)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        scr = _scratch(lib.devias_agg_block_scratch_bytes(_ct.byref(a)), dev)
+        dslots = dslots.contiguous()
+        dattn = dattn.contiguous() if dattn is not None else None
+        dx = torch.empty_like(x)
+        _L.check(lib.devias_agg_block_bwd(_ct.byref(a), x.data_ptr(), dslots.data_ptr(), dattn.data_ptr() if dattn is not None else None, dx.data_ptr(),
+                                          _ct.byref(g), scr.data_ptr(), scr.numel(), ops._stream()), "devias_agg_block_bwd")
+        ctx.keep = ctx.args = None
+        out = gd.out
+        _publish_colsum(dx, out[5])
+        flat = []
+        for i in range(nset):
+            gs = dict(zip(_AGG_GRAD_KEYS, out[6 + 15 * i:6 + 15 * (i + 1)]))
+            flat += [gs[k] for k in _LAYER_KEYS]
+        return (dx, out[0], out[1], out[2], out[3], out[4], None, *flat)
+
+
+# =====================================================================================================
 # module tree (parameter containers with the reference's names)
 # =====================================================================================================
 class Mlp(nn.Module):
@@ -705,7 +982,7 @@ class Block(nn.Module):
             ds = ((keep + r).floor() / keep).contiguous()
             ds1, ds2 = ds[0], ds[1]
         meta = (B, N, a.num_heads, self.norm1.eps, cdt)
-        return EncoderBlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight,
+        return (EncoderBlockRegionFn if _REGIONS else EncoderBlockFn).apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight,
                                     a.proj.bias, self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
                                     self.mlp.fc2.weight, self.mlp.fc2.bias, meta, ds1, ds2)
 
@@ -928,13 +1205,13 @@ class VisionTransformer(nn.Module):
         S = ab.num_latents
         meta = (B, N, S, ab.depth, ab.weight_tie_layers, ab.heads, ab.dim_head, self.norm.eps, ab.last_layer[0].eps, cdt)
         fold = _AGG_FOLD and S <= 4 and D in (384, 512, 768, 1024)
-        slots, attn = (AggBlockFoldFn if fold else AggBlockFn).apply(h, self.norm.weight, self.norm.bias, ab.latents, ab.last_layer[0].weight,
+        slots, attn = ((AggBlockRegionFn if _REGIONS else AggBlockFoldFn) if fold else AggBlockFn).apply(h, self.norm.weight, self.norm.bias, ab.latents, ab.last_layer[0].weight,
                                                                       ab.last_layer[0].bias, meta, *ab.layer_params())
         if self.slot_matching_method == 'hard_select':
             raise NotImplementedError("only slot_matching_method='matching' is on the DEVIAS training path "
                                       "(the reference's hard_select branch returns empty lists, modeling_slot.py:388)")
         mp = self.mask_predictor.decoder
-        slots_head, mask_predictions = HeadFn.apply(slots, self.head.weight, self.head.bias, mp[0].weight, mp[0].bias,
+        slots_head, mask_predictions = (HeadRegionFn if _REGIONS else HeadFn).apply(slots, self.head.weight, self.head.bias, mp[0].weight, mp[0].bias,
                                                     mp[2].weight, mp[2].bias, mp[4].weight, mp[4].bias, cdt)
         idx = ops.slot_select(slots_head.detach(), B, S, self.num_classes).long()      # modeling_slot.py:395-401
         ar = torch.arange(B, device=x.device)

@@ -44,7 +44,8 @@ extern "C" {
 #define DEVIAS_ACT_DRELU 5     /* backward: v = aux_in > 0 ? v : 0 with aux_in = saved ReLU output */
 
 int devias_version(void);          /* 100 + additions: 110 = multi-tensor optimizer entry points, 120 = devias_fame_*, 130 = counters + options,
-                                    140 = stream-K GEMM schedule (devias_gemm_args grew by sk_ws / sk_ws_bytes: recompile callers), devias_allreduce_bucket */
+                                    140 = stream-K GEMM schedule (devias_gemm_args grew by sk_ws / sk_ws_bytes: recompile callers), devias_allreduce_bucket,
+                                    150 = fused regions (devias_encoder_block_* / devias_agg_block_* / devias_head_*), devias_range_* */
 const char* devias_last_error(void);
 /* Launch counters: one per kernel family, incremented by the host side of each entry point (process-wide, relaxed atomics).
  * Tests use them to ASSERT that the kernels a parity claim is made for are the kernels that ran (the reference has no analogue:
@@ -75,6 +76,11 @@ int devias_set_option(const char* name, int32_t value);
 int devias_allreduce_bucket(void* nccl_comm, void* bucket, int64_t count, int32_t dtype, void* stream);
 /* The library allocates nothing persistent; resets the launch counters. */
 void devias_shutdown(void);
+/* ROCTX ranges (`rocprofv3 --marker-trace`): the fused regions open one each; hosts mark their own phases (loss, optimizer, step) with these.
+ * Active only when the environment variable DEVIAS_ROCTX is non-zero (the marker library is then resolved with dlopen); otherwise no-ops.
+ * The reference has no profiler ranges (utils/utils.py:120-164 keeps wall-clock meters only). */
+void devias_range_push(const char* name);
+void devias_range_pop(void);
 
 /* fills: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes per block, [3]=wavefront size, [4]=gfx arch number (e.g. 950) */
 int devias_device_info(int device, int64_t* out5);
@@ -334,6 +340,94 @@ int devias_fame_binarize_pool(const float* blurred, int32_t n_img, int32_t H, in
                               uint8_t* binmask, float* pooled, void* stream);
 int devias_fame_mix(const float* video, const uint8_t* binmask, int32_t mask_stride, const int32_t* src, const int32_t* partner,
                     const int32_t* aug, float* out, int32_t B, int32_t CT, int32_t HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused regions (ABI 150): ONE call enqueues the whole kernel sequence of a block of the step -- the same launches, in the same order and
+ * with the same split-K / workspace policy as the per-kernel entry points above, so the results are bitwise theirs.  The Python host reaches
+ * the library ~40 times per step instead of ~750 (one ctypes hop per fused region).  All memory is caller-owned:
+ *   save     what backward re-reads (opaque layout; written by *_fwd, read by *_bwd; size from *_save_bytes)
+ *   scratch  backward temporaries (dead when the call's work has run; size from *_scratch_bytes)
+ *   ws       fp32 kernel workspace (split-K slabs, partial sums; size from *_workspace_bytes), sk_ws: see devias_gemm_args
+ * Gradient destinations are fp32 and may point anywhere (e.g. into a flat data-parallel gradient bucket).
+ *
+ * Encoder block = Block.forward of model/modeling_slot.py:142-152 (LayerNorm -> QKV Linear with q_bias | 0 | v_bias (:97-101) -> MHSA core
+ * (:102-112) -> proj + residual (:113,150) -> LayerNorm -> fc1 + GELU -> fc2 + residual (:60-67,151)); stochastic depth (:36-47) through ds1 / ds2.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, N, D, H, hidden;          /* M = B*N rows; head dim D / H must be 64 */
+    int32_t dtype;                       /* T: DEVIAS_F32 | DEVIAS_BF16 */
+    float eps;
+    const float *n1w, *n1b, *n2w, *n2b;  /* LayerNorm gamma / beta, fp32 [D] */
+    const void *Wqkv, *Wp, *W1, *W2;     /* T, nn.Linear layout: [3D,D], [D,D], [hidden,D], [D,hidden] */
+    const float* qkv_bias;               /* fp32 [3D] = q_bias | zeros | v_bias */
+    const float *pb, *b1, *b2;           /* fp32 [D], [hidden], [D] */
+    const float *ds1, *ds2;              /* optional fp32 [B]: per-sample stochastic-depth factors (0 or 1/keep) of the two branches */
+    void* save;                          /* devias_encoder_block_save_bytes() */
+    float* ws; int64_t ws_bytes;         /* devias_encoder_block_workspace_bytes() */
+    void* sk_ws; int64_t sk_ws_bytes;    /* optional stream-K scratch (devias_gemm_args.sk_ws) */
+} devias_block_args;
+typedef struct {
+    float *dn1w, *dn1b, *dWqkv, *dbqkv /* [3D]: dq_bias | (k: unused) | dv_bias */, *dWp, *dbp, *dn2w, *dn2b, *dW1, *db1, *dW2, *db2;
+    float* dx_colsum;                    /* [D]: column sums of dx = the fc2-bias gradient of the PREVIOUS block (or the patch-embed bias gradient) */
+    int32_t db2_done;                    /* != 0: the caller already holds colsum(dx2) (the next block's dx_colsum): db2 is not written */
+} devias_block_grads;
+int64_t devias_encoder_block_save_bytes(int32_t B, int32_t N, int32_t D, int32_t H, int32_t hidden, int32_t dtype);
+int64_t devias_encoder_block_scratch_bytes(int32_t B, int32_t N, int32_t D, int32_t H, int32_t hidden, int32_t dtype);
+int64_t devias_encoder_block_workspace_bytes(int32_t B, int32_t N, int32_t D, int32_t H, int32_t hidden, int32_t dtype);
+/* x, x2: T [B*N, D] */
+int devias_encoder_block_fwd(const devias_block_args* a, const void* x, void* x2, void* stream);
+/* x: the block's input again; dx2: gradient of its output; dx: gradient of its input */
+int devias_encoder_block_bwd(const devias_block_args* a, const void* x, const void* dx2, void* dx, const devias_block_grads* g,
+                             void* scratch, int64_t scratch_bytes, void* stream);
+
+/* Shared head + MaskPredictor (modeling_slot.py:392-393, 194-216): Z = slots Wh^T + bh [R,C]; Mk = sigmoid(W4 relu(W2 relu(W0 slots))) [R,G].
+ * R = B*S rows, h1 / h2 = the MaskPredictor's hidden widths (512, 256). */
+typedef struct {
+    int32_t R, D, C, h1, h2, G, dtype;
+    const void *Wh, *W0, *W2, *W4;       /* T: [C,D], [h1,D], [h2,h1], [G,h2] */
+    const float *bh, *b0, *b2, *b4;
+    float* ws; int64_t ws_bytes;         /* devias_head_workspace_bytes() */
+} devias_head_args;
+typedef struct { float *dWh, *dbh, *dW0, *db0, *dW2, *db2, *dW4, *db4; } devias_head_grads;
+int64_t devias_head_workspace_bytes(int32_t R, int32_t D, int32_t C, int32_t h1, int32_t h2, int32_t G, int32_t dtype);
+int64_t devias_head_save_bytes(int32_t R, int32_t h1, int32_t h2, int32_t G, int32_t dtype);
+int devias_head_fwd(const devias_head_args* a, const void* slots, void* Z, void* Mk, void* save, void* stream);
+int devias_head_bwd(const devias_head_args* a, const void* slots, const void* Mk, const void* save, const void* dZ, const void* dM, void* dslots,
+                    const devias_head_grads* g, void* stream);
+
+/* Final LayerNorm + AggregationBlock with the folded slot attention (modeling_slot.py:373,381; agg_block/agg_block.py:105-139;
+ * agg_block/attention.py:29-40,66-72,108-141): `depth` layers over `tied ? 1 : depth` weight sets; S <= 4 slots. */
+#define DEVIAS_AGG_MAX_DEPTH 16
+typedef struct {
+    const void *Wq, *Wk, *Wv, *Wo, *W1, *W2;                      /* T: to_q/to_k/to_v [heads*dh, D], to_out [D, heads*dh], ff [ff,D], [D,ff] */
+    const float *bo, *norm_w, *norm_b, *ctx_w, *ctx_b, *b1, *b2, *ffn_w, *ffn_b;
+} devias_agg_layer_params;
+typedef struct { float *dWq, *dWk, *dWv, *dWo, *dbo, *dnorm_w, *dnorm_b, *dctx_w, *dctx_b, *dW1, *db1, *dW2, *db2, *dffn_w, *dffn_b; } devias_agg_layer_grads;
+typedef struct {
+    int32_t B, N, S, D, depth, tied, heads, dh, ff, dtype;
+    float eps_enc, eps_agg;
+    const float *norm_w, *norm_b;        /* the encoder's final LayerNorm */
+    const float* latents;                /* fp32 [S, D] */
+    const float *last_w, *last_b;        /* last_layer LayerNorm */
+    devias_agg_layer_params sets[DEVIAS_AGG_MAX_DEPTH];
+    void* save;                          /* devias_agg_block_save_bytes() */
+    float* ws; int64_t ws_bytes;         /* devias_agg_block_workspace_bytes() */
+} devias_agg_args;
+typedef struct {
+    float *dnorm_w, *dnorm_b, *dlatents, *dlast_w, *dlast_b;
+    float* dx_colsum;                    /* [D]: column sums of dx (the last encoder block's fc2-bias gradient) */
+    devias_agg_layer_grads sets[DEVIAS_AGG_MAX_DEPTH];
+} devias_agg_grads;
+int64_t devias_agg_block_save_bytes(const devias_agg_args* a);
+int64_t devias_agg_block_scratch_bytes(const devias_agg_args* a);
+int64_t devias_agg_block_workspace_bytes(const devias_agg_args* a);
+/* x: T [B*N, D] encoder output (before the final LayerNorm); slots: T [B*S, D]; *attn_out = the last layer's slot softmax, fp32 [B*heads, S, N], inside `save` */
+int devias_agg_block_fwd(const devias_agg_args* a, const void* x, void* slots, float** attn_out, void* stream);
+int devias_agg_block_bwd(const devias_agg_args* a, const void* x, const void* dslots, const float* dattn, void* dx, const devias_agg_grads* g,
+                         void* scratch, int64_t scratch_bytes, void* stream);
+/* the automatic split-K choices the regions (and the Python host) make, for hosts that size workspaces themselves */
+int32_t devias_policy_small_m_split(int32_t M, int32_t N, int32_t K, int32_t trans_a);
+int32_t devias_policy_wgrad_split(int32_t Nout, int32_t Kin, int32_t Mrows, int32_t dtype);
 
 #ifdef __cplusplus
 }
