@@ -43,6 +43,11 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary full-step number (teacher fwd + AdamW)")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce (N > 1)")
+    ap.add_argument("--force-gradsync", action="store_true", help="N = 1 only: run the whole gradient-bucket path (hooks, events, side stream) with the "
+                    "collective replaced by a same-size device copy on the side stream")
+    ap.add_argument("--cu-hog", type=int, default=0, help="hold this many CUs (128 KiB LDS each) on a side stream during every backward: stand-in for the CUs "
+                    "RCCL's kernels occupy at N > 1")
+    ap.add_argument("--cu-hog-us", type=int, default=36000, help="how long each --cu-hog workgroup holds its CU (about one backward)")
     return ap.parse_args()
 
 
@@ -143,16 +148,23 @@ def main():
     crit = TrainLoss(scene_criterion="KL", num_action_classes=400, slot_matching_method="matching", scene_loss_weight=4000,
                      mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0, sync_loss_dict=False)
     comm_dtype = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
-    sync = GradSync(model, comm_dtype=comm_dtype) if world > 1 else None
+    sync = GradSync(model, comm_dtype=comm_dtype, simulate=args.force_gradsync) if (world > 1 or args.force_gradsync) else None
+    from devias_amd import _lib as _dl
+    hog_stream = torch.cuda.Stream(device=device) if args.cu_hog > 0 else None
 
     def step():
         for p in model.parameters():
             p.grad = None
         out = model(x)
         total, logits, ld = crit(model, out, (None, tl), y, fg_mask=(fg196, fgN))
+        if hog_stream is not None:                     # the hog starts when the forward's work is done, i.e. with backward
+            hog_stream.wait_stream(torch.cuda.current_stream(device))
+            _dl.check(_dl.load().devias_debug_cu_hog(args.cu_hog, args.cu_hog_us, hog_stream.cuda_stream), "devias_debug_cu_hog")
         total.backward()
         if sync is not None:
             sync.finish()
+        if hog_stream is not None:
+            torch.cuda.current_stream(device).wait_stream(hog_stream)
         return total
 
     for _ in range(args.warmup):
@@ -160,7 +172,6 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    from devias_amd import _lib as _dl
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     _dl.CALLS[0] = 0
     t0 = time.perf_counter()
@@ -180,6 +191,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t)
     loss_value = float(loss.detach().float().sum())
+    # host cost of a step: ONE step enqueued on an idle stream (in the back-to-back loop above the launch queue fills up and the host is throttled
+    # to the device's pace, so that number says nothing about the host); median of 5, outside the timed region
+    host_idle = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step()
+        host_idle.append(time.perf_counter() - th)
+    torch.cuda.synchronize()
+    host_idle.sort()
+    from devias_amd import ops as _ops
+    if _ops.streamk_timeouts():
+        raise SystemExit("bench.py: a stream-K GEMM hand-off timed out during the run (results invalid)")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -235,11 +259,16 @@ def main():
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"slot-{args.model} 16-patch {args.frames}x{args.img_size}^2 ({N} tokens), S=2 slots, tied agg depth 8, "
-                               f"B={B} clips/GPU, student fwd + matching loss + bwd" + (f" + RCCL grad all-reduce ({args.comm_dtype} wire format, 64 MiB fp32 buckets, side stream)" if world > 1 else ""),
+                               f"B={B} clips/GPU, student fwd + matching loss + bwd" + (f" + RCCL grad all-reduce ({args.comm_dtype} wire format, 64 MiB fp32 buckets, side stream)" if world > 1 else "") +
+                               (" + gradient-bucket path with the collective replaced by a device copy (--force-gradsync)" if args.force_gradsync and world == 1 else "") +
+                               (f" + {args.cu_hog} CUs held on a side stream during backward (--cu-hog)" if args.cu_hog else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
-                   "kernels": "persistent 256x256 GEMM (forward + dgrad; stream-K schedule for fc2 / dfc1 / dqkv), two-kernel MFMA attention backward, folded slot cross-attention (K/V projections on the slot side)"},
-        "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "host_library_calls_per_step": lib_calls,
+                   "kernels": "persistent 256x256 GEMM (forward + dgrad; stream-K schedule for fc2 / dfc1 / dqkv), two-kernel MFMA attention backward, folded slot cross-attention (K/V projections on the slot side); "
+                              "one library call per fused region and direction (csrc/regions.hip)"},
+        "host_enqueue_ms_per_step": host_idle[len(host_idle) // 2] * 1e3, "host_library_calls_per_step": lib_calls,
+        "host_enqueue_method": "one step enqueued on an idle stream, median of 5, outside the timed region (python + fused-region library calls + HIP launches)",
+        "host_enqueue_ms_per_step_back_to_back": host_enqueue / args.steps * 1e3,
         "device_ms_per_step": dev_ms / args.steps, "final_loss": loss_value, "peak_mem_gib": peak_mem,
     }
     if ach is not None:

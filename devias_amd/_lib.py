@@ -59,7 +59,7 @@ class BlockGrads(Structure):         # devias_block_grads
 
 class HeadArgs(Structure):           # devias_head_args
     _fields_ = [(n, c_int32) for n in ("R", "D", "C", "h1", "h2", "G", "dtype")] + \
-               [(n, c_void_p) for n in ("Wh", "W0", "W2", "W4", "bh", "b0", "b2", "b4", "ws")] + [("ws_bytes", c_int64)]
+               [(n, c_void_p) for n in ("Wh", "W0", "W2", "W4", "bh", "b0", "b2", "b4", "ws")] + [("ws_bytes", c_int64), ("drop_mask", c_void_p)]
 
 
 class HeadGrads(Structure):          # devias_head_grads
@@ -115,6 +115,7 @@ PROTOTYPES = {
     "devias_act_bwd": (c_int, [_P, _P, _P, _I, _I, _L, _P]),
     "devias_row_scale": (c_int, [_P, _P, _I, _P, _I, _I, _I, _P]),
     "devias_add": (c_int, [_P, _P, _P, _I, _L, _P]),
+    "devias_mul_mask": (c_int, [_P, _P, _P, _P, _I, _L, _P]),
     "devias_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "devias_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P, _P]),
     "devias_layernorm_bwd_workspace_bytes": (c_int64, [_I, _I]),
@@ -142,6 +143,7 @@ PROTOTYPES = {
     "devias_fame_seg_refine": (c_int, [_P, _P, _I, _I, _I, _F, _P, _P]),
     "devias_fame_binarize_pool": (c_int, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "devias_fame_mix": (c_int, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "devias_debug_cu_hog": (c_int, [_I, _I, _P]),
     "devias_range_push": (None, [c_char_p]),
     "devias_range_pop": (None, []),
     "devias_encoder_block_save_bytes": (c_int64, [_I, _I, _I, _I, _I, _I]),

@@ -135,6 +135,16 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
     }
 }
 
+// y = a * mask (+ b): element-wise dropout (mask = 0 or 1/keep, fp32) and its backward with the gradient fan-in of the un-dropped consumers
+template <typename T>
+__global__ void mul_mask_kernel(const T* __restrict__ a, const float* __restrict__ mask, const T* __restrict__ b, T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = to_f32(a[i]) * mask[i];
+        if (b) v += to_f32(b[i]);
+        y[i] = from_f32<T>(v);
+    }
+}
+
 template <typename T>
 __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, int64_t n, int act) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -348,6 +358,18 @@ extern "C" int devias_add(const void* a, const void* b_, void* y, int32_t dtype,
     return DEVIAS_OK;
 }
 
+extern "C" int devias_mul_mask(const void* a, const float* mask, const void* b_, void* y, int32_t dtype, int64_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(a && mask && y, "devias_mul_mask: null pointer");
+    if (n == 0) return DEVIAS_OK;
+    dim3 g(grid_for(n)), b(256);
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((mul_mask_kernel<bf16>), g, b, 0, st, (const bf16*)a, mask, (const bf16*)b_, (bf16*)y, n);
+    else if (dtype == DEVIAS_F32) hipLaunchKernelGGL((mul_mask_kernel<float>), g, b, 0, st, (const float*)a, mask, (const float*)b_, (float*)y, n);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_mul_mask: bad dtype %d", dtype);
+    DEVIAS_CHECK_LAUNCH("devias_mul_mask");
+    return DEVIAS_OK;
+}
+
 extern "C" int devias_act_bwd(const void* dy, const void* y, void* dx, int32_t act, int32_t dtype, int64_t n, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     DEVIAS_REQUIRE(dy && y && dx, "devias_act_bwd: null pointer");
@@ -399,5 +421,26 @@ extern "C" int devias_adamw_multi(const devias_opt_tensor* table, const int32_t*
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_tensor, chunk_index, beta1, beta2,
                        eps, grad_scale, grad_scale_dev);
     DEVIAS_CHECK_LAUNCH("devias_adamw_multi");
+    return DEVIAS_OK;
+}
+
+
+// ---- measurement aid: hold K compute units for a while (bench.py --cu-hog) -----------------------------------------------------------------
+// K workgroups that each pin 128 KiB of LDS (so that no 128-KiB-LDS GEMM workgroup can share their CU) and spin for `usec` microseconds of the
+// 100 MHz clock.  Launched on a side stream during backward it stands in for the CUs a concurrent RCCL kernel would occupy: how the persistent
+// GEMM grids (one workgroup per CU, static tile lists) degrade with K CUs missing can be measured on ONE GPU.
+__global__ __launch_bounds__(64) void cu_hog_kernel(unsigned long long ticks, int* sink) {
+    __shared__ int pin[32768];
+    pin[threadIdx.x] = (int)blockIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink && pin[(threadIdx.x * 7) & 63] == -12345) sink[0] = 1;       // keeps the LDS array alive
+}
+extern "C" int devias_debug_cu_hog(int32_t n_workgroups, int32_t usec, void* stream) {
+    DEVIAS_REQUIRE(n_workgroups >= 0 && n_workgroups <= 256 && usec >= 0 && usec <= 2000000, "devias_debug_cu_hog: bad args");
+    if (n_workgroups == 0 || usec == 0) return DEVIAS_OK;
+    hipLaunchKernelGGL(cu_hog_kernel, dim3(n_workgroups), dim3(64), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull, (int*)nullptr);
+    DEVIAS_CHECK_LAUNCH("devias_debug_cu_hog");
     return DEVIAS_OK;
 }

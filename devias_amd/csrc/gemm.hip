@@ -1560,7 +1560,8 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     //   * 256x128 single-stage kernel (2 workgroups/CU): N a multiple of 128 but not of 256;
     //   * 128x128 register-staged kernel: ragged / unaligned / fp32 shapes.
     bool ss = kn.use_ss != 0 && a->dtype == DEVIAS_BF16 && vec && v16 && (a->M % SS_BM == 0) && (a->N % SS_BN == 0) && (a->K % 64 == 0) &&
-              (p.k_per_split % 64 == 0) && batch == 1;
+              (p.k_per_split % 64 == 0) && batch == 1 && !(a->trans_a && !a->trans_b);      // (A k-strided with B k-contiguous: no caller; that
+                                                                                             //  instantiation spilled registers and was removed)
     if (ss && big) {
         const bool nt = !a->trans_a && !a->trans_b;
         if (kn.use_ss < 0 || nt) ss = false;
@@ -1577,8 +1578,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         const int ta = a->trans_a, tb = a->trans_b;
         if (!ta && !tb) hipLaunchKernelGGL((gemm_ss_kernel<false, false, 2>), grid, block, 0, st, p);
         else if (!ta && tb) hipLaunchKernelGGL((gemm_ss_kernel<false, true, 2>), grid, block, 0, st, p);
-        else if (ta && tb) hipLaunchKernelGGL((gemm_ss_kernel<true, true, 2>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gemm_ss_kernel<true, false, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_ss_kernel<true, true, 2>), grid, block, 0, st, p);
         devias_count(DEVIAS_CNT_GEMM_SS);
     } else if (big) {
         p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;

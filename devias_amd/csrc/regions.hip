@@ -226,17 +226,21 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
 // ================================================ head + mask predictor ==========================================================
 namespace {
 struct HeadSave {
-    char *m1, *m2, *Mk;
+    char *m1, *m2, *sd;           // MaskPredictor hidden activations; the dropped-out slots (fc_dropout)
     int64_t bytes;
-    HeadSave(void* base, int R, int h1, int h2, int G, int dtype) {
+    HeadSave(void* base, int R, int D, int h1, int h2, int dtype) {
         const int64_t es = esize(dtype);
         int64_t off = 0;
         char* p = reinterpret_cast<char*>(base);
         auto take = [&](int64_t n) { char* r = p + off; off += al256(n); return r; };
-        m1 = take((int64_t)R * h1 * es); m2 = take((int64_t)R * h2 * es); Mk = take((int64_t)R * G * es);
+        m1 = take((int64_t)R * h1 * es); m2 = take((int64_t)R * h2 * es); sd = take((int64_t)R * D * es);
         bytes = off;
     }
 };
+int64_t head_tmp_bytes(int R, int D, int h1, int h2, int G, int dtype) {       // dp3 [R,G], dp2 [R,h2], dp1 [R,h1], ds_m [R,D], d(dropped slots) [R,D]
+    const int64_t es = esize(dtype);
+    return al256((int64_t)R * G * es) + al256((int64_t)R * h2 * es) + al256((int64_t)R * h1 * es) + 2 * al256((int64_t)R * D * es);
+}
 int head_check(const devias_head_args* a, const char* who) {
     DEVIAS_REQUIRE(a && a->R > 0 && a->D > 0 && a->C > 0 && a->h1 > 0 && a->h2 > 0 && a->G > 0, "%s: bad dims", who);
     DEVIAS_REQUIRE(a->dtype == DEVIAS_BF16 || a->dtype == DEVIAS_F32, "%s: bad dtype %d", who, a->dtype);
@@ -254,19 +258,20 @@ extern "C" int64_t devias_head_workspace_bytes(int32_t R, int32_t D, int32_t C, 
     for (auto& d : wg) w = max64(w, wgrad_ws(d[0], d[1], R, dtype));
     const int cs[] = {G, h2, h1, C};
     for (int n : cs) w = max64(w, devias_colsum_workspace_bytes(R, n));
-    int64_t tmp = (int64_t)R * (G + h2 + h1 + D) * esize(dtype) + 4 * 256;     // backward temporaries dp3, dp2, dp1, ds_m live behind the kernel workspace
-    return al256(w) + 256 + tmp;
+    return al256(w) + 256 + head_tmp_bytes(R, D, h1, h2, G, dtype);            // backward temporaries live behind the kernel workspace
 }
-extern "C" int64_t devias_head_save_bytes(int32_t R, int32_t h1, int32_t h2, int32_t G, int32_t dtype) { return HeadSave(nullptr, R, h1, h2, G, dtype).bytes; }
+extern "C" int64_t devias_head_save_bytes(int32_t R, int32_t D, int32_t h1, int32_t h2, int32_t dtype) { return HeadSave(nullptr, R, D, h1, h2, dtype).bytes; }
 
 // slots [R, D] -> Z = head(slots) [R, C], Mk = MaskPredictor(slots) [R, G] (also the last tensor of `save`)
 extern "C" int devias_head_fwd(const devias_head_args* a, const void* slots, void* Z, void* Mk, void* save, void* stream) {
     RUN(head_check(a, "devias_head_fwd"));
     DEVIAS_REQUIRE(slots && Z && Mk && save, "devias_head_fwd: null pointer");
     const Ctx c{a->dtype, a->ws, a->ws_bytes, nullptr, 0, stream};
-    const HeadSave s(save, a->R, a->h1, a->h2, a->G, a->dtype);
+    const HeadSave s(save, a->R, a->D, a->h1, a->h2, a->dtype);
     devias_range r("head_fwd");
-    { Epi e; e.bias = a->bh; RUN(gemm(c, slots, a->Wh, Z, a->R, a->C, a->D, a->D, a->D, 0, 0, e)); }
+    const void* hin = slots;
+    if (a->drop_mask) { RUN(devias_mul_mask(slots, a->drop_mask, nullptr, s.sd, a->dtype, (int64_t)a->R * a->D, stream)); hin = s.sd; }      // fc_dropout: head input only
+    { Epi e; e.bias = a->bh; RUN(gemm(c, hin, a->Wh, Z, a->R, a->C, a->D, a->D, a->D, 0, 0, e)); }
     { Epi e; e.bias = a->b0; e.act = DEVIAS_ACT_RELU; RUN(gemm(c, slots, a->W0, s.m1, a->R, a->h1, a->D, a->D, a->D, 0, 0, e)); }
     { Epi e; e.bias = a->b2; e.act = DEVIAS_ACT_RELU; RUN(gemm(c, s.m1, a->W2, s.m2, a->R, a->h2, a->h1, a->h1, a->h1, 0, 0, e)); }
     { Epi e; e.bias = a->b4; e.act = DEVIAS_ACT_SIGMOID; RUN(gemm(c, s.m2, a->W4, Mk, a->R, a->G, a->h2, a->h2, a->h2, 0, 0, e)); }
@@ -280,14 +285,15 @@ extern "C" int devias_head_bwd(const devias_head_args* a, const void* slots, con
     DEVIAS_REQUIRE(g->dWh && g->dbh && g->dW0 && g->db0 && g->dW2 && g->db2 && g->dW4 && g->db4, "devias_head_bwd: null gradient destination");
     const int R = a->R, D = a->D, C = a->C, h1 = a->h1, h2 = a->h2, G = a->G;
     const int64_t es = esize(a->dtype);
-    const int64_t wk = devias_head_workspace_bytes(R, D, C, h1, h2, G, a->dtype) - ((int64_t)R * (G + h2 + h1 + D) * es + 4 * 256);
+    const int64_t wk = devias_head_workspace_bytes(R, D, C, h1, h2, G, a->dtype) - head_tmp_bytes(R, D, h1, h2, G, a->dtype);
     const Ctx c{a->dtype, a->ws, wk, nullptr, 0, stream};
     char* tp = reinterpret_cast<char*>(a->ws) + wk;
     char* dp3 = tp; tp += al256((int64_t)R * G * es);
     char* dp2 = tp; tp += al256((int64_t)R * h2 * es);
     char* dp1 = tp; tp += al256((int64_t)R * h1 * es);
-    char* dsm = tp;
-    const HeadSave s(const_cast<void*>(save), R, h1, h2, G, a->dtype);
+    char* dsm = tp; tp += al256((int64_t)R * D * es);
+    char* dsd = tp;
+    const HeadSave s(const_cast<void*>(save), R, D, h1, h2, a->dtype);
     devias_range r("head_bwd");
     RUN(devias_act_bwd(dM, Mk, dp3, DEVIAS_ACT_SIGMOID, a->dtype, (int64_t)R * G, stream));
     RUN(wgrad(c, dp3, s.m2, g->dW4, R, G, h2)); RUN(colsum(c, dp3, R, G, g->db4));
@@ -296,8 +302,15 @@ extern "C" int devias_head_bwd(const devias_head_args* a, const void* slots, con
     { Epi e; e.act = DEVIAS_ACT_DRELU; e.aux_in = s.m1; RUN(gemm(c, dp2, a->W2, dp1, R, h1, h2, h2, h1, 0, 1, e)); }
     RUN(wgrad(c, dp1, slots, g->dW0, R, h1, D)); RUN(colsum(c, dp1, R, h1, g->db0));
     { Epi e; RUN(gemm(c, dp1, a->W0, dsm, R, D, h1, h1, D, 0, 1, e)); }
-    { Epi e; e.res = dsm; RUN(gemm(c, dZ, a->Wh, dslots, R, D, C, C, D, 0, 1, e)); }
-    RUN(wgrad(c, dZ, slots, g->dWh, R, C, D)); RUN(colsum(c, dZ, R, C, g->dbh));
+    if (a->drop_mask) {                  // dslots = (dZ Wh) * mask + the MaskPredictor's gradient; the head saw the dropped slots
+        { Epi e; RUN(gemm(c, dZ, a->Wh, dsd, R, D, C, C, D, 0, 1, e)); }
+        RUN(devias_mul_mask(dsd, a->drop_mask, dsm, dslots, a->dtype, (int64_t)R * D, stream));
+        RUN(wgrad(c, dZ, s.sd, g->dWh, R, C, D));
+    } else {
+        { Epi e; e.res = dsm; RUN(gemm(c, dZ, a->Wh, dslots, R, D, C, C, D, 0, 1, e)); }
+        RUN(wgrad(c, dZ, slots, g->dWh, R, C, D));
+    }
+    RUN(colsum(c, dZ, R, C, g->dbh));
     return DEVIAS_OK;
 }
 

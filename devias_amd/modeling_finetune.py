@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .modeling_slot import (ACT_GELU, Block, PatchEmbed, _WCACHE, _cfg, _f32, get_sinusoid_encoding_table, register_model)
+from .modeling_slot import (ACT_GELU, Block, PatchEmbed, _WCACHE, _cfg, _f32, _qkv_bias, get_sinusoid_encoding_table, register_model)
 
 
 class VisionTransformer(nn.Module):
@@ -107,7 +107,7 @@ class VisionTransformer(nn.Module):
             a = blk.attn
             Wqkv, Wp, W1, W2 = (_WCACHE.get(w, cdt) for w in (a.qkv.weight, a.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight))
             u, _, _ = ops.layernorm_fwd(h, _f32(blk.norm1.weight), _f32(blk.norm1.bias), blk.norm1.eps)
-            qkv = ops.gemm(u, Wqkv, bias=torch.cat((_f32(a.q_bias), torch.zeros_like(_f32(a.v_bias)), _f32(a.v_bias))))
+            qkv = ops.gemm(u, Wqkv, bias=_qkv_bias(a.q_bias, a.v_bias))          # q_bias | 0 | v_bias, rebuilt only when a bias changed
             ops.mhsa_fwd(qkv[:M], B, Nt, a.num_heads, scale, out=o[:M])
             h1 = ops.gemm(o, Wp, bias=_f32(a.proj.bias), res=h)
             u2, _, _ = ops.layernorm_fwd(h1, _f32(blk.norm2.weight), _f32(blk.norm2.bias), blk.norm2.eps)

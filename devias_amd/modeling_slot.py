@@ -790,7 +790,7 @@ class HeadRegionFn(Function):
     """HeadFn as one devias_head_fwd / _bwd call"""
 
     @staticmethod
-    def forward(ctx, slots, hw, hb, w0, b0, w2, b2, w4, b4, cdt):
+    def forward(ctx, slots, hw, hb, w0, b0, w2, b2, w4, b4, cdt, drop_mask=None):
         lib = _L.load()
         dev = slots.device
         slots = slots.contiguous()
@@ -803,12 +803,16 @@ class HeadRegionFn(Function):
         a.R, a.D, a.C, a.h1, a.h2, a.G, a.dtype = R, D, C, h1, h2, G, dt
         (a.Wh, a.W0, a.W2, a.W4, a.bh, a.b0, a.b2, a.b4) = [t.data_ptr() for t in keep]
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        save = torch.empty((lib.devias_head_save_bytes(R, h1, h2, G, dt),), dtype=torch.uint8, device=dev)
+        if drop_mask is not None:            # fc_dropout (modeling_slot.py:291,393): 0 / (1/keep) per element of the head's input
+            drop_mask = ops._chk(drop_mask, "head.drop_mask", torch.float32)
+            assert drop_mask.shape == (R, D)
+            a.drop_mask = drop_mask.data_ptr()
+        save = torch.empty((lib.devias_head_save_bytes(R, D, h1, h2, dt),), dtype=torch.uint8, device=dev)
         Z = torch.empty((R, C), dtype=cdt, device=dev)
         Mk = torch.empty((R, G), dtype=cdt, device=dev)
         _L.check(lib.devias_head_fwd(_ct.byref(a), slots.data_ptr(), Z.data_ptr(), Mk.data_ptr(), save.data_ptr(), ops._stream()), "devias_head_fwd")
         ctx.args = a
-        ctx.keep = (keep, save, slots, Mk)
+        ctx.keep = (keep, save, slots, Mk, drop_mask)
         ctx.params = (hw, hb, w0, b0, w2, b2, w4, b4)
         return Z, Mk
 
@@ -816,7 +820,7 @@ class HeadRegionFn(Function):
     def backward(ctx, dZ, dM):
         lib = _L.load()
         a = ctx.args
-        keep, save, slots, Mk = ctx.keep
+        keep, save, slots, Mk, drop_mask = ctx.keep
         hw, hb, w0, b0, w2, b2, w4, b4 = ctx.params
         dev = slots.device
         dZ = dZ.contiguous() if dZ is not None else torch.zeros((a.R, a.C), dtype=slots.dtype, device=dev)
@@ -831,7 +835,7 @@ class HeadRegionFn(Function):
         _L.check(lib.devias_head_bwd(_ct.byref(a), slots.data_ptr(), Mk.data_ptr(), save.data_ptr(), dZ.data_ptr(), dM.data_ptr(), dslots.data_ptr(),
                                      _ct.byref(g), ops._stream()), "devias_head_bwd")
         ctx.keep = ctx.args = None
-        return (dslots, *gd.out, None)
+        return (dslots, *gd.out, None, None)
 
 
 _AGG_MATS = ("to_q", "to_k", "to_v", "to_out_w", "ff0_w", "ff3_w")                       # -> devias_agg_layer_params.Wq Wk Wv Wo W1 W2
@@ -1088,8 +1092,11 @@ class VisionTransformer(nn.Module):
             raise ValueError("incorrent slot_matching_method")
         if head_type != 'linear':
             raise NotImplementedError("head_type='mlp' is not used by the DEVIAS recipes; only 'linear' is built")
-        if fc_drop_rate or drop_rate or attn_drop_rate:
-            raise NotImplementedError("dropout > 0 is not implemented in the HIP path (all DEVIAS recipes use 0)")
+        if drop_rate or attn_drop_rate:
+            raise NotImplementedError("drop_rate / attn_drop_rate > 0 (dropout inside the encoder blocks) is not implemented in the HIP path: no DEVIAS "
+                                      "recipe sets them (docs/TRAIN.md); fc_drop_rate (dropout before the head, UCF-101 / HMDB recipes) is supported")
+        if not 0.0 <= float(fc_drop_rate) < 1.0:
+            raise ValueError(f"fc_drop_rate must be in [0, 1), got {fc_drop_rate}")
         if use_learnable_pos_emb:
             raise NotImplementedError("learnable pos-emb is not used by DEVIAS (sinusoid table only)")
         self.num_slots = num_latents
@@ -1113,7 +1120,8 @@ class VisionTransformer(nn.Module):
                   attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, init_values=init_values)
             for i in range(depth)])
         self.norm = norm_layer(embed_dim)
-        self.fc_dropout = nn.Identity()
+        self.fc_drop_rate = float(fc_drop_rate)
+        self.fc_dropout = nn.Dropout(p=fc_drop_rate) if fc_drop_rate > 0 else nn.Identity()     # parameter container as in the reference (:291); applied in HeadRegionFn
         self.agg_block = AggregationBlock(num_latents=num_latents, weight_tie_layers=agg_weights_tie, depth=agg_depth,
                                           input_channels=embed_dim, latent_dim=embed_dim)
         grid = (img_size // patch_size) if not isinstance(img_size, (tuple, list)) else (img_size[0] // patch_size)
@@ -1211,8 +1219,14 @@ class VisionTransformer(nn.Module):
             raise NotImplementedError("only slot_matching_method='matching' is on the DEVIAS training path "
                                       "(the reference's hard_select branch returns empty lists, modeling_slot.py:388)")
         mp = self.mask_predictor.decoder
-        slots_head, mask_predictions = (HeadRegionFn if _REGIONS else HeadFn).apply(slots, self.head.weight, self.head.bias, mp[0].weight, mp[0].bias,
-                                                    mp[2].weight, mp[2].bias, mp[4].weight, mp[4].bias, cdt)
+        drop_mask = None
+        if self.training and self.fc_drop_rate > 0:
+            # nn.Dropout(fc_drop_rate) on the head's input only (modeling_slot.py:393): element-wise Bernoulli(keep) / keep, drawn like drop_path's masks
+            keep = 1.0 - self.fc_drop_rate
+            drop_mask = ((keep + torch.rand((B * S, D), device=x.device, dtype=torch.float32)).floor() / keep).contiguous()
+        head_fn = HeadRegionFn if (_REGIONS or drop_mask is not None) else HeadFn
+        head_args = (slots, self.head.weight, self.head.bias, mp[0].weight, mp[0].bias, mp[2].weight, mp[2].bias, mp[4].weight, mp[4].bias, cdt)
+        slots_head, mask_predictions = head_fn.apply(*head_args, drop_mask) if drop_mask is not None else head_fn.apply(*head_args)
         idx = ops.slot_select(slots_head.detach(), B, S, self.num_classes).long()      # modeling_slot.py:395-401
         ar = torch.arange(B, device=x.device)
         sv, hv = slots.view(B, S, D), slots_head.view(B, S, -1)

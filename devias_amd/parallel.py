@@ -28,14 +28,24 @@ import torch.distributed as dist
 
 class GradSync:
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_bytes: int = 64 << 20, average: bool = True,
-                 comm_dtype: torch.dtype = torch.float32):
+                 comm_dtype: torch.dtype = torch.float32, simulate: bool = False, check_unused: bool = False):
+        """Build AFTER module.to(device): the flat buckets are allocated on the parameters' device and every parameter gets the view of its
+        place in them.  `simulate=True` (world size 1 only): every bucket still goes through the whole hook / event / side-stream path and the
+        collective is replaced by a same-size device copy on the side stream (bench.py --force-gradsync: what the bookkeeping and a concurrent
+        bandwidth-bound kernel cost the step, measurable on ONE GPU)."""
         if comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("GradSync: comm_dtype must be torch.float32 or torch.bfloat16")
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
         self.comm_dtype = comm_dtype
+        self.simulate = bool(simulate) and self.world == 1
+        self.check_unused = bool(check_unused)
+        self._sim_buf = {}
         params = [p for p in module.parameters() if p.requires_grad]
+        devs = {p.device for p in params}
+        if len(devs) != 1:
+            raise RuntimeError(f"GradSync: parameters live on {len(devs)} devices ({sorted(map(str, devs))}); move the module to ONE device first")
         self.params = list(reversed(params))
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, cur_bytes = [], 0
@@ -83,13 +93,19 @@ class GradSync:
 
     def _on_grad(self, p: torch.nn.Parameter):
         view = self._view[p]
+        if view.device != p.device:
+            raise RuntimeError("GradSync: a parameter moved to another device after the buckets were built; rebuild GradSync after model.to(device)")
+        bi = self._where[p]
+        if self._launched[bi] and not self._accumulate:
+            # a second backward before finish(): this gradient would be added into a bucket whose all-reduce is already in flight
+            raise RuntimeError("GradSync: gradient arrived for a bucket that is already being reduced -- call finish() after every backward "
+                               "(or set_accumulate(True) for all micro-batches but the last)")
         if p.grad.data_ptr() != view.data_ptr():       # produced elsewhere (or accumulated by autograd into a private tensor): home it
             view.copy_(p.grad)
             p.grad = view
         if self._accumulate or p in self._seen:
             return
         self._seen.add(p)
-        bi = self._where[p]
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
@@ -98,6 +114,17 @@ class GradSync:
         self._launched[bi] = True
         flat = self.flat[bi]
         if self.world == 1:
+            if self.simulate and flat.is_cuda:         # stand-in for the collective: the same bytes moved once on the side stream
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=flat.device)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(flat.device))
+                self._side.wait_event(ev)
+                with torch.cuda.stream(self._side):
+                    buf = self._sim_buf.get(bi)
+                    if buf is None:
+                        buf = self._sim_buf[bi] = torch.empty_like(flat)
+                    buf.copy_(flat, non_blocking=True)
             return
         if flat.is_cuda:
             if self._side is None:
@@ -130,6 +157,18 @@ class GradSync:
         """Block the COMPUTE STREAM (not the host) until every bucket is reduced, then scale to the mean."""
         if self._accumulate:
             raise RuntimeError("GradSync.finish() inside an accumulation window: call set_accumulate(False) before the last backward")
+        # Buckets whose last gradient never arrived (unused parameters) are launched here, in BUCKET-INDEX order.  If the SET of unused parameters
+        # differed between ranks, one rank would issue such a bucket's collective during backward and another one here: mismatched collectives
+        # (hang or cross-bucket reduction).  The reference's 'matching' path has no data-dependent branches (every parameter gets a gradient
+        # every step), so this costs nothing by default; models that do have rank-dependent unused parameters set `check_unused=True`, which
+        # all-reduces the "launched during backward" bitmap every step (what DDP's find_unused_parameters does) and raises on disagreement.
+        if self.check_unused and self.world > 1 and dist.is_initialized():
+            bitmap = torch.tensor([1.0 if l else 0.0 for l in self._launched], device=self.flat[0].device)
+            tot = bitmap.clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.pg)
+            if not torch.equal(tot, bitmap * self.world):
+                raise RuntimeError("GradSync: ranks launched different gradient buckets during backward (rank-dependent unused parameters): "
+                                   "their collectives would be mismatched")
         for bi, b in enumerate(self.buckets):
             if self._launched[bi]:
                 continue

@@ -81,6 +81,10 @@ void devias_shutdown(void);
  * The reference has no profiler ranges (utils/utils.py:120-164 keeps wall-clock meters only). */
 void devias_range_push(const char* name);
 void devias_range_pop(void);
+/* Measurement aid (bench.py --cu-hog K): n_workgroups workgroups that each pin 128 KiB of LDS -- no 128-KiB-LDS GEMM workgroup can share their
+ * CU -- and idle for `usec` microseconds, enqueued on `stream` (a side stream): a stand-in for the compute units a concurrent RCCL kernel
+ * occupies during backward, so that the persistent GEMM grids' sensitivity to missing CUs can be measured on one GPU.  No reference analogue. */
+int devias_debug_cu_hog(int32_t n_workgroups, int32_t usec, void* stream);
 
 /* fills: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes per block, [3]=wavefront size, [4]=gfx arch number (e.g. 950) */
 int devias_device_info(int device, int64_t* out5);
@@ -162,6 +166,9 @@ int devias_rows_broadcast(const float* src, int32_t mod, int32_t N, void* out, i
 int devias_act_bwd(const void* dy, const void* y_or_x, void* dx, int32_t act, int32_t dtype, int64_t n, void* stream);
 /* y[m, :] = x[m, :] * scale[m / rows_per_scale]  (T [M,N]); gradient of a stochastic-depth branch */
 int devias_row_scale(const void* x, const float* scale, int32_t rows_per_scale, void* y, int32_t dtype, int32_t M, int32_t N, void* stream);
+/* y = a * mask (+ b when b != NULL): a, b, y of dtype T, mask fp32, n elements.  Element-wise dropout with a caller-drawn mask of 0 / (1/keep)
+ * (nn.Dropout before the head: fc_dropout, modeling_slot.py:291,393) and, with b, its backward plus the gradient of the un-dropped consumers */
+int devias_mul_mask(const void* a, const float* mask, const void* b, void* y, int32_t dtype, int64_t n, void* stream);
 /* y = a + b (same dtype T, n elements); used for gradient fan-in of the residual stream */
 int devias_add(const void* a, const void* b, void* y, int32_t dtype, int64_t n, void* stream);
 
@@ -387,10 +394,12 @@ typedef struct {
     const void *Wh, *W0, *W2, *W4;       /* T: [C,D], [h1,D], [h2,h1], [G,h2] */
     const float *bh, *b0, *b2, *b4;
     float* ws; int64_t ws_bytes;         /* devias_head_workspace_bytes() */
+    const float* drop_mask;              /* optional fp32 [R, D], 0 or 1/keep: fc_dropout (nn.Dropout(fc_drop_rate), modeling_slot.py:291) applied to the
+                                            slots on their way into the head ONLY (:393; the MaskPredictor and the returned features see the un-dropped slots) */
 } devias_head_args;
 typedef struct { float *dWh, *dbh, *dW0, *db0, *dW2, *db2, *dW4, *db4; } devias_head_grads;
 int64_t devias_head_workspace_bytes(int32_t R, int32_t D, int32_t C, int32_t h1, int32_t h2, int32_t G, int32_t dtype);
-int64_t devias_head_save_bytes(int32_t R, int32_t h1, int32_t h2, int32_t G, int32_t dtype);
+int64_t devias_head_save_bytes(int32_t R, int32_t D, int32_t h1, int32_t h2, int32_t dtype);
 int devias_head_fwd(const devias_head_args* a, const void* slots, void* Z, void* Mk, void* save, void* stream);
 int devias_head_bwd(const devias_head_args* a, const void* slots, const void* Mk, const void* save, const void* dZ, const void* dM, void* dslots,
                     const devias_head_grads* g, void* stream);

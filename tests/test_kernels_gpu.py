@@ -271,11 +271,13 @@ def test_slot_kv_grad_stacked_layers():
 # ------------------------------------------------------------------------------------- selection + loss
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,S", [(2, 2), (5, 4), (3, 3)])
-def test_head_match_loss(dtype, B, S):
+@pytest.mark.parametrize("nb", [400, 101])            # Kinetics-400; UCF-101 (docs/TRAIN.md:80-125: head width 466, not a multiple of 8)
+def test_head_match_loss(dtype, B, S, nb):
     from oracle import ref_cpu
     o = ops()
-    C, nb, ns, D, G, N, nh = 765, 400, 365, 768, 196, 300, 4
-    cfg = ref_cpu.SlotViTConfig()
+    ns, D, G, N, nh = 365, 768, 196, 300, 4
+    C = nb + ns
+    cfg = ref_cpu.SlotViTConfig(num_classes=nb)
     Z = rnd(B * S, C, dtype=dtype, seed=50) * 2
     slots = rnd(B * S, D, dtype=dtype, seed=51)
     maskp = torch.sigmoid(rnd(B * S, G, seed=52)).to(dtype)

@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     """every function declared in include/devias_amd.h is exported by libdevias_amd.so and bound in _lib.PROTOTYPES"""
     from devias_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "devias_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|int64_t|void|const char\*)\s+(devias_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int32_t|int64_t|void|const char\*)\s+(devias_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 25
     lib = _lib.load()
     for name in declared:
