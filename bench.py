@@ -47,6 +47,7 @@ def parse():
                     "collective replaced by a same-size device copy on the side stream")
     ap.add_argument("--cu-hog", type=int, default=0, help="hold this many CUs (128 KiB LDS each) on a side stream during every backward: stand-in for the CUs "
                     "RCCL's kernels occupy at N > 1")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="persistent GEMM grids leave this many CUs free (library option gemm_reserve_cus)")
     ap.add_argument("--cu-hog-us", type=int, default=36000, help="how long each --cu-hog workgroup holds its CU (about one backward)")
     return ap.parse_args()
 
@@ -76,7 +77,7 @@ def cpu_baseline(args):
     B = 2
     P = synth.fill_params(ref_cpu.param_shapes(cfg), seed=0)
     x = synth.video(B, cfg.all_frames, cfg.img_size)
-    y, tl, fg = synth.targets(B), synth.teacher_logits(B), synth.fg_masks(B, cfg.num_patches)
+    y, tl, fg = synth.targets(B), synth.teacher_logits(B), synth.fg_masks(B, cfg.num_patches, (args.img_size // 16) ** 2)
     ref_cpu.train_step(P, cfg, x, y, tl, fg)
     t0 = time.perf_counter()
     for _ in range(args.cpu_steps):
@@ -138,6 +139,9 @@ def main():
     torch.cuda.set_device(device)
 
     model = build_model(args, device)
+    if args.reserve_cus:
+        from devias_amd import ops as _o
+        _o.set_option("gemm_reserve_cus", args.reserve_cus)
     B = args.batch
     N = model.patch_embed.num_patches
     first = rank * B                                   # rank r owns clips [B r, B r + B) of the global batch (weak scaling)
@@ -261,7 +265,8 @@ def main():
         "config": {"workload": f"slot-{args.model} 16-patch {args.frames}x{args.img_size}^2 ({N} tokens), S=2 slots, tied agg depth 8, "
                                f"B={B} clips/GPU, student fwd + matching loss + bwd" + (f" + RCCL grad all-reduce ({args.comm_dtype} wire format, 64 MiB fp32 buckets, side stream)" if world > 1 else "") +
                                (" + gradient-bucket path with the collective replaced by a device copy (--force-gradsync)" if args.force_gradsync and world == 1 else "") +
-                               (f" + {args.cu_hog} CUs held on a side stream during backward (--cu-hog)" if args.cu_hog else ""),
+                               (f" + {args.cu_hog} CUs held on a side stream during backward (--cu-hog)" if args.cu_hog else "") +
+                               (f" + persistent GEMM grids sized for {args.reserve_cus} fewer CUs (--reserve-cus)" if args.reserve_cus else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
                    "kernels": "persistent 256x256 GEMM (forward + dgrad; stream-K schedule for fc2 / dfc1 / dqkv), two-kernel MFMA attention backward, folded slot cross-attention (K/V projections on the slot side); "

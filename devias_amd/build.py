@@ -27,7 +27,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "roctx_shim.h"),
                                                        os.path.join(HERE, "..", "include", "devias_amd.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -65,6 +65,32 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(f"built {LIB} ({os.path.getsize(LIB) / 1e6:.2f} MB)")
     return LIB
+
+
+def build_asan(out_path: str) -> str:
+    """CPU-side sanitizer build (the reference has no native code to sanitize; this library's host side does): the two host-only
+    translation units -- api.hip (error strings, options, counters, RCCL / roctx resolution) and regions.hip (argument structs, arena layouts,
+    workspace arithmetic of the fused regions) -- compiled with AddressSanitizer + UBSan on the HOST side only, linked with the regular objects
+    of the kernel files.  Never run on the GPU box (GPU sanitizers are unavailable there); tests/test_sanitizer_cpu.py drives the
+    argument-validation paths of every entry point through it without touching a device."""
+    build(force=False, verbose=False)                  # regular objects of the kernel translation units
+    san = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-Xarch_host", "-fno-sanitize-recover=undefined", "-g"]
+    objs = []
+    for src in SOURCES:
+        if src in ("api.hip", "regions.hip"):
+            obj = os.path.join(os.path.dirname(out_path), src.replace(".hip", ".asan.o"))
+            cmd = [HIPCC] + [f for f in FLAGS if f != "-O3"] + ["-O1"] + san + ["-c", os.path.join(CSRC, src), "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc (sanitizer build) failed for {src}:\n{r.stdout}\n{r.stderr}")
+            objs.append(obj)
+        else:
+            objs.append(os.path.join(CSRC, src.replace(".hip", ".o")))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan", "-o", out_path] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link (sanitizer build) failed:\n{r.stdout}\n{r.stderr}")
+    return out_path
 
 
 if __name__ == "__main__":

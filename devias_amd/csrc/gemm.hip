@@ -1446,6 +1446,10 @@ struct GemmKnobs {
     int sk_eff;        // "gemm_sk_eff"     DEVIAS_GEMM_SK_EFF   policy: tiles / (rounds * workgroups) below this many percent (default 80) ...
     int sk_mink;       // "gemm_sk_mink"    DEVIAS_GEMM_SK_MINK  ... and at least this many K-tiles per output tile (default 32)
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
+    int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent / stream-K grids leave this many CUs free (default 0).  Their static tile
+                       //                                        lists assume one resident workgroup per CU of the grid: with K CUs held by another kernel
+                       //                                        (RCCL during backward at N > 1) the K workgroups that find no CU run AFTER the others --
+                       //                                        a doubled tail, measured +17 % on the step with 8-32 CUs held (bench.py --cu-hog)
     int ncu;
 };
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -1461,6 +1465,7 @@ GemmKnobs& knobs() {
         x.sk_eff = env_int("DEVIAS_GEMM_SK_EFF", 80);
         x.sk_mink = env_int("DEVIAS_GEMM_SK_MINK", 32);
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
+        x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -1482,6 +1487,7 @@ int devias_gemm_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_sk_eff")) k.sk_eff = value;
     else if (!strcmp(name, "gemm_sk_mink")) k.sk_mink = value;
     else if (!strcmp(name, "gemm_debug")) k.debug = value;
+    else if (!strcmp(name, "gemm_reserve_cus")) k.reserve = value < 0 ? 0 : value;
     else return 0;
     return 1;
 }
@@ -1584,7 +1590,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;
         const int ta = a->trans_a, tb = a->trans_b;
         const int nt = p.tiles_m * p.tiles_n;
-        const int gp = kn.ncu & ~7;
+        const int gp = (kn.ncu - kn.reserve > 8 ? kn.ncu - kn.reserve : 8) & ~7;
         // persistent form (more than one round of tiles, no split-K, bf16 output): measured per shape at M = 50176 (tools/gemm_block_shapes.py, same
         // box, one-tile-per-workgroup -> persistent): qkv 226 -> 204 us, fc1 278 -> 243, dfc2 + dGELU + colsum 415 -> 349, dfc2 plain 275 -> 248,
         // dproj 81 -> 72; the long-K dgrad shapes unchanged (dfc1 252, dqkv 192)

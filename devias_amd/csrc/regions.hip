@@ -111,8 +111,8 @@ struct BlockSave {
     BlockSave(void* base, int B, int N, int D, int H, int hid, int dtype) {
         const int64_t M = (int64_t)B * N, es = esize(dtype);
         int64_t off = 0;
-        char* p = reinterpret_cast<char*>(base);
-        auto take = [&](int64_t n) { char* r = p + off; off += al256(n); return r; };
+        const uintptr_t p = reinterpret_cast<uintptr_t>(base);          // (integer arithmetic: the size queries lay the arena out at address 0)
+        auto take = [&](int64_t n) { char* r = reinterpret_cast<char*>(p + (uintptr_t)off); off += al256(n); return r; };
         u = take(M * D * es); qkv = take(M * 3 * D * es); o = take(M * D * es); x1 = take(M * D * es); u2 = take(M * D * es);
         hpre = take(M * hid * es); hact = take(M * hid * es);
         mean1 = (float*)take(M * 4); rstd1 = (float*)take(M * 4); mean2 = (float*)take(M * 4); rstd2 = (float*)take(M * 4);
@@ -127,8 +127,8 @@ struct BlockScratch {
     BlockScratch(void* base, int B, int N, int D, int H, int hid, int dtype) {
         const int64_t M = (int64_t)B * N, es = esize(dtype);
         int64_t off = 0;
-        char* p = reinterpret_cast<char*>(base);
-        auto take = [&](int64_t n) { char* r = p + off; off += al256(n); return r; };
+        const uintptr_t p = reinterpret_cast<uintptr_t>(base);          // (integer arithmetic: the size queries lay the arena out at address 0)
+        auto take = [&](int64_t n) { char* r = reinterpret_cast<char*>(p + (uintptr_t)off); off += al256(n); return r; };
         big = take(M * (hid > 3 * D ? hid : 3 * D) * es); small = take(M * D * es); dx1 = take(M * D * es); g = take(M * D * es);
         delta = (float*)take((int64_t)B * H * N * 4);
         bytes = off;
@@ -231,8 +231,8 @@ struct HeadSave {
     HeadSave(void* base, int R, int D, int h1, int h2, int dtype) {
         const int64_t es = esize(dtype);
         int64_t off = 0;
-        char* p = reinterpret_cast<char*>(base);
-        auto take = [&](int64_t n) { char* r = p + off; off += al256(n); return r; };
+        const uintptr_t p = reinterpret_cast<uintptr_t>(base);          // (integer arithmetic: the size queries lay the arena out at address 0)
+        auto take = [&](int64_t n) { char* r = reinterpret_cast<char*>(p + (uintptr_t)off); off += al256(n); return r; };
         m1 = take((int64_t)R * h1 * es); m2 = take((int64_t)R * h2 * es); sd = take((int64_t)R * D * es);
         bytes = off;
     }
@@ -330,8 +330,8 @@ struct AggSave {
         const int64_t es = esize(a->dtype), M = (int64_t)a->B * a->N, R = (int64_t)a->B * a->S, D = a->D, hD = (int64_t)a->heads * a->D, F = a->ff;
         const int nset = a->tied ? 1 : a->depth;
         int64_t off = 0;
-        char* p = reinterpret_cast<char*>(base);
-        auto take = [&](int64_t n) { char* r = p + off; off += al256(n); return r; };
+        const uintptr_t p = reinterpret_cast<uintptr_t>(base);          // (integer arithmetic: the size queries lay the arena out at address 0)
+        auto take = [&](int64_t n) { char* r = reinterpret_cast<char*>(p + (uintptr_t)off); off += al256(n); return r; };
         feats = take(M * D * es); m0 = (float*)take(M * 4); r0 = (float*)take(M * 4);
         for (int i = 0; i < nset; ++i) {
             c[i] = take(M * D * es); mc[i] = (float*)take(M * 4); rc[i] = (float*)take(M * 4);
@@ -365,8 +365,8 @@ struct AggScratch {
         const int nl = a->tied ? a->depth : 1;
         const int64_t K = 2 * (int64_t)nl * a->heads * a->S, Np = (a->N + 7) / 8 * 8;
         int64_t off = 0;
-        char* p = reinterpret_cast<char*>(base);
-        auto take = [&](int64_t n) { char* r = p + off; off += al256(n); return r; };
+        const uintptr_t p = reinterpret_cast<uintptr_t>(base);          // (integer arithmetic: the size queries lay the arena out at address 0)
+        auto take = [&](int64_t n) { char* r = reinterpret_cast<char*>(p + (uintptr_t)off); off += al256(n); return r; };
         dz_layer = R * hD * es; ds_layer = (int64_t)a->B * a->heads * a->S * a->N * 4;
         dz_stack = take(dz_layer * a->depth); ds_stack = (float*)take(ds_layer * a->depth);
         dxs[0] = take(R * D * es); dxs[1] = take(R * D * es); dfpre = take(R * F * es); df = take(R * D * es); dxs1 = take(R * D * es);

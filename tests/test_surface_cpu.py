@@ -143,3 +143,50 @@ def test_gemm_debug_build_compiles(tmp_path):
         elif re.search(r"\bst[0-3]\s*=\s*__builtin_amdgcn_s_memrealtime", line) and depth == 0 and not t.startswith("//"):     # (the stream-K hand-off timeout also reads the clock)
             bad.append(ln)
     assert not bad, bad
+
+
+def test_published_column_sums_go_stale_safely_with_two_consumers():
+    """a residual-stream gradient that carries published column sums and then receives a SECOND consumer's gradient (autograd's
+    InputBuffer accumulates it in place into the tagged tensor: same object, same data_ptr) must not hand out the stale sums."""
+    from devias_amd import modeling_slot as ms
+    seen = {}
+
+    class Producer(torch.autograd.Function):          # stands for a block whose LayerNorm backward publishes colsum(dx) on dx
+        @staticmethod
+        def forward(ctx, h, tag):
+            ctx.tag = tag
+            return h * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            dx = g * 2.0
+            ms._publish_colsum(dx, dx.sum(0))
+            return dx, None
+
+    class Upstream(torch.autograd.Function):          # stands for the previous block: consumes the (possibly accumulated) gradient
+        @staticmethod
+        def forward(ctx, h):
+            return h + 0.0
+
+        @staticmethod
+        def backward(ctx, g):
+            cs = ms._peek_colsum(g)
+            seen["hit"] = cs is not None
+            seen["ok"] = cs is None or torch.equal(cs, g.sum(0))
+            seen["true_sum"] = g.sum(0).clone()
+            return g
+
+    h = torch.arange(12.0).reshape(4, 3).requires_grad_(True)
+    y = Upstream.apply(h)
+    (Producer.apply(y, 0).sum() + Producer.apply(y, 1).pow(2).sum()).backward()          # two consumers of y
+    assert seen["ok"], "stale column sums were handed out"
+    assert torch.equal(h.grad.sum(0), seen["true_sum"])
+    # single consumer: the published sums are used
+    h2 = torch.arange(12.0).reshape(4, 3).requires_grad_(True)
+    Producer.apply(Upstream.apply(h2), 0).sum().backward()
+    assert seen["hit"] and seen["ok"]
+    # and an explicit in-place change after publication invalidates the tag
+    t = torch.ones(4, 3)
+    ms._publish_colsum(t, t.sum(0))
+    t.add_(1.0)
+    assert ms._peek_colsum(t) is None
