@@ -23,6 +23,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=f
          "-mllvm", "-amdgpu-mfma-vgpr-form"]   # keep MFMA accumulators in VGPRs: no v_accvgpr_* shuffles around the VALU epilogues
 
 
+def _flags(src: str):
+    return FLAGS
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -37,7 +41,7 @@ def _compile(src: str) -> str:
     deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "roctx_shim.h"), os.path.join(HERE, "..", "include", "devias_amd.h")]
     if os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
         return obj
-    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC] + _flags(src) + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -79,7 +83,7 @@ def build_asan(out_path: str) -> str:
     for src in SOURCES:
         if src in ("api.hip", "regions.hip"):
             obj = os.path.join(os.path.dirname(out_path), src.replace(".hip", ".asan.o"))
-            cmd = [HIPCC] + [f for f in FLAGS if f != "-O3"] + ["-O1"] + san + ["-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [HIPCC] + [f for f in _flags(src) if f != "-O3"] + ["-O1"] + san + ["-c", os.path.join(CSRC, src), "-o", obj]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"hipcc (sanitizer build) failed for {src}:\n{r.stdout}\n{r.stderr}")

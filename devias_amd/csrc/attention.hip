@@ -129,6 +129,39 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
     }
 }
 
+// The same staging through a buffer descriptor (buffer_load ... lds): descriptor + SCALAR tile offset + a loop-invariant per-lane offset, i.e. no
+// vector arithmetic per tile (the per-lane 64-bit source pointers of dma_tile cost 12-15 vector instructions per wave-instruction, and these
+// kernels are bound by their vector instruction count: rocprofv3 PMC, profiles/r3_attn_pmc.txt).  Rows past `nrows` are not clamped: they belong
+// to the next batch entry (finite) or lie beyond the tensor (read as zero); every consumer zeroes their probabilities.
+template <int NW, bool TR>
+struct TileDma {
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t vo[8 / NW];
+    int stride_bytes;
+    __device__ __forceinline__ void init(const bf16* p, int64_t row_stride, int64_t elems_left, int wave, int lane) {
+        const int64_t bytes = elems_left * 2;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p), 0, (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
+        stride_bytes = (int)row_stride * 2;
+#pragma unroll
+        for (int i = 0; i < 8 / NW; ++i) {
+            const int row = (wave * (8 / NW) + i) * 8 + (lane >> 3), slot = lane & 7;
+            const int chunk = TR ? ((((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1)) : (slot ^ (row & 7));
+            vo[i] = (uint32_t)((row * (int)row_stride + chunk * 8) * 2);
+        }
+    }
+    __device__ __forceinline__ void issue(int row0, char* img, int wave) const {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass does not know the builtin)
+#pragma unroll
+        for (int i = 0; i < 8 / NW; ++i) {
+            const int r8 = (wave * (8 / NW) + i) * 8;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(img + r8 * 128), 16, vo[i], row0 * stride_bytes, 0, 0);
+        }
+#else
+        (void)row0; (void)img; (void)wave;
+#endif
+    }
+};
+
 // ======================================= forward (bf16) ===================================================
 template <int QT, int NW, bool DMA, int OCC = 1>
 __global__ __launch_bounds__(NW * 64, OCC) void mhsa_fwd_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
@@ -165,9 +198,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void mhsa_fwd_bf16_kernel(const bf16*
 
     const int nkv = (N + 63) / 64;
     TileRegs<NW * 64> rk, rv;
+    TileDma<NW, false> dK;
+    TileDma<NW, true> dV;
     if constexpr (DMA) {
-        dma_tile<NW, false>(base + D, RS, 0, N, smem, wave, lane);
-        dma_tile<NW, true>(base + 2 * D, RS, 0, N, smem + 8192, wave, lane);
+        const int64_t left = ((int64_t)(xcd >> 16) - b) * N * RS - h * 64;      // elements from `base` to the end of qkv
+        dK.init(base + D, RS, left - D, wave, lane);
+        dV.init(base + 2 * D, RS, left - 2 * D, wave, lane);
+        dK.issue(0, smem, wave);
+        dV.issue(0, smem + 8192, wave);
     } else {
         rk.load(base + D, RS, 0, N, tid);
         rv.load(base + 2 * D, RS, 0, N, tid);
@@ -181,8 +219,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void mhsa_fwd_bf16_kernel(const bf16*
             imgV = imgK + 8192;
             if (t + 1 < nkv) {
                 char* nxt = smem + ((t + 1) & 1) * 16384;
-                dma_tile<NW, false>(base + D, RS, (t + 1) * 64, N, nxt, wave, lane);
-                dma_tile<NW, true>(base + 2 * D, RS, (t + 1) * 64, N, nxt + 8192, wave, lane);
+                dK.issue((t + 1) * 64, nxt, wave);
+                dV.issue((t + 1) * 64, nxt + 8192, wave);
             }
         } else {
             rk.store_rows(imgK, tid);
@@ -336,8 +374,15 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 
     const int nkv = (N + 63) / 64;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    dma_tile<NW, true>(base + D, RS, 0, N, smem, wv, lane);
-    dma_tile<NW, false>(base + 2 * D, RS, 0, N, smem + 8192, wv, lane);
+    TileDma<NW, true> dK;
+    TileDma<NW, false> dV;
+    {
+        const int64_t left = ((int64_t)(xcd >> 16) - b) * N * RS - h * 64;      // elements from `base` to the end of qkv
+        dK.init(base + D, RS, left - D, wv, lane);
+        dV.init(base + 2 * D, RS, left - 2 * D, wv, lane);
+    }
+    dK.issue(0, smem, wv);
+    dV.issue(0, smem + 8192, wv);
     for (int t = 0; t < nkv; ++t) {
         // one barrier per tile: tile t has landed for every wave, and everyone is done reading tile t-1's stage (rows past N re-read row N-1:
         // finite data whose probabilities are exactly zero)
@@ -347,8 +392,8 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
         imgV = imgKt + 8192;
         if (t + 1 < nkv) {
             char* nxt = smem + ((t + 1) & 1) * 16384;
-            dma_tile<NW, true>(base + D, RS, (t + 1) * 64, N, nxt, wv, lane);
-            dma_tile<NW, false>(base + 2 * D, RS, (t + 1) * 64, N, nxt + 8192, wv, lane);
+            dK.issue((t + 1) * 64, nxt, wv);
+            dV.issue((t + 1) * 64, nxt + 8192, wv);
         }
         if (q0 < N) {                         // (waves without a valid query only stage and synchronise: see the forward kernel)
         f32x4 acc_s[4][QT], acc_dp[4][QT];
@@ -463,8 +508,11 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
         return r0 + tid - 64 < N ? dl_bh[r0 + tid - 64] : 0.f;
     };
     float rstat = 0.f;
-    dma_tile<4, true>(base, RS, 0, N, smem, wv, lane);
-    dma_tile<4, true>(dobase, D, 0, N, smem + 8192, wv, lane);
+    TileDma<4, true> dQ_, dO_;
+    dQ_.init(base, RS, ((int64_t)(xcd >> 16) - b) * N * RS - h * 64, wv, lane);
+    dO_.init(dobase, D, ((int64_t)(xcd >> 16) - b) * N * D - h * 64, wv, lane);
+    dQ_.issue(0, smem, wv);
+    dO_.issue(0, smem + 8192, wv);
     if (tid < 128) {
         s_stat[tid] = stat_load(0);
         if (nq > 1) rstat = stat_load(64);      // always one tile ahead of the LDS copy
@@ -480,8 +528,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
         s_dl = s_lse + 64;
         if (t + 1 < nq) {
             char* nxt = smem + ((t + 1) & 1) * 16384;
-            dma_tile<4, true>(base, RS, (t + 1) * 64, N, nxt, wv, lane);
-            dma_tile<4, true>(dobase, D, (t + 1) * 64, N, nxt + 8192, wv, lane);
+            dQ_.issue((t + 1) * 64, nxt, wv);
+            dO_.issue((t + 1) * 64, nxt + 8192, wv);
             if (tid < 128) {
                 s_stat[((t + 1) & 1) * 128 + tid] = rstat;
                 if (t + 2 < nq) rstat = stat_load((t + 2) * 64);
@@ -542,272 +590,6 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             }
         }
         }
-    }
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const int key = key0 + 16 * kt + c;
-        if (key < N) {
-            bf16* row = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                store4(row + D + 16 * dt, acc_dk[dt][kt] * scale);
-                store4(row + 2 * D + 16 * dt, acc_dv[dt][kt]);
-            }
-        }
-    }
-}
-
-// ======================================= backward, single pass (bf16) =====================================
-// dQ, dK and dV from ONE evaluation of S and dP per (query tile, key block): five matrix products per tile pair instead of the seven
-// of the two-kernel scheme above (which recomputes S and dP in both kernels).
-//   workgroup = 4 waves x 32 keys = one 128-key block of one (batch, head); dK^T / dV^T of its keys stay in registers for the whole sweep
-//   over the query tiles (64 queries each); S, dP with the key on the lane (as mhsa_bwd_dkdv); dS additionally goes through LDS ONCE
-//   (image [key][query], transposed reads) for dQ^T(64 d x 64 q) += K^T dS^T over the block's 128 keys, each wave producing 16 queries.
-// dQ needs a sum over the L = ceil(N / 128) key blocks of the head.  It is formed by an ORDERED HAND-OFF, not by atomics: for query tile t
-// the blocks add their contribution in the fixed cyclic order t mod L, t mod L + 1, ... (position pos = (block - t) mod L); a block
-// reads its predecessor's fp32 partial (fragment order, 16 B per lane, sc1), adds its own, and either passes the sum on (sc1 stores, every
-// wave's vmcnt(0), workgroup barrier, ONE agent-scope flag store -- MI355X_MICROARCH.md "hand-offs measured with sc1 loads", row 1) or,
-// at the last position, writes dQ.  The summation order of every element is fixed -> bitwise reproducible.  Block j visits its tiles in
-// the order pos = 0, 1, ..., L-1 (tiles t = j - pos mod L), so a block at position pos needs what its predecessor produced one round
-// earlier: no pipeline fill, and a block only ever spins when its predecessor is not resident yet (dispatch is in block order and the
-// blocks of a head are consecutive on one XCD).  Spins are bounded: on a timeout the error word is set and the block carries on.
-// delta = rowsum(dO * O) is computed per tile from the O rows (no separate pass, no delta buffer).
-enum { FB_LDS = 8192 * 4 + 16384 * 2 + 512 };
-
-__device__ __forceinline__ void fb_next(int& t, int& r, int j, int L, int nt) {
-    t += L;
-    if (t >= nt) { ++r; t = j - r; if (t < 0) t += L; }
-}
-
-// LDS: Q and dO tiles double-buffered (a tile's images are still read after barrier [B] while the next tile is staged), the block's
-// K rows, the dS tile, row statistics.  Two barriers per tile: [A] images + statistics of tile i complete / dS image free,
-// [B] dS image complete.
-__global__ __launch_bounds__(256, 2) void mhsa_bwd_fused_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
-                                                                     const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                                     bf16* __restrict__ dqkv, int* __restrict__ flags, float* __restrict__ part,
-                                                                     unsigned part_bytes, int N, int H, float scale, int xcd, int dbg) {
-    __shared__ __attribute__((aligned(16))) char smem[FB_LDS];
-    char* imgK = smem + 32768;          // this block's 128 K rows, two 64-row images: row reads (S = Q K^T) and transposed reads (dQ^T = K^T dS^T)
-    char* imgS = smem + 49152;          // dS of the current tile, [key][query], two 64-key images
-    float* s_lse = reinterpret_cast<float*>(smem + 65536);   // [64] log2-domain logsumexp (+inf for invalid rows)
-    float* s_dl = s_lse + 64;                                // [64] delta
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L = (N + 127) / 128, nt = (N + 63) / 64;
-    const HeadMap hm = head_map(L, H, xcd >> 16, (xcd & 1) != 0);
-    const int h = hm.h, b = hm.b, j = hm.blk;
-    const int hb = b * H + h;
-    const int D = H * 64;
-    const int64_t RS = 3 * (int64_t)D;
-    const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
-    const bf16* dobase = d_o + (int64_t)b * N * D + h * 64;
-    const bf16* obase = o + (int64_t)b * N * D + h * 64;
-    const int key0 = j * 128 + wave * 32;
-    const float sl2 = scale * LOG2E;
-    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(part, 0, part_bytes, 0x00020000);
-
-    bf16x8 vreg[2][2];                  // this wave's 32 V rows as B operands of dP = dO V^T (its K rows are read from imgK)
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        int key = min(key0 + 16 * kt + c, N - 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            vreg[kt][ks] = *reinterpret_cast<const bf16x8*>(base + 2 * D + (int64_t)key * RS + 32 * ks + 8 * g);
-    }
-    {   // the block's K rows into LDS (rows past N are zero: their dS is zeroed too)
-        TileRegs<256> rk;
-        rk.load(base + D, RS, j * 128, N, tid);
-        rk.store_tr(imgK, tid);
-        rk.load(base + D, RS, j * 128 + 64, N, tid);
-        rk.store_tr(imgK + 8192, tid);
-    }
-    const char* myK = imgK + (wave >> 1) * 8192;        // the 64-row image holding this wave's keys, at rows (wave & 1) * 32 ..
-    const int myrow = (wave & 1) * 32;
-    f32x4 acc_dk[4][2], acc_dv[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) { acc_dk[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dv[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-    const float* lse_bh = lse + (int64_t)hb * N;
-    TileRegs<256> rq, rdo, ro;
-    float rstat = 0.f;
-    int t = j, r = 0;                                   // first tile: position 0 of its chain (j < L <= nt)
-    rq.load(base, RS, t * 64, N, tid);
-    rdo.load(dobase, D, t * 64, N, tid);
-    ro.load(obase, D, t * 64, N, tid);
-    if (tid < 64) rstat = t * 64 + tid < N ? lse_bh[t * 64 + tid] * LOG2E : INFINITY;
-
-    int pub_t = -1, pub_v = 0;                          // tile whose partial this block stored last and the flag value to publish for it
-    int fpeek = 0;                                      // early, non-blocking read of the current tile's flag (thread 0)
-    int buf = 0;
-    while (r < L) {
-        const int pos = r;
-        char* imgQt = smem + buf * 16384;               // Q tile, one image: row reads (S = Q K^T) and transposed reads (dK^T = Q^T dS)
-        char* imgOt = imgQt + 8192;                     // dO tile, one image: row reads (dP = dO V^T) and transposed reads (dV^T = dO^T P)
-        buf ^= 1;
-        // ---- stage the tile: images, logsumexp, delta = rowsum(dO * O) (8 consecutive threads share a row) -------------------------------
-        rq.store_tr(imgQt, tid);
-        rdo.store_tr(imgOt, tid);
-        if (tid < 64) s_lse[tid] = rstat;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&rdo.v[i]), bb = *reinterpret_cast<const bf16x8*>(&ro.v[i]);
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d += (float)a[e] * (float)bb[e];
-            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-            if ((tid & 7) == 0) s_dl[(tid >> 3) + 32 * i] = d;
-        }
-        // ---- the predecessor's partial sum for this tile must have been published (usually already seen by the early peek) ---------------
-        if (pos > 0 && tid == 0 && fpeek < pos && !(dbg & 1)) {
-            const int* f = flags + (int64_t)hb * nt + t;
-            int spins = 0;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pos) {
-                __builtin_amdgcn_s_sleep(8);
-                // bounded: ~0.3 s for the first expired wait of a launch, ~1 ms for every later one (the error word is already set)
-                if (++spins > (1 << 18) || ((spins & 1023) == 0 && __hip_atomic_load(flags - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                    __hip_atomic_store(flags - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __syncthreads();                                                              // [A]
-        const int tcur = t;
-        fb_next(t, r, j, L, nt);
-        const unsigned poff = (unsigned)(((int64_t)hb * nt + tcur) * 16384 + wave * 4096 + lane * 16);
-        u32x4 pq[4];
-        if (pos > 0 && !(dbg & 2)) {                    // the predecessor's partial: in flight under S / dP
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) pq[dt] = __builtin_amdgcn_raw_buffer_load_b128(prs, poff + dt * 1024, 0, 16);
-        }
-        // ---- S and dP, P and dS: acc[q2][kt] holds queries 16(2 s2 + q2) + 4g + r (rows) x key c (col); done in two halves of 32 queries so
-        // that only 32 accumulator registers are live at a time; P / dS are packed to bf16 as they are produced (they are the B operands
-        // of the dV^T / dK^T products) and dS also goes to LDS as [key][query] ---------------------------------------------------------
-        bf16x8 pf[2][2], dsf[2][2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            f32x4 acc_s[2][2], acc_dp[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) { acc_s[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 kf[2];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) kf[kt] = frag_rows_tr(myK, myrow + 16 * kt, ks, lane);
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2) {
-                    bf16x8 qfr = frag_rows_tr(imgQt, 16 * (2 * s2 + q2), ks, lane);
-                    bf16x8 dofr = frag_rows_tr(imgOt, 16 * (2 * s2 + q2), ks, lane);
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
-                        acc_s[q2][kt] = mfma(qfr, kf[kt], acc_s[q2][kt]);
-                        acc_dp[q2][kt] = mfma(dofr, vreg[kt][ks], acc_dp[q2][kt]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                const int qt = 2 * s2 + q2;
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(s_lse + 16 * qt + 4 * g);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dl + 16 * qt + 4 * g);
-                const f32x2 sl2v = {sl2, sl2};
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int rr = 0; rr < 4; rr += 2) {
-                        const f32x2 e = f32x2{acc_s[q2][kt][rr], acc_s[q2][kt][rr + 1]} * sl2v - f32x2{l4[rr], l4[rr + 1]};
-                        const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
-                        const f32x2 ds = p * (f32x2{acc_dp[q2][kt][rr], acc_dp[q2][kt][rr + 1]} - f32x2{d4[rr], d4[rr + 1]});   // dS / scale
-                        acc_s[q2][kt][rr] = p[0]; acc_s[q2][kt][rr + 1] = p[1];
-                        acc_dp[q2][kt][rr] = ds[0]; acc_dp[q2][kt][rr + 1] = ds[1];
-                    }
-            }
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                pf[s2][kt] = pack8(acc_s[0][kt], acc_s[1][kt]);
-                dsf[s2][kt] = pack8(acc_dp[0][kt], acc_dp[1][kt]);
-                const int kl = wave * 32 + 16 * kt + c;                       // key inside the block
-                const bool kvalid = j * 128 + kl < N;                         // keys past N contribute nothing to dQ
-                char* img = imgS + (kl >> 6) * 8192;
-                const bf16x8 v8 = dsf[s2][kt];
-                bf16x4 lo = {v8[0], v8[1], v8[2], v8[3]}, hi = {v8[4], v8[5], v8[6], v8[7]};
-                if (!kvalid) { lo = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}; hi = lo; }
-                *reinterpret_cast<bf16x4*>(img + img_tr_off(kl & 63, 16 * (2 * s2) + 4 * g)) = lo;
-                *reinterpret_cast<bf16x4*>(img + img_tr_off(kl & 63, 16 * (2 * s2 + 1) + 4 * g)) = hi;
-            }
-        }
-        // The previous tile's partial was stored ~one S / dP phase ago, BEFORE this tile's partial loads were requested: vmcnt completes in
-        // issue order, so "at most the 4 partial loads outstanding" means those stores have left the CU.  Then barrier, then ONE flag store.
-        if (pub_t >= 0) {
-            if (pos > 0 && !(dbg & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();                                                              // [B] the dS image is complete; the statistics are free
-        if (pub_t >= 0 && tid == 0) __hip_atomic_store(flags + (int64_t)hb * nt + pub_t, pub_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pub_t = -1;
-        // ---- the next tile's rows and an early look at its flag: requested BEFORE this tile's partial stores, so that waiting for them at the
-        // top of the next tile does not wait for those stores ---------------------------------------------------------------------------------
-        if (r < L) {
-            rq.load(base, RS, t * 64, N, tid);
-            rdo.load(dobase, D, t * 64, N, tid);
-            ro.load(obase, D, t * 64, N, tid);
-            if (tid < 64) rstat = t * 64 + tid < N ? lse_bh[t * 64 + tid] * LOG2E : INFINITY;
-            if (r > 0 && tid == 0) fpeek = __hip_atomic_load(flags + (int64_t)hb * nt + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- dQ^T (64 d x this wave's 16 queries) = K^T dS^T over the block's 128 keys: first, so that its hand-off (stores, then the
-        // publication after the next barrier [A]) has the dV / dK products to hide behind ------------------------------------------------------
-        f32x4 acc_dq[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc_dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 dsT = frag_tr(imgS + kb * 8192, 16 * wave, s2, lane);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    bf16x8 kT = frag_tr(imgK + kb * 8192, 16 * dt, s2, lane);
-                    acc_dq[dt] = mfma(kT, dsT, acc_dq[dt]);
-                }
-            }
-        if (pos > 0 && !(dbg & 2)) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc_dq[dt] += *reinterpret_cast<const f32x4*>(&pq[dt]);     // predecessors first, then this block: fixed order
-        }
-        if (pos < L - 1 && (dbg & 4)) {
-        } else if (pos < L - 1) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&acc_dq[dt]), prs, poff + dt * 1024, 0, 16);
-            pub_t = tcur; pub_v = pos + 1;              // published after the next tile's barrier [B]
-        } else {
-            const int q = tcur * 64 + 16 * wave + c;
-            if (q < N) {
-                bf16* row = dqkv + ((int64_t)b * N + q) * RS + h * 64 + 4 * g;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt, acc_dq[dt] * scale);
-            }
-        }
-        // ---- dV^T += dO^T P, dK^T += Q^T dS -----------------------------------------------------------------------------------------
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                bf16x8 dot = frag_tr(imgOt, 16 * dt, s2, lane);
-                bf16x8 qt_ = frag_tr(imgQt, 16 * dt, s2, lane);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    acc_dv[dt][kt] = mfma(dot, pf[s2][kt], acc_dv[dt][kt]);
-                    acc_dk[dt][kt] = mfma(qt_, dsf[s2][kt], acc_dk[dt][kt]);
-                }
-            }
-    }
-    if (pub_t >= 0) {                                   // cannot happen (a block's last round is position L - 1, which publishes nothing); kept for safety
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(flags + (int64_t)hb * nt + pub_t, pub_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -993,18 +775,12 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dkdv_f32_kernel(const float* __r
 
 // process-wide options, read from the environment once; devias_set_option("attn_cfg" | "attn_xcd", v) changes them at run time
 namespace {
-struct AttnKnobs { int cfg, xcd, bwd, dbg; };
+struct AttnKnobs { int cfg, xcd; };
 AttnKnobs& attn_knobs() {
     static AttnKnobs k = [] {
         AttnKnobs x;
         const char* e = getenv("DEVIAS_ATTN_CFG"); x.cfg = e ? atoi(e) : 0;
         e = getenv("DEVIAS_ATTN_XCD"); x.xcd = e ? atoi(e) : 1;
-        e = getenv("DEVIAS_ATTN_DBG"); x.dbg = e ? atoi(e) : 0;      // timing ablations of the single-pass backward (wrong results): 1 no waits, 2 no partial loads, 4 no partial stores
-        // 0 (default) = dQ and dK/dV kernels (7 products), 1 = single-pass backward (5 products + ordered dQ hand-off; needs the workspace).
-        // Measured on MI355X at B = 32, H = 12, N = 1568 (tools/attn_bwd_ab.py): two kernels 1040 us; single pass 1170-1190 us, of which
-        // 885-920 us is its arithmetic (hand-off disabled) -- the write-through partial stores must have left the CU before the flag is
-        // published and that drain is exposed, so the default stays at the two-kernel path.
-        e = getenv("DEVIAS_ATTN_BWD"); x.bwd = e ? atoi(e) : 0;
         return x;
     }();
     return k;
@@ -1013,8 +789,6 @@ AttnKnobs& attn_knobs() {
 int devias_attn_set_option(const char* name, int value) {
     if (!strcmp(name, "attn_cfg")) attn_knobs().cfg = value;
     else if (!strcmp(name, "attn_xcd")) attn_knobs().xcd = value;
-    else if (!strcmp(name, "attn_bwd")) attn_knobs().bwd = value;
-    else if (!strcmp(name, "attn_dbg")) attn_knobs().dbg = value;
     else return 0;
     return 1;
 }
@@ -1052,14 +826,9 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
     return DEVIAS_OK;
 }
 
-// single-pass backward workspace: 4 int32 header words ([3] = hand-off time-out flag), B*H*ceil(N/64) int32 tile flags, then (256-byte aligned)
-// one 64 x 64 fp32 partial dQ tile per (batch, head, query tile)
-static int64_t fused_flag_words(int32_t B, int32_t N, int32_t H) { return 4 + (int64_t)B * H * cdiv(N, 64); }
-static int64_t fused_part_offset(int32_t B, int32_t N, int32_t H) { return (fused_flag_words(B, N, H) * 4 + 255) / 256 * 256; }
-extern "C" int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H) {
-    if (B <= 0 || N <= 0 || H <= 0) return 0;
-    return fused_part_offset(B, N, H) + (int64_t)B * H * cdiv(N, 64) * 16384;
-}
+// (ABI 140 had a single-pass backward that needed a workspace; it was removed in ABI 150 -- see DESIGN.md -- and the query stays for hosts
+// written against the older header: nothing is needed any more)
+extern "C" int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H) { (void)B; (void)N; (void)H; return 0; }
 
 extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                                int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* ws, void* stream) {
@@ -1070,20 +839,6 @@ extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, 
     if (dtype == DEVIAS_BF16) {
         const int cfg = attn_knobs().cfg;
         const int xcd = attn_xcd_flag(B, H);
-        const int64_t part_bytes = (int64_t)B * H * cdiv(N, 64) * 16384;
-        if (attn_knobs().bwd && ws && aligned16(ws) && part_bytes < ((int64_t)1 << 31) && cdiv(N, 128) < 256) {
-            devias_count(DEVIAS_CNT_MHSA_BWD_FUSED);
-            int* wi = reinterpret_cast<int*>(ws);
-            if (hipMemsetAsync(wi, 0, (size_t)fused_flag_words(B, N, H) * 4, st) != hipSuccess)
-                return devias_set_error(DEVIAS_ELAUNCH, "devias_mhsa_bwd: workspace memset failed");
-            float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + fused_part_offset(B, N, H));
-            const int L = cdiv(N, 128);
-            dim3 grid = (xcd & 1) ? dim3(L * H * B) : dim3(L, H, B);
-            hipLaunchKernelGGL(mhsa_bwd_fused_bf16_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse,
-                               (bf16*)dqkv, wi + 4, part, (unsigned)part_bytes, N, H, scale, xcd, attn_knobs().dbg);
-            DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(fused)");
-            return DEVIAS_OK;
-        }
         devias_count(DEVIAS_CNT_MHSA_BWD_BF16);
 #define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, xcd
 #define BWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)

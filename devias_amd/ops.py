@@ -302,24 +302,9 @@ def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float):
     _chk(qkv, "mhsa_bwd.qkv"); _chk(o, "mhsa_bwd.o", qkv.dtype); _chk(d_o, "mhsa_bwd.d_o", qkv.dtype)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    ws = None
-    if qkv.dtype == torch.bfloat16:          # single-pass backward: hand-off flags + per-tile fp32 partial dQ (devias_amd.h)
-        ws = workspace(_lib.load().devias_mhsa_bwd_workspace_bytes(B, N, H), qkv.device)
     _lib.check(_lib.load().devias_mhsa_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                           dqkv.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), _p(ws), _stream()), "devias_mhsa_bwd")
+                                           dqkv.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), None, _stream()), "devias_mhsa_bwd")
     return dqkv
-
-
-def mhsa_bwd_handoff_timeouts(device=None) -> int:
-    """word [3] of the single-pass backward workspace of the current stream: non-zero if a bounded hand-off wait expired in the last call
-    (synchronises; tests only)"""
-    key = (torch.device(device or "cuda").index or 0, torch.cuda.current_stream(device).cuda_stream)
-    ws = _workspaces.get(key)
-    if ws is None:
-        return 0
-    torch.cuda.synchronize()
-    w = ws[:4].view(torch.int32).tolist()
-    return int(w[3] != 0) + 2 * int(w[2] != 0)          # 1 = a bounded wait expired, 2 = a hand-off crossed XCDs (L2-local mode)
 
 
 def slot_attn_fwd(q, kv, B, S, N, h, dh, scale, attn_out=None, rsum_out=None):

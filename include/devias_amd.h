@@ -61,13 +61,13 @@ const char* devias_last_error(void);
 #define DEVIAS_CNT_MHSA_FWD_F32 8    /* VALU parity kernels */
 #define DEVIAS_CNT_MHSA_BWD_F32 9
 #define DEVIAS_CNT_GEMM_SK 11        /* 256x256 persistent kernel, stream-K schedule */
-#define DEVIAS_CNT_MHSA_BWD_FUSED 10 /* MFMA backward, single pass (dQ by ordered hand-off) */
+#define DEVIAS_CNT_MHSA_BWD_FUSED 10 /* (retired with ABI 150: always 0) */
 #define DEVIAS_CNT_MAX 16
 int64_t devias_counter(int32_t id);          /* -1 for an unknown id */
 void devias_counters_reset(void);
 /* Process-wide integer options (initialised once from the DEVIAS_* environment variables of the same meaning): "gemm_epi",
  * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_streamk", "gemm_sk_eff", "gemm_sk_mink", "gemm_debug", "gemm_reserve_cus" (CUs the persistent
- * GEMM grids leave free for a concurrent kernel, e.g. RCCL's during backward), "attn_cfg", "attn_xcd", "attn_bwd".  0 = ok, DEVIAS_EINVAL = unknown name. */
+ * GEMM grids leave free for a concurrent kernel, e.g. RCCL's during backward), "attn_cfg", "attn_xcd".  0 = ok, DEVIAS_EINVAL = unknown name. */
 int devias_set_option(const char* name, int32_t value);
 
 /* In-place SUM all-reduce of one flat gradient bucket over the caller's RCCL communicator (`nccl_comm` is an ncclComm_t; dtype DEVIAS_F32 or
@@ -192,11 +192,9 @@ int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
  * Encoder multi-head self-attention core (Attention.forward, modeling_slot.py:102-112): non-causal, no mask,
  * head dim 64.  qkv: T [B,N,3,H,64] exactly as F.linear produces it (:101-102, no permute copy); o: T [B,N,H*64];
  * lse: fp32 [B,H,N] = log sum_j exp(scale * q.k_j).  The N x N score matrix is never materialised.
- * backward: dqkv T [B,N,3,H,64]; delta fp32 [B,H,N] scratch (rowsum(dO*O)).  bf16 with a workspace `ws` (16-byte aligned,
- *   >= devias_mhsa_bwd_workspace_bytes; contents need not be initialised): ONE kernel, five matrix products per tile pair; dQ is summed over
- *   the 128-key blocks of a head by an ordered workgroup-to-workgroup hand-off (fixed order: bitwise reproducible), and the first int32
- *   words of `ws` hold hand-off state -- word [3] is non-zero afterwards if a bounded wait expired (results are then invalid).
- *   ws == NULL (or fp32): two kernels (dQ; dK/dV), seven products, `delta` used as scratch.
+ * backward: dqkv T [B,N,3,H,64]; delta fp32 [B,H,N] scratch (rowsum(dO*O)).  Two kernels (dQ; dK/dV), seven matrix products per tile pair (S and dP
+ *   are recomputed in both so that no gradient needs a sum across workgroups: bitwise reproducible, no atomics).  `ws` is unused since ABI 150 and may
+ *   be NULL (ABI 140 offered an opt-in single-pass backward with an ordered dQ hand-off; measured slower -- DESIGN.md -- and removed).
  * ------------------------------------------------------------------------------------------------- */
 int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
                     int32_t dtype, void* stream);

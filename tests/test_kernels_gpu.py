@@ -508,76 +508,42 @@ def test_gemm_persistent_kernels_repeatable(gemm_options):
     assert o.streamk_timeouts() == 0
 
 
-# ------------------------------------------------------------------------------------------------ single-pass attention backward
+# ------------------------------------------------------------------------------------------------ attention backward: grids, ragged shapes, descriptors
 @pytest.fixture
 def attn_options():
     o = ops()
     yield o
-    o.set_option("attn_bwd", 0)
     o.set_option("attn_xcd", 1)
 
 
 @pytest.mark.parametrize("B,N,H", [(1, 64, 1), (2, 100, 3), (1, 784, 2), (1, 1569, 1), (2, 200, 6), (8, 1568, 12), (3, 130, 8), (2, 6401, 4)])
 @pytest.mark.parametrize("xcd", [1, 0])
-def test_mhsa_bwd_single_pass_vs_two_kernel_and_fp32(B, N, H, xcd, attn_options):
-    """mhsa_bwd_fused_bf16_kernel (5 products per tile pair, dQ summed over the key blocks of a head by the ordered hand-off) against the fp32 op
-    and against the two-kernel path on the same inputs; the launch counters assert which path ran; no hand-off wait may expire; the
-    result is bitwise reproducible (fixed summation order).  Shapes cover one key block (no chain), ragged last blocks / tiles, chains of
-    2 .. 51 blocks, B*H not a multiple of 8 (plain 3-D grid) and the XCD-aware linear grid."""
+def test_mhsa_bwd_grids_and_ragged_shapes(B, N, H, xcd, attn_options):
+    """the dQ and dK/dV kernels (operand tiles staged through buffer descriptors: rows past N are NOT clamped -- they belong to the next batch
+    entry or read as zero -- and every consumer zeroes their probabilities) against the fp32 reference: one tile, ragged last tiles, the last
+    batch entry (reads past the end of the tensor), B*H not a multiple of 8 (plain 3-D grid) and the XCD-aware linear grid; bitwise repeatable"""
     o = attn_options
     o.set_option("attn_xcd", xcd)
     scale = 0.125
     qkv = rnd(B * N, 3 * H * 64, dtype=torch.bfloat16, seed=50)
     out, lse = o.mhsa_fwd(qkv, B, N, H, scale)
     d_o = rnd(B * N, H * 64, dtype=torch.bfloat16, seed=51)
-    res = {}
-    for mode in (1, 0):
-        o.set_option("attn_bwd", mode)
-        o.counters(reset=True)
-        res[mode] = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale)
-        cnt = o.counters()
-        assert (cnt["mhsa_bwd_fused"], cnt["mhsa_bwd_bf16"]) == ((1, 0) if mode else (0, 1)), cnt
-        if mode:
-            assert o.mhsa_bwd_handoff_timeouts() == 0
-    f, t = res[1].float().reshape(B, N, 3, H, 64), res[0].float().reshape(B, N, 3, H, 64)
-    for w, name in enumerate("qkv"):
-        assert rel(f[:, :, w], t[:, :, w]) < 1.5e-2, name        # two bf16 roundings of differently ordered fp32 sums
+    o.counters(reset=True)
+    res = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale)
+    cnt = o.counters()
+    assert cnt["mhsa_bwd_bf16"] == 1 and cnt["mhsa_bwd_fused"] == 0, cnt
+    assert torch.isfinite(res.float()).all()
     if B * N * N * H <= 2 * 1600 * 1600 * 2:                         # fp32 reference where the N x N matrix is affordable
         x = qkv.float().clone().requires_grad_(True)
         ro, _ = _attn_ref(x, B, N, H, scale)
+        assert rel(out.float(), ro) < 2e-2
         ro.backward(d_o.float())
         gr = x.grad.reshape(B, N, 3, H, 64)
+        f = res.float().reshape(B, N, 3, H, 64)
         for w, name in enumerate("qkv"):
             assert rel(f[:, :, w], gr[:, :, w]) < 3e-2, name
-    o.set_option("attn_bwd", 1)
-    for it in range(3):
-        assert torch.equal(o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale), res[1]), it
-    assert o.mhsa_bwd_handoff_timeouts() == 0
-
-
-def test_mhsa_bwd_single_pass_full_size_under_load(attn_options):
-    """the measured shape (B = 32, H = 12, N = 1568: 4992 workgroups in chains of 13, ~10 chains resident per XCD) next to a memory-bound stream:
-    20 repetitions bitwise identical, no expired wait"""
-    o = attn_options
-    B, N, H, scale = 32, 1568, 12, 0.125
-    qkv = rnd(B * N, 3 * H * 64, dtype=torch.bfloat16, seed=52)
-    out, lse = o.mhsa_fwd(qkv, B, N, H, scale)
-    d_o = rnd(B * N, H * 64, dtype=torch.bfloat16, seed=53)
-    o.set_option("attn_bwd", 1)
-    o.counters(reset=True)
-    ref = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale)
-    assert o.counters()["mhsa_bwd_fused"] == 1
-    assert torch.isfinite(ref.float()).all()
-    junk = torch.empty(128 << 20, device=DEV)
-    side = torch.cuda.Stream()
-    for it in range(20):
-        with torch.cuda.stream(side):
-            junk.mul_(1.0001)
-        assert torch.equal(o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale), ref), it
-    assert o.mhsa_bwd_handoff_timeouts() == 0
-    o.set_option("attn_bwd", 0)
-    two = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale)
-    assert rel(ref.float(), two.float()) < 1.5e-2
+    for it in range(2):
+        assert torch.equal(o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale), res), it
 
 
 # ------------------------------------------------------------------------------------------------ folded slot attention

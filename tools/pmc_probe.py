@@ -22,9 +22,6 @@ for it in range(3):
     o.wgrad(dy, x)                                                     # fc1 wgrad   (gemm256_kernel<true, true> + split-K reduce)
     out, lse = o.mhsa_fwd(qkv, B, N, H, 0.125)
     o.mhsa_bwd(qkv, out, out, lse, B, N, H, 0.125)
-    o.set_option("attn_bwd", 1)
-    o.mhsa_bwd(qkv, out, out, lse, B, N, H, 0.125)                     # single-pass backward (opt-in path)
-    o.set_option("attn_bwd", 0)
     y, mean, rstd = o.layernorm_fwd(x, g, b, 1e-6)
     o.layernorm_bwd(y, x, g, mean, rstd, dres=x)
     A, r, z = o.slotf_fwd(qp, x, B, 2, N, 4, D, 512 ** -0.5)           # folded slot attention, one layer
