@@ -1,6 +1,6 @@
 """timing ablations of the generation-2 dK/dV kernel (results are wrong by construction): attn_dkdv = 100 * ablation bits + 42"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from devias_amd import ops as o
 B, N, H = 32, 1568, 12

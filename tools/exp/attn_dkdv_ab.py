@@ -2,7 +2,7 @@
 of each variant against the fp32 reference on a small shape and against generation 1 on the measured shape.
 Usage: python tools/attn_dkdv_ab.py [cfgs comma separated, default 0,42,22] [N] [B] [H]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from devias_amd import ops as o
 

@@ -1,6 +1,6 @@
 """one attention forward + backward at the measured shape with a chosen dK/dV kernel: target of rocprofv3 PMC passes.  python tools/attn_one.py <attn_dkdv> [reps]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from devias_amd import ops as o
 c = int(sys.argv[1]) if len(sys.argv) > 1 else 0
