@@ -326,6 +326,203 @@ __global__ __launch_bounds__(NW * 64, OCC) void mhsa_fwd_bf16_kernel(const bf16*
     }
 }
 
+// ======================================= forward (bf16), 32x32x16 MFMAs ====================================
+// The same decomposition as mhsa_fwd_bf16_kernel (workgroup = NW waves x 32 queries, 64-key tiles by LDS-DMA into a two-stage ring, S^T = K Q^T so
+// that a query is a lane COLUMN and the probabilities are the next MFMA's operand without leaving the registers), built for the vector-issue
+// budget instead of the matrix one: these kernels are bound by how many vector instructions fit beside the MFMAs (rocprofv3 PMC: 226 vector
+// instructions per 32 MFMAs in the 16x16x32 kernel, matrix pipe 40 % busy), and a 32x32x16 MFMA leaves 24 of its 32 cycles to the vector
+// ALU where a 16x16x32 leaves 8 of 16.  Per score the kernel issues one v_exp_f32, half a v_max3, half a v_cvt_pk and one add:
+//   * Q is pre-multiplied by scale*log2(e) once (registers), and the S^T accumulators START from -m (the running row maximum, lane-constant), so
+//     the MFMA delivers S' = s - m and p = exp2(S') needs no subtraction;
+//   * the running maximum moves only when a tile's maximum exceeds it by more than THR = 6 (p <= 64: exact in the fp32 sums, bf16 P keeps its
+//     relative precision); then -- and at the first tile -- O, l, -m and the pending S' are rescaled together, BEFORE the tile's P is formed
+//     (MI355X guide T13: exponentiate a tile's P only after the decision that covers it);
+//   * register pairs (r, r + 1) of the S^T tile convert straight to the B operand of O^T += V^T P^T (k order inside a 16-key step: element j of
+//     lane half h is key 8 (j >> 2) + 4 h + (j & 3); the V^T fragments are read with that order by ds_read_b64_tr_b16).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ u32x2 lds_read_tr_asm(const char* p) {
+    u32x2 r;
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const bf16x2 t = {(bf16)a, (bf16)b};
+    return *reinterpret_cast<const unsigned*>(&t);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse,
+                                                                    int N, int H, float scale, int xcd) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];      // two stages of (K row image | V transposed-read image)
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, r32 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const HeadMap hm = head_map((N + NW * 32 - 1) / (NW * 32), H, xcd >> 16, (xcd & 1) != 0);
+    const int h = hm.h, b = hm.b;
+    const int D = H * 64;
+    const int64_t RS = 3 * (int64_t)D;
+    const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
+    const int q0 = hm.blk * (NW * 32) + wave * 32;
+    const bool active = q0 < N;                                        // (a wave without a valid query only stages and synchronises)
+    const float sl2 = scale * LOG2E;
+    constexpr float THR = 6.0f;
+
+    // Q^T as the B operand: lane (hi, query q0 + r32) holds d = 16 ks + 8 hi .. + 8, pre-scaled
+    bf16x8 qf[4];
+    {
+        const int q = min(q0 + r32, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (int64_t)q * RS + 16 * ks + 8 * hi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[ks][j] = (bf16)((float)v[j] * sl2);
+        }
+    }
+    f32x16 ot[2], negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; negm[r] = 0.f; }
+    float mrow = 0.f, lsum = 0.f;                                       // running maximum (log2 units) and this lane's share of the row sum
+
+    // loop-invariant LDS byte offsets: K row fragments (per 16-deep step ks; second key block = + 4096), V^T fragments (per 32-d block, + 2048 per 16 keys)
+    int ko[4], vo_[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ko[ks] = img_row_off(r32, 2 * ks + hi);
+    {
+        const int dsub = (lane >> 4) & 1, c = lane & 15;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) vo_[db] = img_tr_off(4 * hi + (c >> 2), 32 * db + 16 * dsub + 4 * (c & 3));
+    }
+
+    const int nkv = (N + 63) / 64;
+    TileDma<NW, false> dK;
+    TileDma<NW, true> dV;
+    {
+        const int64_t left = ((int64_t)(xcd >> 16) - b) * N * RS - h * 64;
+        dK.init(base + D, RS, left - D, wave, lane);
+        dV.init(base + 2 * D, RS, left - 2 * D, wave, lane);
+    }
+    auto stage = [&](int t) -> char* { return smem + (t & 1) * 16384; };
+    auto dma = [&](int t) { dK.issue(t * 64, stage(t), wave); dV.issue(t * 64, stage(t) + 8192, wave); };
+
+    // S'^T = K Q'^T - m of tile t: two 32-key blocks, rows = keys (r & 3) + 8 (r >> 2) + 4 hi, column = query r32.  MASK: ragged last tile
+    auto s_tile = [&](int t, f32x16 (&st)[2], bool mask) {
+        const char* imgK = stage(t);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            st[kb] = mfma32(*reinterpret_cast<const bf16x8*>(imgK + kb * 4096 + ko[0]), qf[0], negm);
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) st[kb] = mfma32(*reinterpret_cast<const bf16x8*>(imgK + kb * 4096 + ko[ks]), qf[ks], st[kb]);
+        }
+        if (mask) {                                                     // keys >= N contribute p = 0
+            const int k0 = t * 64;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi >= N) st[kb][r] = -INFINITY;
+        }
+    };
+    // maximum of a tile's S' (relative to the running maximum) over this lane's 32 keys and its partner half's; then, if some row's maximum moved by
+    // more than THR (or at the first tile), O, l, -m and the pending S' take the same shift -- before the tile's P exists
+    auto decide = [&](f32x16 (&st)[2], bool first) {
+        float mx = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[0][r]), st[0][r + 1]);
+        mx = fmaxf(mx, st[0][15]);
+        float mx2 = fmaxf(fmaxf(st[1][0], st[1][1]), st[1][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx2 = fmaxf(fmaxf(mx2, st[1][r]), st[1][r + 1]);
+        mx = fmaxf(mx, fmaxf(mx2, st[1][15]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (first || __any(mx > THR)) {
+            const float shift = first ? mx : fmaxf(mx, 0.f);
+            const float alpha = first ? 0.f : fast_exp2(-shift);
+            mrow += shift;
+            lsum *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ot[0][r] *= alpha; ot[1][r] *= alpha;
+                st[0][r] -= shift; st[1][r] -= shift;
+                negm[r] = -mrow;
+            }
+        }
+    };
+    // P = exp2(S'), this lane's share of the row sums, and the B operands of O^T += V^T P^T (register pairs (r, r + 1) -> one packed word)
+    auto soft = [&](const f32x16 (&st)[2], bf16x8 (&pf)[2][2]) {
+        float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 w;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const float p0 = fast_exp2(st[kb][8 * s2 + j]), p1 = fast_exp2(st[kb][8 * s2 + j + 1]);
+                    ls0 += p0; ls1 += p1;
+                    w[j >> 1] = cvt_pk_bf16(p0, p1);
+                }
+                pf[kb][s2] = *reinterpret_cast<const bf16x8*>(&w);
+            }
+        lsum += ls0 + ls1;
+    };
+    // O^T += V^T P^T of tile t: 16-key steps kk = 2 kb + s2; transposed reads from inline assembly (before the builtin the compiler waits
+    // vmcnt(0), i.e. for the LDS-DMA in flight -- gemm.hip)
+    auto pv_tile = [&](int t, const bf16x8 (&pf)[2][2]) {
+        const char* imgV = stage(t) + 8192;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x2 vlo[4], vhi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = 2 * half + (i >> 1), db = i & 1;
+                const char* pv = imgV + kk * 2048 + vo_[db];
+                vlo[i] = lds_read_tr_asm(pv);
+                vhi[i] = lds_read_tr_asm(pv + 1024);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0]), "+v"(vhi[0]), "+v"(vlo[1]), "+v"(vhi[1]), "+v"(vlo[2]), "+v"(vhi[2]), "+v"(vlo[3]), "+v"(vhi[3]) :: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = 2 * half + (i >> 1), db = i & 1;
+                const u32x4 w = {vlo[i][0], vlo[i][1], vhi[i][0], vhi[i][1]};
+                ot[db] = mfma32(*reinterpret_cast<const bf16x8*>(&w), pf[kk >> 1][kk & 1], ot[db]);
+            }
+        }
+    };
+
+    // One tile per iteration and barrier: S' (8 MFMAs) -> decision -> softmax arithmetic -> O^T += V^T P^T (8 MFMAs); the matrix and the vector phases of
+    // a wave do not overlap each other -- the 3-4 waves per SIMD (127 registers) do.  A software-pipelined form (S' of tile t + 1 beside the softmax
+    // arithmetic of tile t, three LDS stages) was built and measured SLOWER: 355 vs 305 us -- it needs 238 registers (two waves per SIMD), and forced
+    // to 168 it spills (2.7 ms).
+    dma(0);
+    for (int t = 0; t < nkv; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tile t has landed for this wave ...
+        __syncthreads();                                                // ... and for every wave; everyone is done reading tile t - 1's stage
+        if (t + 1 < nkv) dma(t + 1);
+        if (!active) continue;
+        f32x16 st[2];
+        bf16x8 pf[2][2];
+        s_tile(t, st, t + 1 == nkv && (N & 63) != 0);
+        decide(st, t == 0);
+        soft(st, pf);
+        pv_tile(t, pf);
+    }
+    if (q0 + r32 < N) {
+        float l = lsum + __shfl_xor(lsum, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + r32;
+        bf16* orow = o + ((int64_t)b * N + q) * D + h * 64 + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                store4(orow + 32 * db + 8 * rq, f32x4{ot[db][4 * rq], ot[db][4 * rq + 1], ot[db][4 * rq + 2], ot[db][4 * rq + 3]} * inv);
+        if (hi == 0) lse[((int64_t)b * H + h) * N + q] = (mrow + log2f(l)) * LN2;
+    } else if (active) {
+        (void)__shfl_xor(lsum, 32, 64);
+    }
+}
+
 // ======================================= backward dQ (bf16) ==============================================
 template <int QT, int NW>
 __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
@@ -815,7 +1012,10 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
         else if (cfg == 3) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 2, false>), FWD_GRID(64), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
         else if (cfg == 4) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, false>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
         else if (cfg == 5) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true, 4>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
-        else hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        else if (cfg == 6) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        else if (cfg == 7) hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<2>), FWD_GRID(64), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        // default (measured at B = 32, H = 12, N = 1568, same box): 32x32x16 kernel 302 us against 334-345 us for the 16x16x32 kernel (cfg 6)
+        else hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<4>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
 #undef FWD_GRID
     }
     else if (dtype == DEVIAS_F32) {

@@ -96,7 +96,7 @@ class GradSync:
         if view.device != p.device:
             raise RuntimeError("GradSync: a parameter moved to another device after the buckets were built; rebuild GradSync after model.to(device)")
         bi = self._where[p]
-        if self._launched[bi] and not self._accumulate:
+        if self._launched[bi] and not self._accumulate and (self.world > 1 or self.simulate):
             # a second backward before finish(): this gradient would be added into a bucket whose all-reduce is already in flight
             raise RuntimeError("GradSync: gradient arrived for a bucket that is already being reduced -- call finish() after every backward "
                                "(or set_accumulate(True) for all micro-batches but the last)")

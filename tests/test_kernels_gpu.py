@@ -215,6 +215,36 @@ def test_mhsa_bf16_online_softmax_rescale():
     assert rel(out.float(), ro) < 2e-2 and rel(lse, rl) < 1e-2
 
 
+@pytest.mark.parametrize("case", ["first_tile_far_below", "spike_mid", "slow_growth", "all_equal"])
+def test_mhsa_bf16_deferred_max_paths(case):
+    """the 32x32x16 forward kernel moves its running row maximum only when a tile's maximum exceeds it by more than THR = 6 (and at the first tile):
+    inputs that FORCE each path (MI355X guide, rule 26) against the fp32 reference -- a first tile far below the later ones (large upward shift,
+    alpha ~ 0), a spike in a middle tile (everything accumulated before is rescaled once), maxima creeping up by less than THR per tile (the deferred
+    path: probabilities above 1, no rescale), and identical keys (uniform attention)."""
+    o = ops()
+    B, N, H = 1, 448, 1                      # 7 key tiles of 64
+    g = torch.Generator().manual_seed(33)
+    qkv = (torch.randn(B * N, 3 * 64, generator=g) * 0.3)
+    q, k = qkv.view(N, 3, 64)[:, 0], qkv.view(N, 3, 64)[:, 1]
+    u = torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0)
+    if case == "first_tile_far_below":
+        q[:] = q * 0.1 + u * 6.0
+        k[:64] = k[:64] * 0.1 - u * 8.0          # scores ~ -6 in tile 0, ~ 0 later  (x scale 0.125 x log2e)
+    elif case == "spike_mid":
+        k[200] = q[17] * 60                       # one key dominates query 17 from tile 3 on
+    elif case == "slow_growth":
+        q[:] = q * 0.1 + u * 4.0
+        for t in range(7):
+            k[64 * t:64 * t + 64] = k[64 * t:64 * t + 64] * 0.05 + u * (1.5 * t)      # tile maxima rise by ~ 1 (log2 units) per tile: below THR
+    else:
+        k[:] = k[0]
+    qkv = qkv.bfloat16().to(DEV)
+    out, lse = o.mhsa_fwd(qkv, B, N, H, 0.125)
+    ro, rl = _attn_ref(qkv, B, N, H, 0.125)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert rel(out.float(), ro) < 2e-2 and rel(lse, rl) < 1e-2, (case, rel(out.float(), ro), rel(lse, rl))
+
+
 # ------------------------------------------------------------------------------------------ slot attention
 def _slot_ref(q, kv, B, S, N, h, dh, scale):
     inner = h * dh
