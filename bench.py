@@ -116,10 +116,10 @@ def dominant_kernel_probe(args, device):
              "flop_per_launch": fl, "avg_ms": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
              "algorithmic_bytes": (M * D + 4 * D * D + 2 * M * 4 * D) * es}
     if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
-        # HBM-side bytes per launch from the committed PMC passes of this same launch (profiles/r2_pmc: 2*FETCH_SIZE + WRITE_SIZE,
-        # the gfx950 FETCH_SIZE correction applied)
-        probe["traffic"] = 1.0804e9
-        probe["traffic_source"] = "profiles/r2_pmc/README.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        # HBM-side bytes per launch from the committed PMC passes of this same launch (profiles/r3_pmc: 2*FETCH_SIZE + WRITE_SIZE,
+        # the gfx950 FETCH_SIZE correction applied; round 2: 1080.4 MB)
+        probe["traffic"] = 1.1073e9
+        probe["traffic_source"] = "profiles/r3_pmc/README.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     return probe
 
 
@@ -269,8 +269,8 @@ def main():
                                (f" + persistent GEMM grids sized for {args.reserve_cus} fewer CUs (--reserve-cus)" if args.reserve_cus else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
-                   "kernels": "persistent 256x256 GEMM (forward + dgrad; stream-K schedule for fc2 / dfc1 / dqkv), two-kernel MFMA attention backward, folded slot cross-attention (K/V projections on the slot side); "
-                              "one library call per fused region and direction (csrc/regions.hip)"},
+                   "kernels": "persistent 256x256 GEMM (forward + dgrad; stream-K schedule for fc2 / dfc1 / dqkv), 32x32x16 MFMA attention forward, two-kernel MFMA attention backward, folded slot "
+                              "cross-attention (K/V projections on the slot side); one library call per fused region and direction (csrc/regions.hip)"},
         "host_enqueue_ms_per_step": host_idle[len(host_idle) // 2] * 1e3, "host_library_calls_per_step": lib_calls,
         "host_enqueue_method": "one step enqueued on an idle stream, median of 5, outside the timed region (python + fused-region library calls + HIP launches)",
         "host_enqueue_ms_per_step_back_to_back": host_enqueue / args.steps * 1e3,

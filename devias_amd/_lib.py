@@ -160,6 +160,7 @@ PROTOTYPES = {
     "devias_agg_block_workspace_bytes": (c_int64, [POINTER(AggArgs)]),
     "devias_agg_block_fwd": (c_int, [POINTER(AggArgs), _P, _P, POINTER(c_void_p), _P]),
     "devias_agg_block_bwd": (c_int, [POINTER(AggArgs), _P, _P, _P, _P, POINTER(AggGrads), _P, _L, _P]),
+    "devias_policy_gemm_cus": (c_int32, []),
     "devias_policy_small_m_split": (c_int32, [_I, _I, _I, _I]),
     "devias_policy_wgrad_split": (c_int32, [_I, _I, _I, _I]),
 }

@@ -1476,6 +1476,12 @@ GemmKnobs& knobs() {
 }
 }  // namespace
 
+// CUs the big-tile grids may count on: the device's, minus the reserve (option gemm_reserve_cus), in whole XCD rows
+extern "C" int32_t devias_policy_gemm_cus(void) {
+    const GemmKnobs& k = knobs();
+    return (k.ncu - k.reserve > 8 ? k.ncu - k.reserve : 8) & ~7;
+}
+
 int devias_gemm_set_option(const char* name, int value) {
     GemmKnobs& k = knobs();
     if (!strcmp(name, "gemm_epi")) k.epi_swap = value;
@@ -1590,7 +1596,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;
         const int ta = a->trans_a, tb = a->trans_b;
         const int nt = p.tiles_m * p.tiles_n;
-        const int gp = (kn.ncu - kn.reserve > 8 ? kn.ncu - kn.reserve : 8) & ~7;
+        const int gp = devias_policy_gemm_cus();
         // persistent form (more than one round of tiles, no split-K, bf16 output): measured per shape at M = 50176 (tools/gemm_block_shapes.py, same
         // box, one-tile-per-workgroup -> persistent): qkv 226 -> 204 us, fc1 278 -> 243, dfc2 + dGELU + colsum 415 -> 349, dfc2 plain 275 -> 248,
         // dproj 81 -> 72; the long-K dgrad shapes unchanged (dfc1 252, dqkv 192)

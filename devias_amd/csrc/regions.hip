@@ -29,9 +29,10 @@ int small_m_split(int M, int N, int K, int trans_a) {
 }
 int wgrad_split(int Nout, int Kin, int Mrows, int dtype) {      // C is [Nout, Kin], the reduction runs over Mrows
     const int bk = dtype == DEVIAS_BF16 ? 64 : 16;
+    const int cus = devias_policy_gemm_cus();                   // 256 on MI355X; fewer when CUs are reserved for a concurrent kernel (gemm_reserve_cus)
     int tiles, slots;
-    if (bk == 64 && Nout % 256 == 0 && Kin % 128 == 0) { tiles = (Nout / 256) * (Kin / 128); slots = 512; }
-    else { tiles = cdiv(Nout, 128) * cdiv(Kin, 128); slots = 768; }
+    if (bk == 64 && Nout % 256 == 0 && Kin % 128 == 0) { tiles = (Nout / 256) * (Kin / 128); slots = 2 * cus; }     // (tiles x splits) fills ONE round of the 256^2 kernel
+    else { tiles = cdiv(Nout, 128) * cdiv(Kin, 128); slots = 3 * cus; }
     if (tiles >= slots || Mrows < 8 * bk) return 1;
     int s = slots / tiles;
     if (Mrows / (4 * bk) < s) s = Mrows / (4 * bk);

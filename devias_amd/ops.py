@@ -91,16 +91,15 @@ def counters(reset: bool = False) -> dict:
     return out
 
 
-_WGRAD_SLOTS = int(__import__("os").environ.get("DEVIAS_WGRAD_SLOTS", "512"))     # A/B knob (tools/ab_bench.py)
-
-
 def auto_split_k(M: int, N: int, K: int, bk: int = 64) -> int:
-    """Split the long reduction of a weight-gradient GEMM so that (tiles x splits) is just under ONE full round of the kernel
-    that will run it: 512 slots for the bf16 256x128 kernel (256 CUs x 2 workgroups), 768 for the 128x128 kernel."""
+    """Split the long reduction of a weight-gradient GEMM so that (tiles x splits) is just under ONE full round of the kernel that will run it:
+    2 slots per CU for the bf16 256x256 kernel counted in 256x128 halves (512 on MI355X), 3 per CU for the 128x128 kernel (768); the CU count
+    is the library's (device CUs minus the option gemm_reserve_cus), the same number the fused regions use (csrc/regions.hip)."""
+    cus = _lib.load().devias_policy_gemm_cus()
     if bk == 64 and M % 256 == 0 and N % 128 == 0:
-        tiles, slots = (M // 256) * (N // 128), _WGRAD_SLOTS
+        tiles, slots = (M // 256) * (N // 128), 2 * cus
     else:
-        tiles, slots = ((M + 127) // 128) * ((N + 127) // 128), 768
+        tiles, slots = ((M + 127) // 128) * ((N + 127) // 128), 3 * cus
     if tiles >= slots or K < 8 * bk:
         return 1
     return max(1, min(slots // tiles, K // (4 * bk), 64))

@@ -434,6 +434,7 @@ int devias_agg_block_fwd(const devias_agg_args* a, const void* x, void* slots, f
 int devias_agg_block_bwd(const devias_agg_args* a, const void* x, const void* dslots, const float* dattn, void* dx, const devias_agg_grads* g,
                          void* scratch, int64_t scratch_bytes, void* stream);
 /* the automatic split-K choices the regions (and the Python host) make, for hosts that size workspaces themselves */
+int32_t devias_policy_gemm_cus(void);      /* CUs the big-tile GEMM grids and the weight-gradient split-K sizing count on: device CUs - gemm_reserve_cus, multiple of 8 */
 int32_t devias_policy_small_m_split(int32_t M, int32_t N, int32_t K, int32_t trans_a);
 int32_t devias_policy_wgrad_split(int32_t Nout, int32_t Kin, int32_t Mrows, int32_t dtype);
 
