@@ -10,6 +10,7 @@
 // The MFMA is issued as mfma(Bfrag, Afrag) so each lane ends up with 4 CONSECUTIVE output columns of one row
 // (8-byte bf16 / 16-byte f32 epilogue accesses, bias as one float4).
 #include "common.h"
+#include <utility>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -1239,6 +1240,403 @@ __global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
 
 
 // =====================================================================================================================
+// Four-wave form of the persistent 256 x 256 kernel (gemm256w_kernel): ONE wave per SIMD, 128 x 128 per wave, the 256 accumulator
+// registers of a wave in AGPRs (the register file is 512 per lane at this occupancy; the MFMA takes its C / D operand from either half).
+// Why (tools/gemm_mscan.py, profiles/r3h_*): per round of tiles the eight-wave kernel needs 26-27 us at K = 768 where the vendor library's
+// kernel of this shape (four waves of 128 x 128) needs 22-23.  Per K-tile a 128 x 128 wave tile reads 128 KiB of fragments from LDS instead
+// of 192 KiB, and with the whole tile's fragments of BOTH k-steps in registers half-way through the K-tile the stage it occupies is
+// free early: the LDS-DMA of K-tile g + 2 goes into the stage of K-tile g while g is still being multiplied (two K-tiles in flight on a
+// two-stage ring).  Per K-tile and wave: 128 MFMAs in 32 groups of 4 (one A row-tile x 4 B column-tiles), pinned order:
+//   groups  0.. 7   k-step 0, rows 0-3; the 16 fragment reads of k-step 1 ride along (2 per group)
+//   groups  8.. 9   k-step 0, row 4;  then lgkmcnt(0) + barrier #1: every wave holds all of K-tile g -> its stage may be overwritten
+//   groups 10..25   rest of k-step 0, k-step 1; the 16 LDS-DMA instructions of K-tile g + 2 ride along (1 per group)
+//   group  26       vmcnt(16) (everything older than those 16 has landed: K-tile g + 1) + barrier #2: K-tile g + 1 is visible
+//   groups 26..31   the 16 fragment reads of K-tile g + 1, k-step 0, ride along; lgkmcnt(0) at the end
+// The K-tile stream runs across tile boundaries as in gemm256p_kernel; results are bitwise those of the other 256 x 256 kernels (same
+// MFMA chain per output element: K-tiles in order, k-steps in order).
+// =====================================================================================================================
+enum { NTW = 256 };
+
+// the 256 accumulator registers of gemm256w_kernel, by literal name (see W_MM4)
+#define DEVIAS_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+template <int I> __device__ __forceinline__ void acc_zero1() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(I)); }
+template <int... I> __device__ __forceinline__ void acc_zero_seq(std::integer_sequence<int, I...>) { (acc_zero1<I>(), ...); }
+// every AGPR is claimed here once (the clobber list is what makes the kernel descriptor allocate them)
+__device__ __forceinline__ void acc_claim() {
+    asm volatile("" ::: DEVIAS_A10(), DEVIAS_A10(1), DEVIAS_A10(2), DEVIAS_A10(3), DEVIAS_A10(4), DEVIAS_A10(5), DEVIAS_A10(6), DEVIAS_A10(7), DEVIAS_A10(8), DEVIAS_A10(9),
+                 DEVIAS_A10(10), DEVIAS_A10(11), DEVIAS_A10(12), DEVIAS_A10(13), DEVIAS_A10(14), DEVIAS_A10(15), DEVIAS_A10(16), DEVIAS_A10(17), DEVIAS_A10(18), DEVIAS_A10(19),
+                 DEVIAS_A10(20), DEVIAS_A10(21), DEVIAS_A10(22), DEVIAS_A10(23), DEVIAS_A10(24), "a250", "a251", "a252", "a253", "a254", "a255");
+}
+__device__ __forceinline__ void acc_zero() { acc_zero_seq(std::make_integer_sequence<int, 256>{}); }
+template <int I> __device__ __forceinline__ float acc_read1() { float x; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(I)); return x; }
+template <typename F, int... N> __device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, N...>) { (f(std::integral_constant<int, N>{}), ...); }
+template <int COUNT, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_seq(f, std::make_integer_sequence<int, COUNT>{}); }
+
+// Epilogue of gemm256w_kernel: the wave's 128 x 128 tile in ONE pass of 32 pieces (column half h, row tile i, tile pair pr; 16 rows x 64 B per
+// store instruction), same arithmetic in the same order as epilogue_swap (acc + bias -> lane-group exchange -> GELU -> row scale -> + residual ->
+// bf16), so the results are bitwise those of the other kernels.  One wave per SIMD: nothing hides a wait, and vmcnt counts in issue order, so
+// every load is REQUESTED before the first store of the tile is issued (bias: 32 registers up front; the rows it reads: a ring of 16 pieces
+// refilled one piece per store, i.e. a wait never sits behind fewer than 16 stores) -- a load issued behind a burst of stores waits for the
+// burst to drain (measured: four quarter-tile passes, each starting with its bias load, cost 17 us per tile instead of 5).
+template <int SIDE>
+__device__ __forceinline__ void epilogue_w(const GemmP& p, int mrow0, int ncol0, int lane) {
+    const int lm = lane & 15, g = lane >> 4;
+    const uint32_t col2 = (uint32_t)(16 * (g & 1) + 8 * (g >> 1)) * 2;
+    const uint32_t vo_c = (uint32_t)lm * (uint32_t)p.ldc * 2 + col2, vo_x = (uint32_t)lm * (uint32_t)p.ld_aux * 2 + col2;
+    constexpr bool BIAS_ON = SIDE != 2, CS_ON = SIDE != 1;       // what the step never combines (host): bias with dGELU / dReLU, column sums with a residual
+    f32x4 bias4[BIAS_ON ? 8 : 1];
+    if constexpr (BIAS_ON) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bias4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float rs_lo = 1.f, rs_hi = 1.f;
+    int rs_edge = 0;
+    if (p.row_scale) {
+        const int r0 = mrow0 / p.rows_per_scale, rl = (p.M - 1) / p.rows_per_scale;
+        rs_lo = p.row_scale[r0]; rs_hi = p.row_scale[r0 < rl ? r0 + 1 : rl];
+        rs_edge = (r0 + 1) * p.rows_per_scale;
+    }
+    const bf16* side = reinterpret_cast<const bf16*>(SIDE == 1 ? p.res : p.aux_in);
+    const int side_ld = SIDE == 1 ? p.ldr : p.ld_aux;
+    bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
+    constexpr int PF = 16;
+    bf16x8 sbuf[SIDE != 0 ? PF : 1];
+    auto side_load = [&](int n) -> bf16x8 {       // piece n = 16 h + 2 i + pr
+        const int h = n >> 4, i = (n >> 1) & 7, pr = n & 1;
+        int m = mrow0 + i * 16 + lm;
+        if (SIDE == 1 && p.res_mod > 0) m %= p.res_mod;
+        return *reinterpret_cast<const bf16x8*>(side + (int64_t)m * side_ld + ncol0 + 64 * h + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1));
+    };
+    if constexpr (SIDE != 0) {
+#pragma unroll
+        for (int n = 0; n < PF; ++n) sbuf[n] = side_load(n);
+    }
+    float cs[CS_ON ? 4 : 1][8];                   // column sums of the stored values: [2 h + pr][8 columns of the lane]
+    if constexpr (CS_ON) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[c][e] = 0.f;
+    }
+    static_for<32>([&](auto nc) {
+        constexpr int n = decltype(nc)::value, h = n >> 4, i = (n >> 1) & 7, pr = n & 1;
+        constexpr int ra = 16 * (8 * h + i) + 8 * pr;       // tiles (h, i, 2 pr) and (h, i, 2 pr + 1): eight consecutive accumulator registers
+        const int m = mrow0 + i * 16 + lm;
+        bf16x8 side8 = sbuf[SIDE != 0 ? n % PF : 0];
+        if constexpr (SIDE != 0 && n + PF < 32) sbuf[n % PF] = side_load(n + PF);
+        f32x4 A = f32x4{acc_read1<ra>(), acc_read1<ra + 1>(), acc_read1<ra + 2>(), acc_read1<ra + 3>()};
+        f32x4 B = f32x4{acc_read1<ra + 4>(), acc_read1<ra + 5>(), acc_read1<ra + 6>(), acc_read1<ra + 7>()};
+        if constexpr (BIAS_ON) { A += bias4[4 * h + 2 * pr]; B += bias4[4 * h + 2 * pr + 1]; }
+        else { A += f32x4{0.f, 0.f, 0.f, 0.f}; B += f32x4{0.f, 0.f, 0.f, 0.f}; }      // the other kernels add a zero bias here: -0 -> +0, kept for bitwise equality
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(A[r]), __float_as_uint(B[r]), false, false);
+            v[r] = __uint_as_float(sw[0]);
+            v[4 + r] = __uint_as_float(sw[1]);
+        }
+        if constexpr (SIDE == 2) {
+            if (p.act == DEVIAS_ACT_DGELU) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 d = dgelu_fast2(f32x2{(float)side8[e], (float)side8[e + 1]});
+                    v[e] *= d[0]; v[e + 1] *= d[1];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)side8[e] > 0.f ? v[e] : 0.f;
+            }
+        } else if (p.act == DEVIAS_ACT_GELU) {
+            if (aux_out) {
+                bf16x8 pre = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+                store16_asm(aux_out + (int64_t)(mrow0 + i * 16) * p.ld_aux + ncol0 + 64 * h + 32 * pr, vo_x, *reinterpret_cast<const u32x4*>(&pre));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 y = gelu_fast2(f32x2{v[e], v[e + 1]});
+                v[e] = y[0]; v[e + 1] = y[1];
+            }
+        }
+        if (p.row_scale) {
+            const float rs = m >= rs_edge ? rs_hi : rs_lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= rs;
+        }
+        if constexpr (SIDE == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)side8[e];
+        }
+        if constexpr (CS_ON) {
+            if (p.colsum_part) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[2 * h + pr][e] += v[e];
+            }
+        }
+        bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        store16_asm(reinterpret_cast<const bf16*>(p.C) + (int64_t)(mrow0 + i * 16) * p.ldc + ncol0 + 64 * h + 32 * pr, vo_c, *reinterpret_cast<const u32x4*>(&o));
+    });
+    if constexpr (CS_ON) {
+        if (p.colsum_part) {
+            // the 16 lanes of a group (same g, rows lm = 0..15) own the same columns: fold them in a fixed order (as epilogue_swap does)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = cs[c][e];
+                    t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                    cs[c][e] = t;
+                }
+                if (lm == 0) {
+                    float* dst = p.colsum_part + (int64_t)(mrow0 / 128) * p.N + ncol0 + 64 * (c >> 1) + 16 * (2 * (c & 1) + (g & 1)) + 8 * (g >> 1);
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{cs[c][0], cs[c][1], cs[c][2], cs[c][3]};
+                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{cs[c][4], cs[c][5], cs[c][6], cs[c][7]};
+                }
+            }
+        }
+    }
+}
+
+template <bool TB>
+__device__ __forceinline__ void glds_w(const bf16* __restrict__ a_src, int lda, const bf16* __restrict__ b_src, int ldb, char* stage, int wave, int lane) {
+    const uint32_t vo_a = glds_voff_kc(lda, lane);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int r8 = wave * 64 + n * 8;
+        const char* ub = reinterpret_cast<const char*>(a_src + (int64_t)r8 * lda);
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo_a), (lds_void_ptr)(stage + r8 * 128), 16, 0, 0);
+    }
+    if constexpr (!TB) {
+        const uint32_t vo_b = glds_voff_kc(ldb, lane);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int r8 = wave * 64 + n * 8;
+            const char* ub = reinterpret_cast<const char*>(b_src + (int64_t)r8 * ldb);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo_b), (lds_void_ptr)(stage + 32768 + r8 * 128), 16, 0, 0);
+        }
+    } else {
+        // k-strided B ([K, N] row-major): wave w owns k rows [16 w, 16 w + 16), 2 k-rows x 512 B per instruction; (k >> 3) & 1 == n >> 2 & 1
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int k2 = wave * 16 + n * 2;
+            const uint32_t vo = glds_voff_ks(ldb, lane, (n >> 2) & 1, n & 1);
+            const char* ub = reinterpret_cast<const char*>(b_src + (int64_t)k2 * ldb);
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(ub + vo), (lds_void_ptr)(stage + 32768 + k2 * 512), 16, 0, 0);
+        }
+    }
+}
+
+// wait until at most N LDS operations of this wave are outstanding (they complete in issue order); the raw halves of the transposing reads are
+// operands so that nothing that reads them can be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void tr_fence_cnt(TrFrag (&f)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%c16)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo), "+v"(f[3].hi),
+                 "+v"(f[4].lo), "+v"(f[4].hi), "+v"(f[5].lo), "+v"(f[5].hi), "+v"(f[6].lo), "+v"(f[6].hi), "+v"(f[7].lo), "+v"(f[7].hi) : "i"(N) : "memory");
+}
+
+// per-wave constants of the LDS-DMA: one buffer descriptor per operand and K-tile (base = the K-tile's first element), one loop-invariant per-lane
+// offset per instruction form, one SCALAR offset per instruction -> an LDS-DMA instruction costs s_mov m0 + buffer_load ... lds and nothing else
+template <bool TB>
+struct WDma {
+    uint32_t vo_a, vo_b[TB ? 4 : 1];
+    int so_a[8], so_b[8];
+    __amdgpu_buffer_rsrc_t rs_a, rs_b;
+    __device__ __forceinline__ void set_src(const bf16* a_src, const bf16* b_src) {
+        rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a_src), 0, 0x7fffffff, 0x00020000);
+        rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(b_src), 0, 0x7fffffff, 0x00020000);
+    }
+    __device__ __forceinline__ void init(int lda, int ldb, int wave, int lane) {
+        vo_a = glds_voff_kc(lda, lane);
+        if constexpr (!TB) vo_b[0] = glds_voff_kc(ldb, lane);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) vo_b[c] = glds_voff_ks(ldb, lane, c >> 1, c & 1);
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            so_a[n] = (wave * 64 + n * 8) * lda * 2;
+            so_b[n] = TB ? (wave * 16 + n * 2) * ldb * 2 : (wave * 64 + n * 8) * ldb * 2;
+        }
+    }
+};
+
+// one K-tile; fa0 / fb0: fragments of k-step 0 of THIS K-tile on entry, of the NEXT one on exit.  TB: B is k-strided in memory ([K, N] row-major, the
+// dgrad layout): its LDS image is the k-strided one of the eight-wave kernels and a fragment is two transposing reads issued from inline asm (see
+// ds_read_tr_asm), complete only behind a fence.  ONE wave per SIMD: whatever is not an MFMA has to issue in the shadow of one (16 cycles), so every
+// MFMA is its own statement and at most one other operation sits between two of them.
+// `next_src(a, b)`: advances the kernel's load cursor and yields the source of the K-tile the NEXT call loads; it runs under the last MFMAs of this
+// one (the scalar address arithmetic of a K-tile costs ~25 instructions: at the loop head nothing would hide them).
+template <bool TB, typename NEXT>
+__device__ __forceinline__ void ktile_w(bf16x8 (&fa0)[8], bf16x8 (&fb0)[8], char* cur, const char* nxt, WDma<TB>& d, NEXT&& next_src,
+                                        int wave, int lane, int wm, int wn) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass does not know the buffer-load-to-LDS builtin)
+    const __amdgpu_buffer_rsrc_t rs_a = d.rs_a, rs_b = d.rs_b;
+    bf16x8 fa1[8], fb1[8];
+    TrFrag tb[TB ? 8 : 1];
+#define W_RA(F, buf, ks, i) F[i] = read_frag2<false>(buf, wm * 128 + (i) * 16, ks, lane);
+#define W_RB(F, T, buf, ks, j) { if constexpr (!TB) F[j] = read_frag2<false>((buf) + 32768, wn * 128 + (j) * 16, ks, lane); \
+                                 else T[j] = read_frag2a((buf) + 32768, wn * 128 + (j) * 16, ks, lane); }
+    // an MFMA on LITERAL accumulator registers: tile (h, i, jj) lives in a[16 (8 h + i) + 4 jj ...+3].  256 live accumulators fill the AGPR half
+    // exactly; as C++ values (builtin or "+a" operands) the register allocator shuffles them through scratch at every loop head.  Named literally they
+    // are invisible to it: the kernel must (and does: audited in the ISA, tests/test_build_cpu.py) use no AGPR of its own and spill nothing.  Hazards:
+    // the A / B operands are written by LDS reads only (waits: the compiler's for plain reads, tr_fence_cnt for the asm ones; no VALU writes them: audited);
+    // a D is next touched 64 MFMAs later, or by acc_read1() behind the kernel's s_nop pad
+#define W_M(i, h, jj, FB, FA) asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(FB[(h) * 4 + (jj)]), "v"(FA[i]), \
+                                           "i"(16 * (8 * (h) + (i)) + 4 * (jj)), "i"(16 * (8 * (h) + (i)) + 4 * (jj) + 3));
+#define W_SB __builtin_amdgcn_sched_barrier(0);
+#define W_DMA(n) { if constexpr ((n) < 8) \
+                       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void_ptr)(cur + (wave * 64 + (n) * 8) * 128), 16, d.vo_a, d.so_a[n], 0, 0); \
+                   else if constexpr (!TB) \
+                       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_ptr)(cur + 32768 + (wave * 64 + ((n) & 7) * 8) * 128), 16, d.vo_b[0], d.so_b[(n) & 7], 0, 0); \
+                   else \
+                       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_ptr)(cur + 32768 + (wave * 16 + ((n) & 7) * 2) * 512), 16, \
+                                                                d.vo_b[((((n) & 7) >> 2) & 1) * 2 + ((n) & 1)], d.so_b[(n) & 7], 0, 0); }
+    // group forms: 4 MFMAs of (row tile i, column half h) with nothing / one A read + one B read / one LDS-DMA instruction in between
+#define W_G(i, h, FB, FA) W_M(i, h, 0, FB, FA) W_M(i, h, 1, FB, FA) W_M(i, h, 2, FB, FA) W_M(i, h, 3, FB, FA) W_SB
+#define W_GR(i, h, FB, FA, RA_, RB_) W_M(i, h, 0, FB, FA) W_SB RA_ W_SB W_M(i, h, 1, FB, FA) W_M(i, h, 2, FB, FA) W_SB RB_ W_SB W_M(i, h, 3, FB, FA) W_SB
+#define W_GD(i, h, FB, FA, n) W_M(i, h, 0, FB, FA) W_SB W_DMA(n) W_SB W_M(i, h, 1, FB, FA) W_M(i, h, 2, FB, FA) W_M(i, h, 3, FB, FA) W_SB
+    W_SB
+    W_GR(0, 0, fb0, fa0, W_RA(fa1, cur, 1, 0), W_RB(fb1, tb, cur, 1, 0))
+    W_GR(0, 1, fb0, fa0, W_RA(fa1, cur, 1, 1), W_RB(fb1, tb, cur, 1, 1))
+    W_GR(1, 0, fb0, fa0, W_RA(fa1, cur, 1, 2), W_RB(fb1, tb, cur, 1, 2))
+    W_GR(1, 1, fb0, fa0, W_RA(fa1, cur, 1, 3), W_RB(fb1, tb, cur, 1, 3))
+    W_GR(2, 0, fb0, fa0, W_RA(fa1, cur, 1, 4), W_RB(fb1, tb, cur, 1, 4))
+    W_GR(2, 1, fb0, fa0, W_RA(fa1, cur, 1, 5), W_RB(fb1, tb, cur, 1, 5))
+    W_GR(3, 0, fb0, fa0, W_RA(fa1, cur, 1, 6), W_RB(fb1, tb, cur, 1, 6))
+    W_GR(3, 1, fb0, fa0, W_RA(fa1, cur, 1, 7), W_RB(fb1, tb, cur, 1, 7))
+    W_G(4, 0, fb0, fa0)
+    W_G(4, 1, fb0, fa0)
+    if constexpr (TB) { tr_fence_cnt<0>(tb); _Pragma("unroll") for (int j = 0; j < 8; ++j) fb1[j] = tr_assemble(tb[j]); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave holds all of the K-tile in registers ...
+    __builtin_amdgcn_s_barrier();                           // #1: ... and so does every other one: the stage may be overwritten
+    W_SB
+    W_GD(5, 0, fb0, fa0, 0)
+    W_GD(5, 1, fb0, fa0, 1)
+    W_GD(6, 0, fb0, fa0, 2)
+    W_GD(6, 1, fb0, fa0, 3)
+    W_GD(7, 0, fb0, fa0, 4)
+    W_GD(7, 1, fb0, fa0, 5)
+    W_GD(0, 0, fb1, fa1, 6)
+    W_GD(0, 1, fb1, fa1, 7)
+    W_GD(1, 0, fb1, fa1, 8)
+    W_GD(1, 1, fb1, fa1, 9)
+    W_GD(2, 0, fb1, fa1, 10)
+    W_GD(2, 1, fb1, fa1, 11)
+    W_GD(3, 0, fb1, fa1, 12)
+    W_GD(3, 1, fb1, fa1, 13)
+    W_GD(4, 0, fb1, fa1, 14)
+    W_GD(4, 1, fb1, fa1, 15)
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // everything older than this K-tile's 16 LDS-DMA instructions has landed: the next K-tile
+    __builtin_amdgcn_s_barrier();                           // #2: ... of every wave
+    W_SB
+    // the next K-tile's k-step 0 (TB: the asm reads of B first; the counted fence then leaves the 7 A reads issued behind them in flight); the last
+    // group carries no read, so that the loop head finds the fragments complete, and the cursor arithmetic for the next call instead
+    W_GR(5, 0, fb1, fa1, W_RB(fb0, tb, nxt, 0, 0) W_RB(fb0, tb, nxt, 0, 1), W_RB(fb0, tb, nxt, 0, 2) W_RB(fb0, tb, nxt, 0, 3))
+    W_GR(5, 1, fb1, fa1, W_RA(fa0, nxt, 0, 0), W_RB(fb0, tb, nxt, 0, 4) W_RB(fb0, tb, nxt, 0, 5))
+    W_GR(6, 0, fb1, fa1, W_RB(fb0, tb, nxt, 0, 6) W_RB(fb0, tb, nxt, 0, 7), W_RA(fa0, nxt, 0, 1) W_RA(fa0, nxt, 0, 2))
+    W_GR(6, 1, fb1, fa1, W_RA(fa0, nxt, 0, 3) W_RA(fa0, nxt, 0, 4), W_RA(fa0, nxt, 0, 5))
+    W_GR(7, 0, fb1, fa1, W_RA(fa0, nxt, 0, 6), W_RA(fa0, nxt, 0, 7))
+    const bf16 *a_next, *b_next;
+    W_GR(7, 1, fb1, fa1, next_src(a_next, b_next);, d.set_src(a_next, b_next);)
+    if constexpr (TB) { tr_fence_cnt<7>(tb); _Pragma("unroll") for (int j = 0; j < 8; ++j) fb0[j] = tr_assemble(tb[j]); }
+#undef W_RA
+#undef W_RB
+#undef W_M
+#undef W_SB
+#undef W_DMA
+#undef W_G
+#undef W_GR
+#undef W_GD
+#endif
+}
+
+template <bool TB, int SIDE>
+__global__ __launch_bounds__(NTW) void gemm256w_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / 64;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int cnt = q + (xcd < r ? 1 : 0);
+    int li = blockIdx.x >> 3;
+    if (li >= cnt) return;
+    auto coords = [&](int l, int& m0, int& n0) {
+        int tm, tn;
+        tile_coords(base + l, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        m0 = tm * T2; n0 = tn * T2;
+    };
+    int m0, n0;
+    coords(li, m0, n0);
+    // the load cursor runs two K-tiles ahead of the multiply cursor; past the last tile it stays on the last K-tile (harmless re-reads
+    // keep the per-iteration count of LDS-DMA instructions, which the counted vmcnt relies on, constant)
+    int ll = li, lkt = 0;
+    const bf16* a_base = A + (int64_t)m0 * p.lda;                                 // first element of the cursor's tile rows / columns
+    const bf16* b_base = TB ? B + n0 : B + (int64_t)n0 * p.ldb;
+    auto a_src = [&]() { return a_base + lkt * 64; };
+    auto b_src = [&]() { return TB ? b_base + (int64_t)(lkt * 64) * p.ldb : b_base + lkt * 64; };
+    auto advance = [&]() {
+        if (lkt + 1 < nk) { ++lkt; return; }
+        if (ll + stride < cnt) {
+            ll += stride; lkt = 0;
+            int tm0, tn0;
+            coords(ll, tm0, tn0);
+            a_base = A + (int64_t)tm0 * p.lda;
+            b_base = TB ? B + tn0 : B + (int64_t)tn0 * p.ldb;
+        }
+    };
+    glds_w<TB>(a_src(), p.lda, b_src(), p.ldb, smem, wave, lane);
+    advance();
+    glds_w<TB>(a_src(), p.lda, b_src(), p.ldb, smem + STAGE2, wave, lane);
+    advance();
+    acc_claim();
+    acc_zero();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // K-tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8 fa0[8], fb0[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa0[i] = read_frag2<false>(smem, wm * 128 + i * 16, 0, lane);
+    if constexpr (!TB) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fb0[j] = read_frag2<false>(smem + 32768, wn * 128 + j * 16, 0, lane);
+        plain_fence(fa0); plain_fence(fb0);
+    } else {
+        TrFrag tb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tb[j] = read_frag2a(smem + 32768, wn * 128 + j * 16, 0, lane);
+        plain_fence(fa0); tr_fence(tb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fb0[j] = tr_assemble(tb[j]);
+    }
+    int ln = li + stride;
+    bool has_next = ln < cnt;
+    WDma<TB> dma;
+    dma.init(p.lda, p.ldb, wave, lane);
+    dma.set_src(a_src(), b_src());
+    for (int g = 0, kt = 0;; ++g) {
+        char* cur = smem + (g & 1) * STAGE2;
+        const char* nxt = smem + ((g + 1) & 1) * STAGE2;
+        ktile_w<TB>(fa0, fb0, cur, nxt, dma, [&](const bf16*& an, const bf16*& bn) { advance(); an = a_src(); bn = b_src(); }, wave, lane, wm, wn);
+        if (++kt < nk) continue;
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results are not readable before their passes are through (asm MFMAs: nobody pads this)
+        epilogue_w<SIDE>(p, m0 + wm * 128, n0 + wn * 128, lane);
+        if (!has_next) break;
+        kt = 0;
+        li = ln; coords(li, m0, n0);
+        ln = li + stride;
+        has_next = ln < cnt;
+        acc_zero();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // trailing re-reads must land before the LDS is released
+}
+
+
+// =====================================================================================================================
 // 256 x 128 x 64 tile, 256 threads (4 waves as 2(M) x 2(N), 128 x 64 per wave), ONE 48 KiB LDS stage filled by LDS-DMA,
 // three workgroups per CU: load/compute overlap and -- the point -- epilogue/compute overlap come from the co-resident
 // workgroups (independent waves, independent vmcnt), not from an in-kernel software pipeline.
@@ -1446,6 +1844,7 @@ struct GemmKnobs {
     int sk_eff;        // "gemm_sk_eff"     DEVIAS_GEMM_SK_EFF   policy: tiles / (rounds * workgroups) below this many percent (default 80) ...
     int sk_mink;       // "gemm_sk_mink"    DEVIAS_GEMM_SK_MINK  ... and at least this many K-tiles per output tile (default 32)
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
+    int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       != 0: four-wave form of the persistent kernel (gemm256w_kernel) where it applies
     int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent / stream-K grids leave this many CUs free (default 0).  Their static tile
                        //                                        lists assume one resident workgroup per CU of the grid: with K CUs held by another kernel
                        //                                        (RCCL during backward at N > 1) the K workgroups that find no CU run AFTER the others --
@@ -1466,6 +1865,7 @@ GemmKnobs& knobs() {
         x.sk_mink = env_int("DEVIAS_GEMM_SK_MINK", 32);
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
         x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
+        x.w4 = env_int("DEVIAS_GEMM_W4", 0);
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -1493,6 +1893,7 @@ int devias_gemm_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_sk_eff")) k.sk_eff = value;
     else if (!strcmp(name, "gemm_sk_mink")) k.sk_mink = value;
     else if (!strcmp(name, "gemm_debug")) k.debug = value;
+    else if (!strcmp(name, "gemm_w4")) k.w4 = value;
     else if (!strcmp(name, "gemm_reserve_cus")) k.reserve = value < 0 ? 0 : value;
     else return 0;
     return 1;
@@ -1624,6 +2025,11 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
             dim3 grid(gp), block(NT2);
             PERS_LAUNCH(gemm256sk_kernel);
             devias_count(DEVIAS_CNT_GEMM_SK);
+        } else if (kn.persistent && kn.w4 && pers_ok && nt > gp && a->K >= 128 &&
+                   (a->act == DEVIAS_ACT_NONE || a->act == DEVIAS_ACT_GELU || a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU)) {
+            dim3 grid(gp), block(NTW);
+            PERS_LAUNCH(gemm256w_kernel);
+            devias_count(DEVIAS_CNT_GEMM256P);
         } else if (kn.persistent && pers_ok && nt > gp) {
             dim3 grid(gp), block(NT2);
             PERS_LAUNCH(gemm256p_kernel);
