@@ -1278,8 +1278,21 @@ template <int COUNT, typename F> __device__ __forceinline__ void static_for(F&& 
 // every load is REQUESTED before the first store of the tile is issued (bias: 32 registers up front; the rows it reads: a ring of 16 pieces
 // refilled one piece per store, i.e. a wait never sits behind fewer than 16 stores) -- a load issued behind a burst of stores waits for the
 // burst to drain (measured: four quarter-tile passes, each starting with its bias load, cost 17 us per tile instead of 5).
+// the rows the epilogue reads (residual / saved pre-activation), piece n = 16 h + 2 i + pr of the wave's 128 x 128 tile
 template <int SIDE>
-__device__ __forceinline__ void epilogue_w(const GemmP& p, int mrow0, int ncol0, int lane) {
+__device__ __forceinline__ bf16x8 side_load_w(const GemmP& p, int mrow0, int ncol0, int lane, int n) {
+    const int lm = lane & 15, g = lane >> 4;
+    const bf16* side = reinterpret_cast<const bf16*>(SIDE == 1 ? p.res : p.aux_in);
+    const int side_ld = SIDE == 1 ? p.ldr : p.ld_aux;
+    const int h = n >> 4, i = (n >> 1) & 7, pr = n & 1;
+    int m = mrow0 + i * 16 + lm;
+    if (SIDE == 1 && p.res_mod > 0) m %= p.res_mod;
+    return *reinterpret_cast<const bf16x8*>(side + (int64_t)m * side_ld + ncol0 + 64 * h + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1));
+}
+
+// sbuf: the first 16 pieces of those rows, requested by the kernel two K-tiles before the tile is done
+template <int SIDE>
+__device__ __forceinline__ void epilogue_w(const GemmP& p, int mrow0, int ncol0, int lane, bf16x8 (&sbuf)[SIDE != 0 ? 16 : 1]) {
     const int lm = lane & 15, g = lane >> 4;
     const uint32_t col2 = (uint32_t)(16 * (g & 1) + 8 * (g >> 1)) * 2;
     const uint32_t vo_c = (uint32_t)lm * (uint32_t)p.ldc * 2 + col2, vo_x = (uint32_t)lm * (uint32_t)p.ld_aux * 2 + col2;
@@ -1296,21 +1309,9 @@ __device__ __forceinline__ void epilogue_w(const GemmP& p, int mrow0, int ncol0,
         rs_lo = p.row_scale[r0]; rs_hi = p.row_scale[r0 < rl ? r0 + 1 : rl];
         rs_edge = (r0 + 1) * p.rows_per_scale;
     }
-    const bf16* side = reinterpret_cast<const bf16*>(SIDE == 1 ? p.res : p.aux_in);
-    const int side_ld = SIDE == 1 ? p.ldr : p.ld_aux;
     bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
     constexpr int PF = 16;
-    bf16x8 sbuf[SIDE != 0 ? PF : 1];
-    auto side_load = [&](int n) -> bf16x8 {       // piece n = 16 h + 2 i + pr
-        const int h = n >> 4, i = (n >> 1) & 7, pr = n & 1;
-        int m = mrow0 + i * 16 + lm;
-        if (SIDE == 1 && p.res_mod > 0) m %= p.res_mod;
-        return *reinterpret_cast<const bf16x8*>(side + (int64_t)m * side_ld + ncol0 + 64 * h + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1));
-    };
-    if constexpr (SIDE != 0) {
-#pragma unroll
-        for (int n = 0; n < PF; ++n) sbuf[n] = side_load(n);
-    }
+    auto side_load = [&](int n) -> bf16x8 { return side_load_w<SIDE>(p, mrow0, ncol0, lane, n); };
     float cs[CS_ON ? 4 : 1][8];                   // column sums of the stored values: [2 h + pr][8 columns of the lane]
     if constexpr (CS_ON) {
 #pragma unroll
@@ -1618,13 +1619,23 @@ __global__ __launch_bounds__(NTW) void gemm256w_kernel(GemmP p) {
     WDma<TB> dma;
     dma.init(p.lda, p.ldb, wave, lane);
     dma.set_src(a_src(), b_src());
+    bf16x8 sbuf[SIDE != 0 ? 16 : 1];
     for (int g = 0, kt = 0;; ++g) {
         char* cur = smem + (g & 1) * STAGE2;
         const char* nxt = smem + ((g + 1) & 1) * STAGE2;
-        ktile_w<TB>(fa0, fb0, cur, nxt, dma, [&](const bf16*& an, const bf16*& bn) { advance(); an = a_src(); bn = b_src(); }, wave, lane, wm, wn);
+        ktile_w<TB>(fa0, fb0, cur, nxt, dma, [&](const bf16*& an, const bf16*& bn) {
+            advance(); an = a_src(); bn = b_src();
+            if constexpr (SIDE != 0) {
+                // the rows the epilogue reads: requested behind this K-tile's counted wait, two K-tiles before the tile is done (a K-tile and a half to arrive)
+                if (kt == nk - 2) {
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) sbuf[n] = side_load_w<SIDE>(p, m0 + wm * 128, n0 + wn * 128, lane, n);
+                }
+            }
+        }, wave, lane, wm, wn);
         if (++kt < nk) continue;
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results are not readable before their passes are through (asm MFMAs: nobody pads this)
-        epilogue_w<SIDE>(p, m0 + wm * 128, n0 + wn * 128, lane);
+        epilogue_w<SIDE>(p, m0 + wm * 128, n0 + wn * 128, lane, sbuf);
         if (!has_next) break;
         kt = 0;
         li = ln; coords(li, m0, n0);
@@ -1844,7 +1855,8 @@ struct GemmKnobs {
     int sk_eff;        // "gemm_sk_eff"     DEVIAS_GEMM_SK_EFF   policy: tiles / (rounds * workgroups) below this many percent (default 80) ...
     int sk_mink;       // "gemm_sk_mink"    DEVIAS_GEMM_SK_MINK  ... and at least this many K-tiles per output tile (default 32)
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
-    int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       != 0: four-wave form of the persistent kernel (gemm256w_kernel) where it applies
+    int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
+                       //                                        15 = all four); a served call is not considered for stream-K
     int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent / stream-K grids leave this many CUs free (default 0).  Their static tile
                        //                                        lists assume one resident workgroup per CU of the grid: with K CUs held by another kernel
                        //                                        (RCCL during backward at N > 1) the K workgroups that find no CU run AFTER the others --
@@ -2015,7 +2027,17 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         // M = 50176 with tools/gemm_block_shapes.py) whole rounds would idle more than (100 - sk_eff) % of the chip while K is long enough to
         // amortise the hand-off (one 256 KiB partial written and read per workgroup, ~8 us): fc2 275 -> 263 us, dfc1 252 -> 239, dqkv 192 -> 183;
         // at K = 768 the same 588-tile grids lose (proj 92 -> 100, dproj 72 -> 80), and grids with < 10 % quantisation loss always lose
-        const bool sk_policy = kn.streamk >= 3 || ((int64_t)nt * 100 < (int64_t)cdiv(nt, gp) * gp * kn.sk_eff && a->K >= 64 * kn.sk_mink);
+        // gemm_w4 is a mask over the four instantiations: 1 = B k-contiguous, no side rows; 2 = B k-contiguous + residual; 4 = B k-strided, no side rows;
+        // 8 = B k-strided + saved pre-activation
+        // Default 0.  Timed alone (tools/exp/w4_check.py, 20 back-to-back launches per shape) every form wins: -5.6 % on the sum of the block's eight forward /
+        // dgrad GEMMs, qkv -11 %, fc1 -9 %, fc2 -8 %.  IN the step the gain is not there (tools/step_gemm_shapes.py on rocprofv3 traces of bench.py, one box:
+        // qkv -7 us, fc1 -6, fc2 -3..-10 per call; proj +11, dfc2 +12, and dfc1 +30 / dqkv +14 against the stream-K schedule they would replace; bench.py over
+        // three interleaved runs per mask: 53.33 / 53.47 / 53.22 ms per step for masks 0 / 3 / 31) -- the GEMM phases of the step run at the board's power limit
+        // (DESIGN.md 5, round 3), where a K loop with fewer stalls buys a lower clock, not a shorter time
+        const int w4_form = (tb ? 2 : 0) + (side != 0 ? 1 : 0);
+        const bool w4_ok = kn.persistent && ((kn.w4 >> w4_form) & 1) && pers_ok && nt > gp && a->K >= 128 &&
+                           (a->act == DEVIAS_ACT_NONE || a->act == DEVIAS_ACT_GELU || a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU);
+        const bool sk_policy = kn.streamk >= 3 || (!w4_ok && (int64_t)nt * 100 < (int64_t)cdiv(nt, gp) * gp * kn.sk_eff && a->K >= 64 * kn.sk_mink);
         if (pers_ok && kn.streamk && a->sk_ws && aligned16(a->sk_ws) && a->sk_ws_bytes >= devias_gemm_streamk_workspace_bytes() &&
             (nt >> 3) >= (gp >> 3) && nt % gp != 0 && sk_policy && ((nt >> 3) + 1) / (gp >> 3) + 4 <= SK_MAX_ITEMS) {
             static std::atomic<unsigned long long> epoch{((unsigned long long)time(nullptr) << 24) | 1ull};
@@ -2025,11 +2047,11 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
             dim3 grid(gp), block(NT2);
             PERS_LAUNCH(gemm256sk_kernel);
             devias_count(DEVIAS_CNT_GEMM_SK);
-        } else if (kn.persistent && kn.w4 && pers_ok && nt > gp && a->K >= 128 &&
-                   (a->act == DEVIAS_ACT_NONE || a->act == DEVIAS_ACT_GELU || a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU)) {
+        } else if (w4_ok) {
             dim3 grid(gp), block(NTW);
             PERS_LAUNCH(gemm256w_kernel);
             devias_count(DEVIAS_CNT_GEMM256P);
+            devias_count(DEVIAS_CNT_GEMM256W);
         } else if (kn.persistent && pers_ok && nt > gp) {
             dim3 grid(gp), block(NT2);
             PERS_LAUNCH(gemm256p_kernel);

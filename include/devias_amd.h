@@ -61,6 +61,8 @@ const char* devias_last_error(void);
 #define DEVIAS_CNT_MHSA_FWD_F32 8    /* VALU parity kernels */
 #define DEVIAS_CNT_MHSA_BWD_F32 9
 #define DEVIAS_CNT_GEMM_SK 11        /* 256x256 persistent kernel, stream-K schedule */
+#define DEVIAS_CNT_GEMM256W 12       /* 256x256 persistent kernel, four-wave form (one wave per SIMD, accumulators in AGPRs): the default persistent kernel;
+                                        every such launch also counts as DEVIAS_CNT_GEMM256P */
 #define DEVIAS_CNT_MHSA_BWD_FUSED 10 /* (retired with ABI 150: always 0) */
 #define DEVIAS_CNT_MAX 16
 int64_t devias_counter(int32_t id);          /* -1 for an unknown id */

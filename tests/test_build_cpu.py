@@ -1,0 +1,52 @@
+"""Audit of the compiled four-wave GEMM kernels (gemm256w_kernel, devias_amd/csrc/gemm.hip).  Their 256 accumulator registers are AGPRs named
+LITERALLY in inline asm: the compiler does not know they are live, so the kernels are correct only if the compiler itself touches no AGPR and
+spills nothing (a spill would go through the AGPR half or scratch).  This test compiles the device code with the production flags and checks
+exactly that in the ISA, for every instantiation.  CPU only: hipcc cross-compiles gfx950 without a GPU."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from devias_amd import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(900)
+def test_four_wave_gemm_kernels_own_their_accumulators():
+    src = os.path.join(ROOT, "devias_amd", "csrc", "gemm.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "gemm.s")
+        cmd = [build.HIPCC if hasattr(build, "HIPCC") else "/opt/rocm/bin/hipcc"] + list(build.FLAGS) + ["--cuda-device-only", "-S", src, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = open(out).read().split("\n")
+    found = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\S*gemm256w_kernel\S*):", l)
+        if not m:
+            continue
+        name = m.group(1)
+        found += 1
+        j = i
+        while "s_endpgm" not in lines[j]:
+            j += 1
+        inasm, compiler_agpr, scratch, mfma = False, [], 0, 0
+        for b in lines[i:j + 1]:
+            code = b.split(";")[0]
+            if "ASMSTART" in b:
+                inasm = True
+            elif "ASMEND" in b:
+                inasm = False
+            elif not inasm and re.search(r"v_accvgpr|\ba\[\d+:\d+\]|\ba\d+\b", code):
+                compiler_agpr.append(code.strip())
+            scratch += "scratch_" in code
+            mfma += "v_mfma" in code
+        assert not compiler_agpr, (name, compiler_agpr[:5])
+        assert scratch == 0, name
+        assert mfma == 128, (name, mfma)                                     # one K-tile of 128 x 128 per wave, nothing duplicated by the compiler
+        meta = "\n".join(x for x in lines if name in x and (".num_agpr" in x or ".private_seg_size" in x))
+        assert re.search(r"\.num_agpr, 256", meta) and re.search(r"\.private_seg_size, 0\b", meta), meta
+    assert found == 4          # <B k-contiguous | k-strided> x <rows the epilogue reads>

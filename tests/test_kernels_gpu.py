@@ -420,7 +420,7 @@ def gemm_options():
     """restores the process-wide kernel-selection options a test changes"""
     o = ops()
     yield o
-    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 1)):
+    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 1), ("gemm_w4", 0)):
         o.set_option(k, v)
 
 
@@ -435,8 +435,9 @@ def _persistent_serves(tb, epi):
 @pytest.mark.parametrize("M,N,K", [(256 * 70, 1024, 128), (256 * 300, 256, 320), (256 * 99, 768, 768), (256 * 131, 512, 64),
                                    (256 * 196, 768, 448), (256 * 196, 2304, 192)])
 def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
-    """gemm256p_kernel (persistent: K-tile stream across tile boundaries, asm-issued epilogue stores left in flight) and gemm256sk_kernel
-    (the same with the stream-K schedule: split tiles handed from one workgroup to the next as fp32 partials, the chain continued)
+    """gemm256p_kernel (persistent: K-tile stream across tile boundaries, asm-issued epilogue stores left in flight), gemm256w_kernel (its
+    four-wave form: one wave per SIMD, accumulators in literal AGPRs, two K-tiles of LDS-DMA in flight; the default) and gemm256sk_kernel
+    (the eight-wave kernel with the stream-K schedule: split tiles handed from one workgroup to the next as fp32 partials, the chain continued)
     against the fp32 op on the bf16-rounded inputs; the same call through the one-tile-per-workgroup kernel, with both epilogues,
     must agree BITWISE (same MFMA order, same fp32 epilogue arithmetic).  Tile counts are not multiples of the CU count (all-stream-K
     ranges and ranges with 1 and 5 data-parallel rounds), K covers one to twelve K-tiles, and the counters assert which kernel
@@ -465,9 +466,10 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         kw = dict(act=ACT_DGELU, aux_in=pre); ref = ref * dg
     outs = {}
     serves = _persistent_serves(tb, epi)
-    for mode in ("sk", "p", "0", "0s"):     # stream-K; persistent; one tile per workgroup with the register-transposed / the LDS-staged epilogue
+    for mode in ("sk", "p", "w", "0", "0s"):     # stream-K; persistent (eight / four waves); one tile per workgroup with the register-transposed / the LDS-staged epilogue
         o.set_option("gemm_streamk", 3 if mode == "sk" else 0)
-        o.set_option("gemm_persistent", 1 if mode in ("sk", "p") else 0)
+        o.set_option("gemm_persistent", 1 if mode in ("sk", "p", "w") else 0)
+        o.set_option("gemm_w4", 15 if mode == "w" else 0)
         o.set_option("gemm_epi", 0 if mode.endswith("s") else 1)
         kw2 = dict(kw)
         if epi == "gelu_aux":
@@ -478,21 +480,22 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         c = o.gemm(A, B, trans_b=tb, **kw2)
         torch.cuda.synchronize()
         cnt = o.counters()
-        want = {"sk": (1, 0, 0), "p": (0, 1, 0)}.get(mode if serves else "0", (0, 0, 1))
+        want = {"sk": (1, 0, 0), "p": (0, 1, 0), "w": (0, 1, 0)}.get(mode if serves else "0", (0, 0, 1))
         assert (cnt["gemm_sk"], cnt["gemm256p"], cnt["gemm256"]) == want, (mode, cnt)
+        assert cnt["gemm256w"] == (1 if mode == "w" and serves and K >= 128 else 0), (mode, cnt)       # (one K-tile: the eight-wave kernel)
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
     assert o.streamk_timeouts() == 0
     c, aux, cs = outs["0"]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]
-    for mode in ("sk", "p", "0s"):
+    for mode in ("sk", "p", "w", "0s"):
         assert torch.equal(c, outs[mode][0]), mode
     if aux is not None:
         assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16]
-        for mode in ("sk", "p", "0s"):
+        for mode in ("sk", "p", "w", "0s"):
             assert torch.equal(aux, outs[mode][1]), mode
     if cs is not None:
         assert rel(cs, c.float().sum(0)) < 1e-2                 # sums the fp32 values before bf16 rounding
-        for mode in ("sk", "p", "0s"):
+        for mode in ("sk", "p", "w", "0s"):
             assert rel(cs, outs[mode][2]) < 1e-5, mode
 
 
@@ -521,20 +524,21 @@ def test_gemm_persistent_kernels_repeatable(gemm_options):
     ref = run()
     junk = torch.empty(64 << 20, device=DEV)
     side = torch.cuda.Stream()
-    for sk in (0, 3):
+    for sk, w4 in ((0, 0), (0, 15), (3, 0)):
         o.set_option("gemm_persistent", 1)
         o.set_option("gemm_streamk", sk)                  # 3: stream-K whatever the quantisation loss
+        o.set_option("gemm_w4", w4)
         o.counters(reset=True)
         for it in range(30):
             with torch.cuda.stream(side):
                 junk.add_(1.0)                            # uneven memory load next to the GEMMs
             got = run()
             for a, b in zip(got[:5], ref[:5]):
-                assert torch.equal(a, b), (sk, it)
+                assert torch.equal(a, b), (sk, w4, it)
             assert rel(got[5], ref[5]) < 1e-5
         torch.cuda.synchronize()
         cnt = o.counters()
-        assert (cnt["gemm_sk"], cnt["gemm256p"]) == ((120, 0) if sk else (0, 120)), cnt
+        assert (cnt["gemm_sk"], cnt["gemm256p"], cnt["gemm256w"]) == ((120, 0, 0) if sk else (0, 120, 120 if w4 else 0)), cnt
     assert o.streamk_timeouts() == 0
 
 

@@ -136,7 +136,7 @@ def test_bf16_full_size_step_properties():
     cnt = ops.counters()
     # M = 50176: the four forward and four dgrad GEMMs of a block run persistent, three of them (fc2, dfc1, dqkv: 588 tiles, K >= 2304) with the
     # stream-K schedule; the four wgrads split K on the one-tile-per-workgroup kernel
-    assert cnt["gemm256p"] >= 12 * 5 and cnt["gemm_sk"] == 12 * 3 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_bwd_bf16"] == 12 and cnt["gemm128_f32"] == 0, cnt
+    assert cnt["gemm256p"] >= 12 * 5 and cnt["gemm_sk"] == 12 * 3 and cnt["gemm256w"] == 0 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_bwd_bf16"] == 12 and cnt["gemm128_f32"] == 0, cnt
     assert ops.streamk_timeouts() == 0
     sh1 = out1[2][0].detach().clone()
     out2, t2, g2 = step(model, x, y, tl, fg)

@@ -23,7 +23,7 @@ for name, N, K, epi, tb in (("qkv bias", 2304, 768, "bias", 0), ("proj bias+res"
     rs = (torch.rand(M // 1568, device=dev) > 0.3).float() / 0.7 if epi == "res_rs" else None
     outs, ts = [], []
     for w4 in (0, 1):
-        o.set_option("gemm_w4", w4)
+        o.set_option("gemm_w4", 15 if w4 else 0)
         o.set_option("gemm_streamk", 1 if sk else 0)
         out = torch.full((M, N), float("nan"), device=dev, dtype=bf)
         aux = torch.full((M, N), float("nan"), device=dev, dtype=bf) if epi == "gelu" else None
