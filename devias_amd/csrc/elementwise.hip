@@ -55,7 +55,8 @@ __global__ void im2col_kernel(const S* __restrict__ x, D* __restrict__ out, int 
 // partial[rb][n]; stage 2: out[n] = beta*out[n] + sum_rb partial (fixed order).
 enum { CS_ROWS = 256, CS_COLS = 256 };
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int M, int N, int ldx, float* __restrict__ part, int vec) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int M, int N, int ldx, float* __restrict__ part, int vec,
+                                                             float* __restrict__ out, float beta) {
     __shared__ float sm[8][CS_COLS + 8];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n0 = blockIdx.x * CS_COLS + tx * 8;
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += sm[k][c];
-        part[(int64_t)blockIdx.y * N + n] = t;
+        if (out) out[n] = t + (beta != 0.f ? beta * out[n] : 0.f);      // a single row block (M <= CS_ROWS): the result itself, no second stage
+        else part[(int64_t)blockIdx.y * N + n] = t;
     }
 }
 // block (64 columns, 16 partial lanes)
@@ -306,9 +308,11 @@ extern "C" int devias_colsum(const void* x, int32_t dtype, int32_t M, int32_t N,
     int nparts = cdiv(M, CS_ROWS);
     dim3 g(cdiv(N, CS_COLS), nparts), b(256);
     int vec = (ldx % 8 == 0) && aligned16(x);
-    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), g, b, 0, st, (const bf16*)x, M, N, ldx, ws, vec);
-    else hipLaunchKernelGGL((colsum_partial_kernel<float>), g, b, 0, st, (const float*)x, M, N, ldx, ws, vec);
+    float* direct = nparts == 1 ? out : nullptr;
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16>), g, b, 0, st, (const bf16*)x, M, N, ldx, ws, vec, direct, beta);
+    else hipLaunchKernelGGL((colsum_partial_kernel<float>), g, b, 0, st, (const float*)x, M, N, ldx, ws, vec, direct, beta);
     DEVIAS_CHECK_LAUNCH("devias_colsum(partial)");
+    if (direct) return DEVIAS_OK;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64, 16), 0, st, ws, nparts, N, out, beta);
     DEVIAS_CHECK_LAUNCH("devias_colsum(final)");
     return DEVIAS_OK;

@@ -68,7 +68,8 @@ template <typename T, int NIT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
-                                                     T* __restrict__ dx, float* __restrict__ part, int M, int D) {
+                                                     T* __restrict__ dx, float* __restrict__ part, int M, int D,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum, float beta_acc) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [3 waves][3][NIT*256]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 g[NIT], dg[NIT], db[NIT], dc[NIT];     // dc: column sums of the stored dx
@@ -168,6 +169,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     b += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 3 * W + W + c);
                     cc += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 3 * W + 2 * W + c);
                 }
+                if (dgamma) {      // a single workgroup (M <= LNB_ROWS): these ARE the results -- no reduce pass (same values: the pass adds zeros to them)
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(dgamma + c) = a + (beta_acc != 0.f ? beta_acc * *reinterpret_cast<const f32x4*>(dgamma + c) : z);
+                    *reinterpret_cast<f32x4*>(dbeta + c) = b + (beta_acc != 0.f ? beta_acc * *reinterpret_cast<const f32x4*>(dbeta + c) : z);
+                    if (dxsum) *reinterpret_cast<f32x4*>(dxsum + c) = cc + z;
+                    continue;
+                }
                 *reinterpret_cast<f32x4*>(out + c) = a;
                 *reinterpret_cast<f32x4*>(out + D + c) = b;
                 *reinterpret_cast<f32x4*>(out + 2 * D + c) = cc;
@@ -209,10 +217,11 @@ int ln_fwd_dispatch(const T* x, const float* g, const float* b, T* y, float* mea
 }
 template <typename T>
 int ln_bwd_dispatch(const T* dy, const T* x, const float* g, const float* mean, const float* rstd, const T* dres, T* dx,
-                    float* part, int M, int D, hipStream_t st) {
+                    float* part, int M, int D, float* dgamma, float* dbeta, float* dxsum, float beta_acc, hipStream_t st) {
     dim3 grid(cdiv(M, LNB_ROWS)), block(256);
     int nit = cdiv(D, 256);
-#define LNB(N) hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 3 * 3 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D)
+#define LNB(N) hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 3 * 3 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D, \
+                                  dgamma, dbeta, dxsum, beta_acc)
     if (nit <= 2) LNB(2); else if (nit <= 3) LNB(3); else if (nit <= 4) LNB(4); else LNB(8);
 #undef LNB
     return 0;
@@ -245,13 +254,16 @@ extern "C" int devias_layernorm_bwd(const void* dy, const void* x, const float* 
     DEVIAS_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "devias_layernorm_bwd: need D %% 4 == 0 and D <= 2048 (D=%d)", D);
     DEVIAS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dres || aligned16(dres)) && aligned16(ws),
                    "devias_layernorm_bwd: unaligned pointer");
+    const int nparts = cdiv(M, LNB_ROWS);
+    const bool direct = nparts == 1 && aligned16(dgamma) && aligned16(dbeta) && (!dx_colsum || aligned16(dx_colsum));   // one workgroup: it writes the results itself
+    float *dg_k = direct ? dgamma : nullptr, *db_k = direct ? dbeta : nullptr, *ds_k = direct ? dx_colsum : nullptr;
     if (dtype == DEVIAS_BF16)
-        ln_bwd_dispatch<bf16>((const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, ws, M, D, st);
+        ln_bwd_dispatch<bf16>((const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, ws, M, D, dg_k, db_k, ds_k, beta_acc, st);
     else if (dtype == DEVIAS_F32)
-        ln_bwd_dispatch<float>((const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, ws, M, D, st);
+        ln_bwd_dispatch<float>((const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, ws, M, D, dg_k, db_k, ds_k, beta_acc, st);
     else return devias_set_error(DEVIAS_EINVAL, "devias_layernorm_bwd: bad dtype %d", dtype);
     DEVIAS_CHECK_LAUNCH("devias_layernorm_bwd");
-    int nparts = cdiv(M, LNB_ROWS);
+    if (direct) return DEVIAS_OK;
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(3 * D, 64)), dim3(64, 16), 0, st, ws, nparts, D, dgamma, dbeta, dx_colsum, beta_acc);
     DEVIAS_CHECK_LAUNCH("devias_layernorm_bwd(param reduce)");
     return DEVIAS_OK;
