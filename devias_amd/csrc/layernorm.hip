@@ -7,10 +7,10 @@
 
 namespace {
 
-#ifndef DEVIAS_LNB_ROWS
-#define DEVIAS_LNB_ROWS 128       /* 64 -> 128 rows: 88.7 -> 86.5 us per call at M = 50176 (half the partial rows for the parameter reduce) */
-#endif
-enum { LN_WAVES = 4, LN_MAXIT = 16, LNB_ROWS = DEVIAS_LNB_ROWS };   // backward: rows per workgroup (a quarter per wave)
+// backward: ONE workgroup of 16 waves per CU, the rows divided evenly over the workgroups (M = 50176, D = 768, with the residual add and the dx column sums,
+// tools/exp/ln_ab.py: 392 workgroups of 4 waves x 128 rows 85.5 us; 8 or 16 waves at 128 rows 85.6 / 82.2; 512 workgroups x 98 rows 77-78; 256 workgroups of 16
+// waves x 196 rows 63.5 us = 4.9 TB/s -- it is the even spread over the CUs that counts, and fewer partial rows for the parameter reduce)
+enum { LN_WAVES = 4, LN_MAXIT = 16, LNB_MIN_ROWS = 32, LNB_ONE_WG_ROWS = 256 };
 
 template <typename T, int NIT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -62,15 +62,15 @@ template <> struct Raw4<bf16> { typedef bf16x4 type; };
 __device__ __forceinline__ f32x4 raw_to_f32(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 raw_to_f32(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
-// backward: workgroup = 4 waves, each wave walks LNB_ROWS/4 rows; lane-owned columns are fixed so the
-// dgamma/dbeta partial sums live in registers and are combined across the 4 waves through LDS at the end.
-template <typename T, int NIT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// backward: workgroup = NW waves, each wave walks every NW-th row of the workgroup's rows; lane-owned columns are fixed so the
+// dgamma/dbeta partial sums live in registers and are combined across the waves through LDS at the end.
+template <typename T, int NIT, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
-                                                     T* __restrict__ dx, float* __restrict__ part, int M, int D,
+                                                     T* __restrict__ dx, float* __restrict__ part, int M, int D, int rows,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum, float beta_acc) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [3 waves][3][NIT*256]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [NW / 2 waves][3][NIT*256]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 g[NIT], dg[NIT], db[NIT], dc[NIT];     // dc: column sums of the stored dx
 #pragma unroll
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         db[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         dc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int r0 = blockIdx.x * LNB_ROWS;
+    const int r0 = blockIdx.x * rows;
     // software pipeline over rows: the (packed) loads of row r+4 are issued before the reductions of row r, so each wave keeps
     // two rows of dy / x / dres in flight (the kernel is latency-bound otherwise: one dependent HBM round trip per row)
     typedef typename Raw4<T>::type raw4;
@@ -100,14 +100,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         nmu = mean[row]; nrs = rstd[row];
     };
     if (r0 + wave < M) issue(r0 + wave);
-    for (int rr = wave; rr < LNB_ROWS; rr += LN_WAVES) {
+    for (int rr = wave; rr < rows; rr += NW) {
         const int row = r0 + rr;
         if (row >= M) break;
         raw4 cd[NIT], cx[NIT], cr[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) { cd[it] = nd[it]; cx[it] = nx[it]; cr[it] = nr[it]; }
         const float mu = nmu, rs = nrs;
-        if (rr + LN_WAVES < LNB_ROWS && row + LN_WAVES < M) issue(row + LN_WAVES);
+        if (rr + NW < rows && row + NW < M) issue(row + NW);
         f32x4 a[NIT], xh[NIT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -143,33 +143,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             }
         }
     }
-    // combine the 4 waves' partials -> part[blockIdx][3][D]
+    // combine the waves' partials in a fixed tree (waves [h, 2h) hand theirs to waves [0, h) through LDS, h = NW/2 ... 1) -> part[blockIdx][3][D]
     const int W = NIT * 256;
-    if (wave > 0) {
-        float* dst = sm + (size_t)(wave - 1) * 3 * W;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            int c = (it * 64 + lane) * 4;
-            *reinterpret_cast<f32x4*>(dst + c) = dg[it];
-            *reinterpret_cast<f32x4*>(dst + W + c) = db[it];
-            *reinterpret_cast<f32x4*>(dst + 2 * W + c) = dc[it];
+    for (int h = NW / 2; h >= 1; h >>= 1) {
+        if (wave >= h && wave < 2 * h) {
+            float* dst = sm + (size_t)(wave - h) * 3 * W;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                int c = (it * 64 + lane) * 4;
+                *reinterpret_cast<f32x4*>(dst + c) = dg[it];
+                *reinterpret_cast<f32x4*>(dst + W + c) = db[it];
+                *reinterpret_cast<f32x4*>(dst + 2 * W + c) = dc[it];
+            }
         }
+        __syncthreads();
+        if (wave < h) {
+            const float* src = sm + (size_t)wave * 3 * W;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                int c = (it * 64 + lane) * 4;
+                dg[it] += *reinterpret_cast<const f32x4*>(src + c);
+                db[it] += *reinterpret_cast<const f32x4*>(src + W + c);
+                dc[it] += *reinterpret_cast<const f32x4*>(src + 2 * W + c);
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (wave == 0) {
         float* out = part + (int64_t)blockIdx.x * 3 * D;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int c = (it * 64 + lane) * 4;
             if (c < D) {
-                f32x4 a = dg[it], b = db[it], cc = dc[it];
-#pragma unroll
-                for (int w = 0; w < 3; ++w) {
-                    a += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 3 * W + c);
-                    b += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 3 * W + W + c);
-                    cc += *reinterpret_cast<const f32x4*>(sm + (size_t)w * 3 * W + 2 * W + c);
-                }
-                if (dgamma) {      // a single workgroup (M <= LNB_ROWS): these ARE the results -- no reduce pass (same values: the pass adds zeros to them)
+                const f32x4 a = dg[it], b = db[it], cc = dc[it];
+                if (dgamma) {      // a single workgroup: these ARE the results -- no reduce pass (same values: the pass adds zeros to them)
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(dgamma + c) = a + (beta_acc != 0.f ? beta_acc * *reinterpret_cast<const f32x4*>(dgamma + c) : z);
                     *reinterpret_cast<f32x4*>(dbeta + c) = b + (beta_acc != 0.f ? beta_acc * *reinterpret_cast<const f32x4*>(dbeta + c) : z);
@@ -215,14 +223,28 @@ int ln_fwd_dispatch(const T* x, const float* g, const float* b, T* y, float* mea
 #undef LNF
     return 0;
 }
+// workgroups and rows per workgroup of the backward kernel: up to LNB_ONE_WG_ROWS rows one workgroup (which then writes the parameter gradients itself),
+// otherwise the rows spread evenly over at most one workgroup per CU
+int ln_ncu() {
+    static int n = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
+    return n;
+}
+void ln_bwd_shape(int M, int& nwg, int& rows) {
+    nwg = M <= LNB_ONE_WG_ROWS ? 1 : (cdiv(M, LNB_MIN_ROWS) < ln_ncu() ? cdiv(M, LNB_MIN_ROWS) : ln_ncu());
+    rows = cdiv(M, nwg);
+    nwg = cdiv(M, rows);
+}
+
 template <typename T>
 int ln_bwd_dispatch(const T* dy, const T* x, const float* g, const float* mean, const float* rstd, const T* dres, T* dx,
                     float* part, int M, int D, float* dgamma, float* dbeta, float* dxsum, float beta_acc, hipStream_t st) {
-    dim3 grid(cdiv(M, LNB_ROWS)), block(256);
+    int nwg, rows;
+    ln_bwd_shape(M, nwg, rows);
     int nit = cdiv(D, 256);
-#define LNB(N) hipLaunchKernelGGL((ln_bwd_kernel<T, N>), grid, block, 3 * 3 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D, \
-                                  dgamma, dbeta, dxsum, beta_acc)
-    if (nit <= 2) LNB(2); else if (nit <= 3) LNB(3); else if (nit <= 4) LNB(4); else LNB(8);
+    // waves per workgroup: 16 while the combine tree's LDS (NW / 2 x 3 x NIT x 1 KiB) fits, 8 for the widest rows
+#define LNB(N, NW) hipLaunchKernelGGL((ln_bwd_kernel<T, N, NW>), dim3(nwg), dim3(NW * 64), (NW / 2) * 3 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D, rows, \
+                                      dgamma, dbeta, dxsum, beta_acc)
+    if (nit <= 2) LNB(2, 16); else if (nit <= 3) LNB(3, 16); else if (nit <= 4) LNB(4, 16); else LNB(8, 8);
 #undef LNB
     return 0;
 }
@@ -243,7 +265,9 @@ extern "C" int devias_layernorm_fwd(const void* x, const float* gamma, const flo
 }
 
 extern "C" int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
-    return (int64_t)cdiv(M, LNB_ROWS) * 3 * D * 4;
+    int nwg, rows;
+    ln_bwd_shape(M, nwg, rows);
+    return (int64_t)nwg * 3 * D * 4;
 }
 
 extern "C" int devias_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
@@ -254,7 +278,8 @@ extern "C" int devias_layernorm_bwd(const void* dy, const void* x, const float* 
     DEVIAS_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "devias_layernorm_bwd: need D %% 4 == 0 and D <= 2048 (D=%d)", D);
     DEVIAS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dres || aligned16(dres)) && aligned16(ws),
                    "devias_layernorm_bwd: unaligned pointer");
-    const int nparts = cdiv(M, LNB_ROWS);
+    int nparts, rows_per_wg;
+    ln_bwd_shape(M, nparts, rows_per_wg);
     const bool direct = nparts == 1 && aligned16(dgamma) && aligned16(dbeta) && (!dx_colsum || aligned16(dx_colsum));   // one workgroup: it writes the results itself
     float *dg_k = direct ? dgamma : nullptr, *db_k = direct ? dbeta : nullptr, *ds_k = direct ? dx_colsum : nullptr;
     if (dtype == DEVIAS_BF16)

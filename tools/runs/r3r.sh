@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 3, call r: LayerNorm backward as one 16-wave workgroup per CU: tests, kernel timing, bench
+mkdir -p gpurun_out/r3r
+python3 tools/exp/ln_ab.py 2>&1 | tail -1
+timeout 1500 python3 -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "layernorm or ln_" > gpurun_out/r3r/tests_ln.log 2>&1; tail -2 gpurun_out/r3r/tests_ln.log
+timeout 2400 python3 -m pytest tests/test_regions_gpu.py tests/test_parity_gpu.py tests/test_recipe_gpu.py tests/test_measured_path_gpu.py -x -q -m gpu > gpurun_out/r3r/tests_path.log 2>&1; tail -2 gpurun_out/r3r/tests_path.log
+for i in 1 2; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-full-step 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); print(round(d['value'],1), round(d['ms_per_step'],3))"; done
