@@ -10,57 +10,86 @@ namespace {
 // backward: ONE workgroup of 16 waves per CU, the rows divided evenly over the workgroups (M = 50176, D = 768, with the residual add and the dx column sums,
 // tools/exp/ln_ab.py: 392 workgroups of 4 waves x 128 rows 85.5 us; 8 or 16 waves at 128 rows 85.6 / 82.2; 512 workgroups x 98 rows 77-78; 256 workgroups of 16
 // waves x 196 rows 63.5 us = 4.9 TB/s -- it is the even spread over the CUs that counts, and fewer partial rows for the parameter reduce)
-enum { LN_WAVES = 4, LN_MAXIT = 16, LNB_MIN_ROWS = 32, LNB_ONE_WG_ROWS = 256 };
-
-template <typename T, int NIT>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, T* __restrict__ y,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
-                                                     float eps) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * LN_WAVES + wave;
-    if (row >= M) return;
-    const T* xr = x + (int64_t)row * D;
-    f32x4 v[NIT];
-    float s = 0.f;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        int c = (it * 64 + lane) * 4;
-        if (c < D) { v[it] = load4(xr + c); s += v[it][0] + v[it][1] + v[it][2] + v[it][3]; }
-        else v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const float mu = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        int c = (it * 64 + lane) * 4;
-        if (c < D) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { float d = v[it][j] - mu; q += d * d; }
-        }
-    }
-    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
-    T* yr = y + (int64_t)row * D;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        int c = (it * 64 + lane) * 4;
-        if (c < D) {
-            f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-            f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (v[it][j] - mu) * rs * g[j] + b[j];
-            store4(yr + c, o);
-        }
-    }
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#ifndef DEVIAS_LNF_WGS_PER_CU
+#define DEVIAS_LNF_WGS_PER_CU 8
+#endif
+enum { LN_WAVES = 4, LN_MAXIT = 16, LNB_MIN_ROWS = 32, LNB_ONE_WG_ROWS = 256, LNF_WGS_PER_CU = DEVIAS_LNF_WGS_PER_CU };
+int ln_ncu() {
+    static int n = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
+    return n;
 }
+
 
 template <typename T> struct Raw4;
 template <> struct Raw4<float> { typedef f32x4 type; };
 template <> struct Raw4<bf16> { typedef bf16x4 type; };
 __device__ __forceinline__ f32x4 raw_to_f32(f32x4 v) { return v; }
 __device__ __forceinline__ f32x4 raw_to_f32(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+
+// forward: every wave walks rows (row = first + k * stride) with the next row's loads in flight while it reduces the current one; gamma / beta stay in registers
+template <typename T, int NIT>
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int stride = gridDim.x * LN_WAVES;
+    int row = blockIdx.x * LN_WAVES + wave;
+    if (row >= M) return;
+    typedef typename Raw4<T>::type raw4;
+    f32x4 g[NIT], b[NIT];
+    raw4 nx[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int c = (it * 64 + lane) * 4;
+        if (c < D) {
+            g[it] = *reinterpret_cast<const f32x4*>(gamma + c);
+            b[it] = *reinterpret_cast<const f32x4*>(beta + c);
+            nx[it] = *reinterpret_cast<const raw4*>(x + (int64_t)row * D + c);
+        }
+    }
+    for (; row < M; row += stride) {
+        f32x4 v[NIT];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = (it * 64 + lane) * 4;
+            if (c < D) { v[it] = raw_to_f32(nx[it]); s += v[it][0] + v[it][1] + v[it][2] + v[it][3]; }
+            else v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (row + stride < M) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                int c = (it * 64 + lane) * 4;
+                if (c < D) nx[it] = *reinterpret_cast<const raw4*>(x + (int64_t)(row + stride) * D + c);
+            }
+        }
+        const float mu = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = (it * 64 + lane) * 4;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { float d = v[it][j] - mu; q += d * d; }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+        T* yr = y + (int64_t)row * D;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = (it * 64 + lane) * 4;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (v[it][j] - mu) * rs * g[it][j] + b[it][j];
+                store4(yr + c, o);
+            }
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
 
 // backward: workgroup = NW waves, each wave walks every NW-th row of the workgroup's rows; lane-owned columns are fixed so the
 // dgamma/dbeta partial sums live in registers and are combined across the waves through LDS at the end.
@@ -216,7 +245,9 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ part, int npart
 template <typename T>
 int ln_fwd_dispatch(const T* x, const float* g, const float* b, T* y, float* mean, float* rstd, int M, int D, float eps,
                     hipStream_t st) {
-    dim3 grid(cdiv(M, LN_WAVES)), block(256);
+    // rows per wave: at most DEVIAS_LNF_WGS_PER_CU workgroups of 4 waves per CU walk the rows (tools/exp/ln_ab.py)
+    const int cap = ln_ncu() * LNF_WGS_PER_CU;
+    dim3 grid(cdiv(M, LN_WAVES) < cap ? cdiv(M, LN_WAVES) : cap), block(256);
     int nit = cdiv(D, 256);
 #define LNF(N) hipLaunchKernelGGL((ln_fwd_kernel<T, N>), grid, block, 0, st, x, g, b, y, mean, rstd, M, D, eps)
     if (nit <= 2) LNF(2); else if (nit <= 3) LNF(3); else if (nit <= 4) LNF(4); else if (nit <= 8) LNF(8); else LNF(16);
@@ -225,10 +256,6 @@ int ln_fwd_dispatch(const T* x, const float* g, const float* b, T* y, float* mea
 }
 // workgroups and rows per workgroup of the backward kernel: up to LNB_ONE_WG_ROWS rows one workgroup (which then writes the parameter gradients itself),
 // otherwise the rows spread evenly over at most one workgroup per CU
-int ln_ncu() {
-    static int n = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
-    return n;
-}
 void ln_bwd_shape(int M, int& nwg, int& rows) {
     nwg = M <= LNB_ONE_WG_ROWS ? 1 : (cdiv(M, LNB_MIN_ROWS) < ln_ncu() ? cdiv(M, LNB_MIN_ROWS) : ln_ncu());
     rows = cdiv(M, nwg);

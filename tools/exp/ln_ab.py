@@ -13,3 +13,8 @@ e0.record()
 for _ in range(50): o.layernorm_bwd(dy, x, g, mean, rstd, dres=dr, dx_colsum=cs)
 e1.record(); torch.cuda.synchronize()
 print(f"layernorm_bwd (+ param reduce) M={M} D={D}: {e0.elapsed_time(e1)/50*1e3:.1f} us")
+for _ in range(5): o.layernorm_fwd(x, g, b, 1e-6)
+e0.record()
+for _ in range(50): o.layernorm_fwd(x, g, b, 1e-6)
+e1.record(); torch.cuda.synchronize()
+print(f"layernorm_fwd M={M} D={D}: {e0.elapsed_time(e1)/50*1e3:.1f} us")
