@@ -10,6 +10,7 @@
 // Memory: everything is caller-owned.  `save` arenas hold what backward needs (opaque layout, sized by the *_save_bytes functions),
 // `scratch` holds backward temporaries, `ws` is the small fp32 workspace the individual kernels use (split-K slabs, partial sums).
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 #include "roctx_shim.h"
 
@@ -20,6 +21,8 @@ inline int esize(int dtype) { return dtype == DEVIAS_BF16 ? 2 : 4; }
 
 // ---- the split policies of the Python host (devias_amd/ops.py: gemm / wgrad / auto_split_k), restated; tests/test_regions_cpu.py keeps them equal ----
 int small_m_split(int M, int N, int K, int trans_a) {
+    static const int off = [] { const char* e = getenv("DEVIAS_SMALL_M_SPLIT"); return e && atoi(e) == 0; }();      // experiment switch (tools/exp): 0 = never split
+    if (off) return 1;
     if (!(M <= 256 && K >= 512 && !trans_a)) return 1;
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
     int s = K / 128;
@@ -338,11 +341,18 @@ struct AggSave {
             c[i] = take(M * D * es); mc[i] = (float*)take(M * 4); rc[i] = (float*)take(M * 4);
             Wqk[i] = take(hD * D * es); Wov[i] = take(D * hD * es);
         }
-        for (int l = 0; l < a->depth; ++l) {
-            Layer& y = L[l];
-            y.xs_in = take(R * D * es); y.qn = take(R * D * es); y.z = take(R * hD * es); y.xs1 = take(R * D * es); y.f = take(R * D * es);
-            y.fpre = take(R * F * es); y.fact = take(R * F * es);
-            y.mq = (float*)take(R * 4); y.rq = (float*)take(R * 4); y.mf = (float*)take(R * 4); y.rf = (float*)take(R * 4);
+        // per-layer tensors, one stack per field, the layers contiguous: the deferred weight gradients of a tied weight set reduce over all its
+        // layers' rows in ONE product ([depth * R, .] operands)
+        {
+            char *xs_in = take(a->depth * R * D * es), *qn = take(a->depth * R * D * es), *z = take(a->depth * R * hD * es), *xs1 = take(a->depth * R * D * es);
+            char *f = take(a->depth * R * D * es), *fpre = take(a->depth * R * F * es), *fact = take(a->depth * R * F * es);
+            float *mq = (float*)take(a->depth * R * 4), *rq = (float*)take(a->depth * R * 4), *mf = (float*)take(a->depth * R * 4), *rf = (float*)take(a->depth * R * 4);
+            for (int l = 0; l < a->depth; ++l) {
+                Layer& y = L[l];
+                y.xs_in = xs_in + l * R * D * es; y.qn = qn + l * R * D * es; y.z = z + l * R * hD * es; y.xs1 = xs1 + l * R * D * es; y.f = f + l * R * D * es;
+                y.fpre = fpre + l * R * F * es; y.fact = fact + l * R * F * es;
+                y.mq = mq + l * R; y.rq = rq + l * R; y.mf = mf + l * R; y.rf = rf + l * R;
+            }
         }
         qp_layer = R * hD * es; attn_layer = (int64_t)a->B * a->heads * a->S * a->N * 4; rsum_layer = (int64_t)a->B * a->heads * a->S * 4;
         qp_stack = take(qp_layer * a->depth);
@@ -354,7 +364,9 @@ struct AggSave {
 };
 struct AggScratch {
     char *dz_stack; float* ds_stack;
-    char *dxs[2], *dfpre, *df, *dxs1, *dqp, *dqn;      // B*S-row temporaries
+    char *dxs_stack, *dfpre_stack, *dxs1_stack, *dqp_stack;      // gradients of every layer's output / FF pre-activation / attention residual / q', kept for the deferred weight gradients
+    char *df, *dqn;                                    // B*S-row temporaries
+    int64_t rd, rf, rh;                                // bytes of one layer of a [R, D] / [R, F] / [R, h*D] stack
     char *coef, *vec, *dc, *dfeats[2];                 // deferred context gradient
     float *gWqk[DEVIAS_AGG_MAX_DEPTH], *gWov[DEVIAS_AGG_MAX_DEPTH];   // fp32 gradient accumulators of the composite weights
     char *gqk_t, *gov_t;                               // their compute-dtype copies (bf16 mode)
@@ -370,8 +382,10 @@ struct AggScratch {
         auto take = [&](int64_t n) { char* r = reinterpret_cast<char*>(p + (uintptr_t)off); off += al256(n); return r; };
         dz_layer = R * hD * es; ds_layer = (int64_t)a->B * a->heads * a->S * a->N * 4;
         dz_stack = take(dz_layer * a->depth); ds_stack = (float*)take(ds_layer * a->depth);
-        dxs[0] = take(R * D * es); dxs[1] = take(R * D * es); dfpre = take(R * F * es); df = take(R * D * es); dxs1 = take(R * D * es);
-        dqp = take(R * hD * es); dqn = take(R * D * es);
+        rd = R * D * es; rf = R * F * es; rh = R * hD * es;
+        dxs_stack = take((a->depth + 1) * rd);         // slot l + 1 = gradient of layer l's output; slot 0 = gradient of the latents' rows
+        dfpre_stack = take(a->depth * rf); dxs1_stack = take(a->depth * rd); dqp_stack = take(a->depth * rh);
+        df = take(rd); dqn = take(rd);
         coef = take((int64_t)a->B * K * Np * es); vec = take((int64_t)a->B * K * D * es); dc = take(M * D * es);
         dfeats[0] = take(M * D * es); dfeats[1] = take(M * D * es);
         for (int i = 0; i < nset; ++i) { gWqk[i] = (float*)take(hD * D * 4); gWov[i] = (float*)take(D * hD * 4); }
@@ -407,9 +421,10 @@ extern "C" int64_t devias_agg_block_workspace_bytes(const devias_agg_args* a) {
     w = max64(w, devias_slotf_workspace_bytes(a->B, a->S, a->N, a->heads, D));
     const int dims[][3] = {{R, hD, D}, {R, D, hD}, {R, F, D}, {R, D, F}};
     for (auto& d : dims) w = max64(w, gemm_ws(d[0], d[1], d[2], 0));
+    const int RL = R * (a->tied ? a->depth : 1);
     const int wg[][2] = {{D, F}, {F, D}, {D, hD}, {hD, D}};
-    for (auto& d : wg) w = max64(w, wgrad_ws(d[0], d[1], R, a->dtype));
-    w = max64(w, max64(devias_colsum_workspace_bytes(R, D), devias_colsum_workspace_bytes(R, F)));
+    for (auto& d : wg) w = max64(w, wgrad_ws(d[0], d[1], RL, a->dtype));
+    w = max64(w, max64(devias_colsum_workspace_bytes(RL, D), devias_colsum_workspace_bytes(RL, F)));
     return al256(w) + 256;
 }
 
@@ -480,9 +495,8 @@ extern "C" int devias_agg_block_bwd(const devias_agg_args* a, const void* x, con
     devias_range r("agg_block_bwd");
     bool seen[DEVIAS_AGG_MAX_DEPTH];
     for (int i = 0; i < DEVIAS_AGG_MAX_DEPTH; ++i) seen[i] = false;
-    char* dxs = t.dxs[0];
-    char* dxs_other = t.dxs[1];
-    RUN(ln_bwd(c, dslots, s.xs_last, a->last_w, s.ml, s.rl, nullptr, dxs, g->dlast_w, g->dlast_b, 0.f, nullptr, R, D));
+    auto dxs_of = [&](int l) { return t.dxs_stack + (int64_t)(l + 1) * t.rd; };      // gradient of layer l's output (l = -1: of the first layer's input)
+    RUN(ln_bwd(c, dslots, s.xs_last, a->last_w, s.ml, s.rl, nullptr, dxs_of(a->depth - 1), g->dlast_w, g->dlast_b, 0.f, nullptr, R, D));
     for (int l = a->depth - 1; l >= 0; --l) {
         const int si = a->tied ? 0 : l;
         const devias_agg_layer_params& P = a->sets[si];
@@ -493,22 +507,20 @@ extern "C" int devias_agg_block_bwd(const devias_agg_args* a, const void* x, con
         float* rsum = reinterpret_cast<float*>(reinterpret_cast<char*>(s.rsum_stack) + l * s.rsum_layer);
         char* dz = t.dz_stack + l * t.dz_layer;
         float* ds = reinterpret_cast<float*>(reinterpret_cast<char*>(t.ds_stack) + l * t.ds_layer);
+        char *dxs = dxs_of(l), *dfpre = t.dfpre_stack + l * t.rf, *dxs1 = t.dxs1_stack + l * t.rd, *dqp = t.dqp_stack + l * t.rh;
+        // the activation-gradient chain only: the weight (and bias) gradients of W2, W1, Wov, Wqk wait until every layer of the weight set has run
         // feed-forward: xs2 = xs1 + W2 gelu(W1 LN(xs1) + b1) + b2
-        { Epi e; e.act = DEVIAS_ACT_DGELU; e.aux_in = y.fpre; RUN(gemm(c, dxs, P.W2, t.dfpre, R, F, D, D, F, 0, 1, e)); }
-        RUN(wgrad(c, dxs, y.fact, G.dW2, R, D, F, acc)); RUN(colsum(c, dxs, R, D, G.db2, acc));
-        { Epi e; RUN(gemm(c, t.dfpre, P.W1, t.df, R, D, F, F, D, 0, 1, e)); }
-        RUN(wgrad(c, t.dfpre, y.f, G.dW1, R, F, D, acc)); RUN(colsum(c, t.dfpre, R, F, G.db1, acc));
-        RUN(ln_bwd(c, t.df, y.xs1, P.ffn_w, y.mf, y.rf, dxs, t.dxs1, G.dffn_w, G.dffn_b, acc, nullptr, R, D));
+        { Epi e; e.act = DEVIAS_ACT_DGELU; e.aux_in = y.fpre; RUN(gemm(c, dxs, P.W2, dfpre, R, F, D, D, F, 0, 1, e)); }
+        { Epi e; RUN(gemm(c, dfpre, P.W1, t.df, R, D, F, F, D, 0, 1, e)); }
+        RUN(ln_bwd(c, t.df, y.xs1, P.ffn_w, y.mf, y.rf, dxs, dxs1, G.dffn_w, G.dffn_b, acc, nullptr, R, D));
         // cross attention: xs1 = xs + Wov z + bo
-        { Epi e; RUN(gemm(c, t.dxs1, s.Wov[si], dz, R, hD, D, D, hD, 0, 1, e)); }
-        RUN(wgrad(c, t.dxs1, y.z, t.gWov[si], R, D, hD, acc)); RUN(colsum(c, t.dxs1, R, D, G.dbo, acc));
-        RUN(devias_slotf_bwd(s.c[si], attn, rsum, y.z, dz, l == a->depth - 1 ? dattn : nullptr, t.dqp, ds, B, S, N, heads, D, scale, a->dtype, a->ws, stream));
-        { Epi e; RUN(gemm(c, t.dqp, s.Wqk[si], t.dqn, R, D, hD, hD, D, 0, 1, e)); }
-        RUN(wgrad(c, t.dqp, y.qn, t.gWqk[si], R, hD, D, acc));
-        RUN(ln_bwd(c, t.dqn, y.xs_in, P.norm_w, y.mq, y.rq, t.dxs1, dxs_other, G.dnorm_w, G.dnorm_b, acc, nullptr, R, D));
-        { char* tmp = dxs; dxs = dxs_other; dxs_other = tmp; }
+        { Epi e; RUN(gemm(c, dxs1, s.Wov[si], dz, R, hD, D, D, hD, 0, 1, e)); }
+        RUN(devias_slotf_bwd(s.c[si], attn, rsum, y.z, dz, l == a->depth - 1 ? dattn : nullptr, dqp, ds, B, S, N, heads, D, scale, a->dtype, a->ws, stream));
+        { Epi e; RUN(gemm(c, dqp, s.Wqk[si], t.dqn, R, D, hD, hD, D, 0, 1, e)); }
+        RUN(ln_bwd(c, t.dqn, y.xs_in, P.norm_w, y.mq, y.rq, dxs1, dxs_of(l - 1), G.dnorm_w, G.dnorm_b, acc, nullptr, R, D));
         seen[si] = true;
     }
+    const char* dxs = dxs_of(-1);
     RUN(devias_rows_reduce_mod(dxs, a->dtype, R, D, S, g->dlatents, stream));
     // deferred context gradient: one pass per distinct context over all the layers that used it; composite -> parameter gradients
     const void* dfeats = nullptr;
@@ -518,6 +530,15 @@ extern "C" int devias_agg_block_bwd(const devias_agg_args* a, const void* x, con
         const devias_agg_layer_grads& G = g->sets[si];
         const int l0 = a->tied ? 0 : si, nl = a->tied ? a->depth : 1;
         const int K = 2 * nl * heads * S;
+        {   // weight and bias gradients of the set's W2 / W1 / Wov / Wqk over the rows of ALL its layers (layer-major stacks): one product each instead of one per layer
+            const int RL = nl * R;
+            const AggSave::Layer& y0 = s.L[l0];
+            const char *dxs_s = dxs_of(l0), *dfpre_s = t.dfpre_stack + l0 * t.rf, *dxs1_s = t.dxs1_stack + l0 * t.rd, *dqp_s = t.dqp_stack + l0 * t.rh;
+            RUN(wgrad(c, dxs_s, y0.fact, G.dW2, RL, D, F)); RUN(colsum(c, dxs_s, RL, D, G.db2));
+            RUN(wgrad(c, dfpre_s, y0.f, G.dW1, RL, F, D)); RUN(colsum(c, dfpre_s, RL, F, G.db1));
+            RUN(wgrad(c, dxs1_s, y0.z, t.gWov[si], RL, D, hD)); RUN(colsum(c, dxs1_s, RL, D, G.dbo));
+            RUN(wgrad(c, dqp_s, y0.qn, t.gWqk[si], RL, hD, D));
+        }
         RUN(devias_slotf_pack(reinterpret_cast<const float*>(reinterpret_cast<const char*>(s.attn_stack) + l0 * s.attn_layer),
                               reinterpret_cast<const float*>(reinterpret_cast<const char*>(s.rsum_stack) + l0 * s.rsum_layer),
                               reinterpret_cast<const float*>(reinterpret_cast<const char*>(t.ds_stack) + l0 * t.ds_layer), t.dz_stack + l0 * t.dz_layer,

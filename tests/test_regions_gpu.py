@@ -1,5 +1,7 @@
 """The fused regions (devias_encoder_block_* / devias_agg_block_* / devias_head_*, one library call per region and direction) against the
-per-kernel path they replace: the SAME launches in the same order, so outputs and every parameter gradient must be BITWISE equal --
+per-kernel path they replace: the SAME launches in the same order, so outputs and every parameter gradient must be BITWISE equal
+(one exception since the agg block's region defers the weight / bias gradients of a TIED weight set until all its layers have run and reduces over
+all their rows in one product -- the per-kernel path adds one product per layer: those gradients agree to fp32 summation order) --
 fp32 and bf16, weight-tied and untied aggregation block, stochastic depth (same masks), gradient accumulation into existing .grad, and
 with the data-parallel gradient buckets attached (weight gradients written straight into the bucket views)."""
 import pytest
@@ -59,8 +61,20 @@ def _data(cfg, B):
     return x.cuda(), y.cuda(), tl.cuda(), (fg[0].cuda(), fg[1].cuda())
 
 
-def _assert_bitwise(a, b, what):
-    bad = [k for k in a if not torch.equal(a[k], b[k])]
+# the agg block's matrices and biases whose gradients the region reduces over all layers of a tied weight set at once (csrc/regions.hip: devias_agg_block_bwd)
+_DEFERRED = ("to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight", "to_out.0.bias", ".net.0.weight", ".net.0.bias", ".net.3.weight", ".net.3.bias")
+
+
+def _assert_bitwise(a, b, what, order_tol=0.0):
+    bad = []
+    for k in a:
+        if torch.equal(a[k], b[k]):
+            continue
+        if order_tol and "agg_block" in k and k.endswith(_DEFERRED):
+            err = (a[k].float() - b[k].float()).abs().max().item() / (a[k].float().abs().max().item() + 1e-30)
+            if err <= order_tol:
+                continue
+        bad.append(k)
     assert not bad, f"{what}: not bitwise equal: {bad[:6]} ({len(bad)} of {len(a)})"
 
 
@@ -77,7 +91,9 @@ def test_regions_bitwise_equal_per_kernel_path(name, dtype, B):
     o1, g1 = _step(model, crit, data, regions=True)
     cnt = ops.counters()
     _assert_bitwise(o0, o1, f"{name} {dtype} outputs")
-    _assert_bitwise(g0, g1, f"{name} {dtype} gradients")
+    # (bf16: the fp32 gradients of the composite matrices are rounded to bf16 before the products that recover to_q / to_k / to_v / to_out from them:
+    #  a last-bit difference in fp32 can flip such a rounding)
+    _assert_bitwise(g0, g1, f"{name} {dtype} gradients", order_tol=1e-5 if dtype == "fp32" else 5e-3)
     if dtype == "bf16" and (B * cfg.num_patches) % 256 == 0:            # the measured kernels served the fused regions too
         assert cnt["gemm256p"] + cnt["gemm256"] + cnt["gemm_sk"] >= 12 * 12 and cnt["mhsa_bwd_bf16"] == cfg.depth, cnt
 
@@ -90,7 +106,7 @@ def test_regions_with_stochastic_depth_same_masks():
     o0, g0 = _step(model, crit, data, regions=False, seed=7)
     o1, g1 = _step(model, crit, data, regions=True, seed=7)
     _assert_bitwise(o0, o1, "drop-path outputs")
-    _assert_bitwise(g0, g1, "drop-path gradients")
+    _assert_bitwise(g0, g1, "drop-path gradients", order_tol=5e-3)
 
 
 def test_regions_accumulate_into_existing_grads():
@@ -103,7 +119,7 @@ def test_regions_accumulate_into_existing_grads():
     _, g0 = _step(model, crit, data, regions=False, zero=False)
     _step(model, crit, data, regions=True)
     _, g1 = _step(model, crit, data, regions=True, zero=False)
-    _assert_bitwise(g0, g1, "accumulated gradients")
+    _assert_bitwise(g0, g1, "accumulated gradients", order_tol=1e-5)
 
 
 def test_regions_write_into_gradient_buckets_without_copies():
