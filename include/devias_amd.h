@@ -433,6 +433,9 @@ int64_t devias_agg_block_scratch_bytes(const devias_agg_args* a);
 int64_t devias_agg_block_workspace_bytes(const devias_agg_args* a);
 /* x: T [B*N, D] encoder output (before the final LayerNorm); slots: T [B*S, D]; *attn_out = the last layer's slot softmax, fp32 [B*heads, S, N], inside `save` */
 int devias_agg_block_fwd(const devias_agg_args* a, const void* x, void* slots, float** attn_out, void* stream);
+/* dslots: gradient of `slots`; dattn: optional gradient arriving on *attn_out; dx: gradient of x.  Gradients of a weight set used by several layers (tied) are the
+ * sum over those layers: LayerNorm parameters accumulate layer by layer, the matrices and biases are reduced over all layers' rows in one product each after the last
+ * layer has run (fixed order: deterministic) */
 int devias_agg_block_bwd(const devias_agg_args* a, const void* x, const void* dslots, const float* dattn, void* dx, const devias_agg_grads* g,
                          void* scratch, int64_t scratch_bytes, void* stream);
 /* the automatic split-K choices the regions (and the Python host) make, for hosts that size workspaces themselves */
