@@ -268,10 +268,12 @@ int ln_bwd_dispatch(const T* dy, const T* x, const float* g, const float* mean, 
     int nwg, rows;
     ln_bwd_shape(M, nwg, rows);
     int nit = cdiv(D, 256);
-    // waves per workgroup: 16 while the combine tree's LDS (NW / 2 x 3 x NIT x 1 KiB) fits, 8 for the widest rows
+    // waves per workgroup: 16 where the row fits 128 registers per lane (bf16 up to D = 768, fp32 up to 512), 8 up to D = 1024, 4 beyond: no instantiation may spill
+    // (the combine tree's LDS is NW / 2 x 3 x NIT x 1 KiB)
+    constexpr bool half = sizeof(T) == 2;
 #define LNB(N, NW) hipLaunchKernelGGL((ln_bwd_kernel<T, N, NW>), dim3(nwg), dim3(NW * 64), (NW / 2) * 3 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D, rows, \
                                       dgamma, dbeta, dxsum, beta_acc)
-    if (nit <= 2) LNB(2, 16); else if (nit <= 3) LNB(3, 16); else if (nit <= 4) LNB(4, 16); else LNB(8, 8);
+    if (nit <= 2) LNB(2, 16); else if (nit <= 3) { if constexpr (half) LNB(3, 16); else LNB(3, 8); } else if (nit <= 4) LNB(4, 8); else LNB(8, 4);
 #undef LNB
     return 0;
 }

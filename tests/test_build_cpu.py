@@ -19,7 +19,7 @@ def test_four_wave_gemm_kernels_own_their_accumulators():
     src = os.path.join(ROOT, "devias_amd", "csrc", "gemm.hip")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "gemm.s")
-        cmd = [build.HIPCC if hasattr(build, "HIPCC") else "/opt/rocm/bin/hipcc"] + list(build.FLAGS) + ["--cuda-device-only", "-S", src, "-o", out]
+        cmd = [build.HIPCC] + list(build.FLAGS) + ["--cuda-device-only", "-S", src, "-o", out]
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = open(out).read().split("\n")
@@ -50,3 +50,19 @@ def test_four_wave_gemm_kernels_own_their_accumulators():
         meta = "\n".join(x for x in lines if name in x and (".num_agpr" in x or ".private_seg_size" in x))
         assert re.search(r"\.num_agpr, 256", meta) and re.search(r"\.private_seg_size, 0\b", meta), meta
     assert found == 4          # <B k-contiguous | k-strided> x <rows the epilogue reads>
+
+
+@pytest.mark.timeout(600)
+def test_layernorm_kernels_do_not_spill():
+    """the backward LayerNorm kernel's waves per workgroup are chosen per row width and element type so that the row fits the register budget of that
+    occupancy (devias_amd/csrc/layernorm.hip: ln_bwd_dispatch): no instantiation may use scratch"""
+    src = os.path.join(ROOT, "devias_amd", "csrc", "layernorm.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "ln.s")
+        cmd = [build.HIPCC] + list(build.FLAGS) + ["--cuda-device-only", "-S", src, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text = open(out).read()
+    sizes = re.findall(r"\.set (\S*ln_(?:fwd|bwd)_kernel\S*)\.private_seg_size, (\d+)", text)
+    assert len(sizes) >= 16, len(sizes)
+    assert all(int(v) == 0 for _, v in sizes), [(n[-40:], v) for n, v in sizes if int(v)]
