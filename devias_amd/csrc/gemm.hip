@@ -36,6 +36,7 @@ struct GemmP {
     int debug;            // timing ablations, compiled in only with -DDEVIAS_GEMM_DEBUG (option "gemm_debug"): 1 = one K-tile, 2 = no epilogue,
                           // 4 = no LDS-DMA after tile 0, 8 = s_memrealtime stamps into ws, 64 = epilogue without its C stores,
                           // 128 = without its pre-activation stores, 256 = without the GELU / dGELU polynomial
+    int tail_split;       // gemm256p_kernel: split the tiles of the last partial round between two workgroups (128-row halves)
     int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
     float* sk_part; unsigned long long* sk_flag; unsigned long long sk_epoch;   // stream-K kernel: partial slots, flags (+ error word), this launch's tag
 };
@@ -930,21 +931,41 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     const int q = ntiles >> 3, r = ntiles & 7;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int cnt = q + (xcd < r ? 1 : 0);
-    int li = blockIdx.x >> 3;
+    const int li0 = blockIdx.x >> 3;
+    int li = li0;
     if (li >= cnt) return;
     auto coords = [&](int l, int& m0, int& n0) {
         int tm, tn;
         tile_coords(base + l, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
         m0 = tm * T2; n0 = tn * T2;
     };
+    // Tail split: the last, partial round of the group (rem tiles for `stride` workgroups) leaves stride - rem CUs idle for a whole tile time.  When
+    // 2 rem <= stride every tail tile goes to TWO workgroups, each computing one 128-row half: in the other half's waves (wm != half) only the operand
+    // staging and the barriers run.  The two wave rows of a workgroup share the SIMDs pairwise, so the active row has the matrix cores to itself and the
+    // tile's K loop takes a bit more than half its time; every output element is computed by the same wave code as before (bitwise equal).
+    const int rfull = cnt / stride, rem = cnt - rfull * stride;
+    const bool split = p.tail_split != 0 && rfull >= 1 && rem > 0 && 2 * rem <= stride;
+    // this workgroup's k-th tile: (logical index, half: -1 = whole tile); false = none
+    auto tile_at = [&](int k, int& l, int& half) -> bool {
+        half = -1;
+        if (k < rfull) { l = li0 + k * stride; return true; }
+        if (k > rfull) return false;
+        if (split) { if (li0 >= 2 * rem) return false; l = rfull * stride + (li0 >> 1); half = li0 & 1; return true; }
+        if (li0 >= rem) return false;
+        l = rfull * stride + li0;
+        return true;
+    };
+    int tk = 0, half = -1, halfn = -1;
     int m0, n0;
+    (void)tile_at(0, li, half);
     coords(li, m0, n0);
     glds_tile<false>(A, p.lda, m0, 0, smem, wave, lane);
     glds_tile<TB>(B, p.ldb, n0, 0, smem + 32768, wave, lane);
-    int ln = li + stride;
-    bool has_next = ln < cnt;
+    int ln = li;
+    bool has_next = tile_at(1, ln, halfn);
     int m0n = m0, n0n = n0;
     if (has_next) coords(ln, m0n, n0n);
+    bool act = half < 0 || wm == half;                    // (wave-uniform)
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -988,11 +1009,15 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
         int lane_k = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_k));
         if constexpr (!TB) {
-            ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
+            if (act) ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
+            else {                                         // the other half's waves of a split tail tile: staging only
+                glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
+                glds_tile<false>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
+            }
         } else {
             glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
             glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
-            ktile_generic<false, true>(acc, cur, lane_k, wm, wn);
+            if (act) ktile_generic<false, true>(acc, cur, lane_k, wm, wn);
         }
         if (same) {
             ++kt;
@@ -1003,15 +1028,17 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
         PSTAMP(2); PSTAMP(10);
         int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
-        epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
+        if (act) epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
         if (!has_next) break;
         // the epilogue issued >= 16 stores per wave AFTER the DMA of the next tile's first K-tile: wait for the DMA only, the stores drain under the next MFMAs
+        // (a tile with a successor is a whole tile: every wave has run the epilogue)
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         PSTAMP(3);
         kt = 0;
-        li = ln; m0 = m0n; n0 = n0n;
-        ln = li + stride;
-        has_next = ln < cnt;
+        ++tk;
+        li = ln; m0 = m0n; n0 = n0n; half = halfn;
+        act = half < 0 || wm == half;
+        has_next = tile_at(tk + 1, ln, halfn);
         if (has_next) coords(ln, m0n, n0n);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1855,6 +1882,7 @@ struct GemmKnobs {
     int sk_eff;        // "gemm_sk_eff"     DEVIAS_GEMM_SK_EFF   policy: tiles / (rounds * workgroups) below this many percent (default 80) ...
     int sk_mink;       // "gemm_sk_mink"    DEVIAS_GEMM_SK_MINK  ... and at least this many K-tiles per output tile (default 32)
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
+    int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups
     int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
                        //                                        15 = all four); a served call is not considered for stream-K
     int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent / stream-K grids leave this many CUs free (default 0).  Their static tile
@@ -1878,6 +1906,7 @@ GemmKnobs& knobs() {
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
         x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
         x.w4 = env_int("DEVIAS_GEMM_W4", 0);
+        x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 1);
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -1906,6 +1935,7 @@ int devias_gemm_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_sk_mink")) k.sk_mink = value;
     else if (!strcmp(name, "gemm_debug")) k.debug = value;
     else if (!strcmp(name, "gemm_w4")) k.w4 = value;
+    else if (!strcmp(name, "gemm_tail_split")) k.tail_split = value;
     else if (!strcmp(name, "gemm_reserve_cus")) k.reserve = value < 0 ? 0 : value;
     else return 0;
     return 1;
@@ -1964,6 +1994,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         DEVIAS_REQUIRE(split == 1 && !a->colsum && !a->res && !a->aux_in && !a->aux_out && batch <= 65535,
                        "devias_gemm: batched launches support bias / activation epilogues only (no split-K, residual, aux, colsum)");
     p.debug = kn.debug;
+    p.tail_split = kn.tail_split;
     p.epi_swap = kn.epi_swap;
     p.sk_part = nullptr; p.sk_flag = nullptr; p.sk_epoch = 0;
     // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
