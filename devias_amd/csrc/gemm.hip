@@ -2060,11 +2060,10 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         // at K = 768 the same 588-tile grids lose (proj 92 -> 100, dproj 72 -> 80), and grids with < 10 % quantisation loss always lose
         // gemm_w4 is a mask over the four instantiations: 1 = B k-contiguous, no side rows; 2 = B k-contiguous + residual; 4 = B k-strided, no side rows;
         // 8 = B k-strided + saved pre-activation
-        // Default 0.  Timed alone (tools/exp/w4_check.py, 20 back-to-back launches per shape) every form wins: -5.6 % on the sum of the block's eight forward /
-        // dgrad GEMMs, qkv -11 %, fc1 -9 %, fc2 -8 %.  IN the step the gain is not there (tools/step_gemm_shapes.py on rocprofv3 traces of bench.py, one box:
-        // qkv -7 us, fc1 -6, fc2 -3..-10 per call; proj +11, dfc2 +12, and dfc1 +30 / dqkv +14 against the stream-K schedule they would replace; bench.py over
-        // three interleaved runs per mask: 53.33 / 53.47 / 53.22 ms per step for masks 0 / 3 / 31) -- the GEMM phases of the step run at the board's power limit
-        // (DESIGN.md 5, round 3), where a K loop with fewer stalls buys a lower clock, not a shorter time
+        // Default 0.  Timed alone (tools/exp/w4_check.py, the two kernels alternately) the forms with B k-contiguous win (qkv -11 %, fc1 -9 %, fc2 -8 %; the block's eight
+        // forward / dgrad GEMMs -4.9 %, and 0 % against the eight-wave kernel with its tail split), the k-strided forms are equal.  IN the step the gain is not there
+        // (tools/step_gemm_shapes.py on rocprofv3 traces of bench.py, one box: qkv -7 us, fc1 -6, fc2 -3..-10 per call; proj +11, dfc2 +12, and dfc1 +30 / dqkv +14 against
+        // the stream-K schedule they would replace; bench.py over three interleaved runs per mask: 53.33 / 53.47 / 53.22 ms per step for masks 0 / 3 / 15)
         const int w4_form = (tb ? 2 : 0) + (side != 0 ? 1 : 0);
         const bool w4_ok = kn.persistent && ((kn.w4 >> w4_form) & 1) && pers_ok && nt > gp && a->K >= 128 &&
                            (a->act == DEVIAS_ACT_NONE || a->act == DEVIAS_ACT_GELU || a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU);
