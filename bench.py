@@ -118,7 +118,7 @@ def dominant_kernel_probe(args, device):
     if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
         # HBM-side bytes per launch from the committed PMC passes of this same launch (profiles/r3_pmc: 2*FETCH_SIZE + WRITE_SIZE,
         # the gfx950 FETCH_SIZE correction applied; round 2: 1080.4 MB)
-        probe["traffic"] = 1.1073e9
+        probe["traffic"] = 1.0895e9
         probe["traffic_source"] = "profiles/r3_pmc/README.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     return probe
 

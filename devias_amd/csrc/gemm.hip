@@ -1877,7 +1877,8 @@ struct GemmKnobs {
     int use_ss;        // "gemm_ss"         DEVIAS_GEMM_SS       -1 = measured policy, 0 = never, 1 = prefer the single-stage 256x128 kernel for k-strided layouts
     int group_m;       // "gemm_groupm"     DEVIAS_GEMM_GROUPM   0 = measured policy, > 0 forces the rasterisation group height
     int persistent;    // "gemm_persistent" DEVIAS_GEMM_PERSIST  != 0: persistent 256x256 kernel where it applies (default), 0 = one tile per workgroup
-    int streamk;       // "gemm_streamk"    DEVIAS_GEMM_SK       stream-K form of the persistent kernel (needs args.sk_ws): 0 = never, 1 = by policy (default),
+    int streamk;       // "gemm_streamk"    DEVIAS_GEMM_SK       stream-K form of the persistent kernel (needs args.sk_ws): 0 = never (default since the tail split: in the
+                       //                                        step, three interleaved bench.py pairs, 51.35 ms with the policy vs 51.20 without), 1 = by policy,
                        //                                        3 = wherever it can run (tests)
     int sk_eff;        // "gemm_sk_eff"     DEVIAS_GEMM_SK_EFF   policy: tiles / (rounds * workgroups) below this many percent (default 80) ...
     int sk_mink;       // "gemm_sk_mink"    DEVIAS_GEMM_SK_MINK  ... and at least this many K-tiles per output tile (default 32)
@@ -1900,7 +1901,7 @@ GemmKnobs& knobs() {
         x.use_ss = env_int("DEVIAS_GEMM_SS", -1);
         x.group_m = env_int("DEVIAS_GEMM_GROUPM", 0);
         x.persistent = env_int("DEVIAS_GEMM_PERSIST", 1);
-        x.streamk = env_int("DEVIAS_GEMM_SK", 1);
+        x.streamk = env_int("DEVIAS_GEMM_SK", 0);
         x.sk_eff = env_int("DEVIAS_GEMM_SK_EFF", 80);
         x.sk_mink = env_int("DEVIAS_GEMM_SK_MINK", 32);
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
