@@ -68,8 +68,10 @@ const char* devias_last_error(void);
 int64_t devias_counter(int32_t id);          /* -1 for an unknown id */
 void devias_counters_reset(void);
 /* Process-wide integer options (initialised once from the DEVIAS_* environment variables of the same meaning): "gemm_epi",
- * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_streamk", "gemm_sk_eff", "gemm_sk_mink", "gemm_debug", "gemm_reserve_cus" (CUs the persistent
- * GEMM grids leave free for a concurrent kernel, e.g. RCCL's during backward), "attn_cfg", "attn_xcd".  0 = ok, DEVIAS_EINVAL = unknown name. */
+ * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_tail_split" (1, default: the tiles of a persistent launch's last partial round are computed as
+ * 128-row halves by two workgroups when at least half the CUs would idle), "gemm_streamk" (0 = never, default; 1 = by policy; 3 = wherever it can run), "gemm_sk_eff",
+ * "gemm_sk_mink", "gemm_w4" (mask of the forms the four-wave persistent kernel serves, default 0), "gemm_debug", "gemm_reserve_cus" (CUs the persistent GEMM grids
+ * leave free for a concurrent kernel, e.g. RCCL's during backward), "attn_cfg", "attn_xcd".  Every choice computes the same bits.  0 = ok, DEVIAS_EINVAL = unknown name. */
 int devias_set_option(const char* name, int32_t value);
 
 /* In-place SUM all-reduce of one flat gradient bucket over the caller's RCCL communicator (`nccl_comm` is an ncclComm_t; dtype DEVIAS_F32 or
