@@ -149,7 +149,9 @@ def test_cast_im2col_colsum_rows():
 
 # --------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,D,eps", [(4, 768, 1e-6), (1571, 768, 1e-5), (130, 384, 1e-6), (67, 1024, 1e-6)])
+@pytest.mark.parametrize("M,D,eps", [(4, 768, 1e-6), (1571, 768, 1e-5), (130, 384, 1e-6), (67, 1024, 1e-6),
+                                     # backward grids: one 16-wave workgroup per CU with ragged rows per workgroup; 8-wave (D = 1024) and 4-wave (D = 2048) forms
+                                     (20011, 768, 1e-6), (9001, 1024, 1e-6), (3001, 2048, 1e-6), (257, 512, 1e-5)])
 def test_layernorm(dtype, M, D, eps):
     o = ops()
     x = rnd(M, D, dtype=dtype, seed=20) * 2 + 0.5
