@@ -165,7 +165,7 @@ PROTOTYPES = {
     "devias_policy_wgrad_split": (c_int32, [_I, _I, _I, _I]),
 }
 COUNTERS = {"gemm128_f32": 0, "gemm128_bf16": 1, "gemm_ss": 2, "gemm256": 3, "gemm256p": 4, "splitk_reduce": 5,
-            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10, "gemm_sk": 11, "gemm256w": 12}     # DEVIAS_CNT_*
+            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10, "gemm_sk": 11, "gemm256w": 12, "gemm_smallm": 13}     # DEVIAS_CNT_*
 OPT_CHUNK = 16384          # DEVIAS_OPT_CHUNK
 OPT_TENSOR_BYTES = 64      # sizeof(devias_opt_tensor)
 

@@ -1810,6 +1810,112 @@ __global__ void splitk_reduce_kernel(GemmP p) {
     }
 }
 
+// =====================================================================================================================
+// Small-M GEMM (M <= 128 rows: the B*S slot rows of the aggregation block and the head), bf16, B in nn.Linear layout [N, K]:
+// C[M, N] = epilogue(A[M, K] W^T).  These products stream a weight matrix of a few MB once and do almost no arithmetic; through the 128 x 128
+// kernel they needed split-K to reach more than a handful of CUs, i.e. two launches (product + reduce, ~8 + 6.5 us in the step) for ~1 us of
+// memory traffic.  Here: one workgroup per 16 output columns (N / 16 workgroups: 48 ... 256), its four waves split K four ways, every operand
+// fragment is ONE 16-byte global load per lane straight into the MFMA operand registers (A rows and W rows are both k-contiguous: no LDS
+// staging), PD k-steps of loads in flight per wave; the waves' partial tiles meet in LDS in a fixed order (deterministic) and wave 0 applies
+// the epilogue of splitk_reduce_kernel (same arithmetic, same order).
+// =====================================================================================================================
+enum { SM_PD = 4 };
+template <int MT>      // MT = 16-row tiles of the output (M <= 16 MT)
+__global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) f32x4 red[3][MT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lm = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kw = p.K / 4;                                  // this wave's share of K (a multiple of 32: host)
+    const int k0 = wave * kw;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* W = reinterpret_cast<const bf16*>(p.B);
+    const bf16* wrow = W + (int64_t)(n0 + lm) * p.ldb + k0 + 8 * g;
+    const bf16* arow[MT];
+    bool aok[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + lm;
+        aok[t] = m < p.M;
+        arow[t] = A + (int64_t)(aok[t] ? m : 0) * p.lda + k0 + 8 * g;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // what the epilogue reads is requested before the K loop (wave 0): these launches are latency chains, not bandwidth
+    const bf16* res = reinterpret_cast<const bf16*>(p.res);
+    const bf16* aux_in = reinterpret_cast<const bf16*>(p.aux_in);
+    const int n = n0 + 4 * g;                               // this lane's four output columns
+    f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x4 resv[MT], auxv[MT];
+    const bool dact = p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU;
+    if (wave == 0) {
+        if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = t * 16 + lm;
+            if (res && m < p.M) resv[t] = *reinterpret_cast<const bf16x4*>(res + (int64_t)(p.res_mod > 0 ? m % p.res_mod : m) * p.ldr + n);
+            if (dact && m < p.M) auxv[t] = *reinterpret_cast<const bf16x4*>(aux_in + (int64_t)m * p.ld_aux + n);
+        }
+    }
+    const int nks = kw / 32;
+    bf16x8 fb[SM_PD], fa[SM_PD][MT];
+    auto issue = [&](int slot, int ks) {
+        fb[slot] = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) fa[slot][t] = *reinterpret_cast<const bf16x8*>(arow[t] + ks * 32);
+    };
+#pragma unroll
+    for (int d = 0; d < SM_PD; ++d) if (d < nks) issue(d, d);
+    for (int ks0 = 0; ks0 < nks; ks0 += SM_PD) {
+#pragma unroll
+        for (int d = 0; d < SM_PD; ++d) {
+            const int ks = ks0 + d;
+            if (ks < nks) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = mfma16(fb[d], fa[d][t], acc[t]);
+                if (ks + SM_PD < nks) issue(d, ks + SM_PD);
+            }
+        }
+    }
+    // rows beyond M were computed from row 0's data: they are never stored.  Partial tiles of waves 1..3 -> LDS; wave 0 adds them in that order
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[wave - 1][t][lane] = acc[t];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    bf16* aux_out = reinterpret_cast<bf16*>(p.aux_out);
+    bf16* C = reinterpret_cast<bf16*>(p.C);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + lm;
+        f32x4 v = acc[t];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += red[w][t][lane];
+        if (m >= p.M) continue;
+        if (p.bias) v += bias;
+        if (p.act == DEVIAS_ACT_GELU) {
+            if (aux_out) store4(aux_out + (int64_t)m * p.ld_aux + n, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_t<bf16>(v[e]);
+        } else if (p.act == DEVIAS_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == DEVIAS_ACT_SIGMOID) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+        } else if (dact) {
+            const f32x4 a4 = {(float)auxv[t][0], (float)auxv[t][1], (float)auxv[t][2], (float)auxv[t][3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = p.act == DEVIAS_ACT_DGELU ? v[e] * dgelu_t<bf16>(a4[e]) : (a4[e] > 0.f ? v[e] : 0.f);
+        }
+        if (p.row_scale) v *= p.row_scale[m / p.rows_per_scale];
+        if (res) v += f32x4{(float)resv[t][0], (float)resv[t][1], (float)resv[t][2], (float)resv[t][3]};
+        store4(C + (int64_t)m * p.ldc + n, v);
+    }
+}
+
 // the weight-gradient case of the reduce (fp32 C with ldc == N, no epilogue beyond beta): 16 bytes per lane, no per-element div/mod
 __global__ __launch_bounds__(256) void splitk_reduce_plain_kernel(const float* __restrict__ ws, int split_k, int64_t total4, float* __restrict__ C, float beta) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
@@ -1883,6 +1989,7 @@ struct GemmKnobs {
     int sk_eff;        // "gemm_sk_eff"     DEVIAS_GEMM_SK_EFF   policy: tiles / (rounds * workgroups) below this many percent (default 80) ...
     int sk_mink;       // "gemm_sk_mink"    DEVIAS_GEMM_SK_MINK  ... and at least this many K-tiles per output tile (default 32)
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
+    int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K)
     int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups
     int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
                        //                                        15 = all four); a served call is not considered for stream-K
@@ -1908,6 +2015,7 @@ GemmKnobs& knobs() {
         x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
         x.w4 = env_int("DEVIAS_GEMM_W4", 0);
         x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 1);
+        x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -1937,6 +2045,7 @@ int devias_gemm_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_debug")) k.debug = value;
     else if (!strcmp(name, "gemm_w4")) k.w4 = value;
     else if (!strcmp(name, "gemm_tail_split")) k.tail_split = value;
+    else if (!strcmp(name, "gemm_smallm")) k.smallm = value;
     else if (!strcmp(name, "gemm_reserve_cus")) k.reserve = value < 0 ? 0 : value;
     else return 0;
     return 1;
@@ -2022,6 +2131,24 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     if (ss && big) {
         const bool nt = !a->trans_a && !a->trans_b;
         if (kn.use_ss < 0 || nt) ss = false;
+    }
+    // small-M products (the aggregation block's and the head's B*S-row GEMMs): one launch, no split-K (gemm_smallm_kernel)
+    const bool smallm = kn.smallm && a->dtype == DEVIAS_BF16 && !a->trans_a && !a->trans_b && a->M <= 128 && batch == 1 && !p.c_f32 && !a->colsum && vec && vc &&
+                        (a->N % 16 == 0) && (a->K % 128 == 0) && (a->lda % 8 == 0) && (a->ldb % 8 == 0) && (a->ldc % 4 == 0) && aligned8(a->C) &&
+                        (!a->bias || aligned16(a->bias)) && (!a->res || (a->ldr % 4 == 0 && aligned8(a->res))) &&
+                        (!a->aux_in || (a->ld_aux % 4 == 0 && aligned8(a->aux_in))) && (!a->aux_out || (a->ld_aux % 4 == 0 && aligned8(a->aux_out)));
+    if (smallm) {
+        p.split_k = 1; p.k_per_split = a->K;
+        const int mt = cdiv(a->M, 16);
+        dim3 grid(a->N / 16), block(256);
+        if (mt <= 1) hipLaunchKernelGGL((gemm_smallm_kernel<1>), grid, block, 0, st, p);
+        else if (mt <= 2) hipLaunchKernelGGL((gemm_smallm_kernel<2>), grid, block, 0, st, p);
+        else if (mt <= 4) hipLaunchKernelGGL((gemm_smallm_kernel<4>), grid, block, 0, st, p);
+        else if (mt <= 6) hipLaunchKernelGGL((gemm_smallm_kernel<6>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_smallm_kernel<8>), grid, block, 0, st, p);
+        devias_count(DEVIAS_CNT_GEMM_SMALLM);
+        DEVIAS_CHECK_LAUNCH("devias_gemm(small M)");
+        return DEVIAS_OK;
     }
     bool colsum_fused = false;
     if (a->colsum) {

@@ -61,6 +61,7 @@ const char* devias_last_error(void);
 #define DEVIAS_CNT_MHSA_FWD_F32 8    /* VALU parity kernels */
 #define DEVIAS_CNT_MHSA_BWD_F32 9
 #define DEVIAS_CNT_GEMM_SK 11        /* 256x256 persistent kernel, stream-K schedule */
+#define DEVIAS_CNT_GEMM_SMALLM 13     /* small-M kernel (M <= 128, bf16, B k-contiguous): one launch instead of split-K product + reduce */
 #define DEVIAS_CNT_GEMM256W 12       /* 256x256 persistent kernel, four-wave form (one wave per SIMD, accumulators in AGPRs): the default persistent kernel;
                                         every such launch also counts as DEVIAS_CNT_GEMM256P */
 #define DEVIAS_CNT_MHSA_BWD_FUSED 10 /* (retired with ABI 150: always 0) */
@@ -70,8 +71,9 @@ void devias_counters_reset(void);
 /* Process-wide integer options (initialised once from the DEVIAS_* environment variables of the same meaning): "gemm_epi",
  * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_tail_split" (1, default: the tiles of a persistent launch's last partial round are computed as
  * 128-row halves by two workgroups when at least half the CUs would idle), "gemm_streamk" (0 = never, default; 1 = by policy; 3 = wherever it can run), "gemm_sk_eff",
- * "gemm_sk_mink", "gemm_w4" (mask of the forms the four-wave persistent kernel serves, default 0), "gemm_debug", "gemm_reserve_cus" (CUs the persistent GEMM grids
- * leave free for a concurrent kernel, e.g. RCCL's during backward), "attn_cfg", "attn_xcd".  Every choice computes the same bits.  0 = ok, DEVIAS_EINVAL = unknown name. */
+ * "gemm_sk_mink", "gemm_smallm" (1, default: bf16 products with M <= 128 and B k-contiguous run as ONE launch of the small-M kernel instead of split-K
+ * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves, default 0), "gemm_debug", "gemm_reserve_cus" (CUs the persistent GEMM grids
+ * leave free for a concurrent kernel, e.g. RCCL's during backward), "attn_cfg", "attn_xcd".  Every choice except gemm_smallm computes the same bits.  0 = ok, DEVIAS_EINVAL = unknown name. */
 int devias_set_option(const char* name, int32_t value);
 
 /* In-place SUM all-reduce of one flat gradient bucket over the caller's RCCL communicator (`nccl_comm` is an ncclComm_t; dtype DEVIAS_F32 or

@@ -422,7 +422,7 @@ def gemm_options():
     """restores the process-wide kernel-selection options a test changes"""
     o = ops()
     yield o
-    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 0), ("gemm_w4", 0), ("gemm_tail_split", 1)):
+    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 0), ("gemm_w4", 0), ("gemm_tail_split", 1), ("gemm_smallm", 1)):
         o.set_option(k, v)
 
 
@@ -678,3 +678,51 @@ def test_c_abi_allreduce_bucket_single_rank():
         assert torch.equal(x, ref)
     rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+# ------------------------------------------------------------------------------------------------ small-M GEMM (agg block / head rows)
+@pytest.mark.parametrize("epi", ["bias_res", "gelu_aux", "dgelu", "relu", "sigmoid", "plain", "rowscale_resmod"])
+@pytest.mark.parametrize("M,N,K", [(64, 3072, 768), (64, 768, 3072), (96, 768, 768), (4, 384, 384), (6, 1536, 384), (128, 512, 256), (70, 400, 768), (64, 48, 128)])
+def test_gemm_small_m_kernel(M, N, K, epi, gemm_options):
+    """gemm_smallm_kernel (M <= 128, bf16, B k-contiguous: one launch, the four waves of a workgroup split K) against the fp32 op on the bf16-rounded inputs and
+    against the split-K path it replaces (same epilogue arithmetic; the K summation order differs), with the counter asserting which kernel ran"""
+    o = gemm_options
+    from devias_amd._lib import ACT_DGELU, ACT_GELU, ACT_RELU, ACT_SIGMOID
+    A = rnd(M, K, dtype=torch.bfloat16, seed=31)
+    W = rnd(N, K, dtype=torch.bfloat16, scale=0.1, seed=32)
+    bias = rnd(N, seed=33)
+    ref = A.float() @ W.float().t()
+    kw = {}
+    if epi == "bias_res":
+        res = rnd(M, N, dtype=torch.bfloat16, seed=34); kw = dict(bias=bias, res=res); ref = ref + bias + res.float()
+    elif epi == "gelu_aux":
+        kw = dict(bias=bias, act=ACT_GELU); ref_pre = ref + bias; ref = F.gelu(ref_pre)
+    elif epi == "dgelu":
+        pre = rnd(M, N, dtype=torch.bfloat16, seed=35); x = pre.float()
+        kw = dict(act=ACT_DGELU, aux_in=pre); ref = ref * (0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi))
+    elif epi == "relu":
+        kw = dict(bias=bias, act=ACT_RELU); ref = torch.relu(ref + bias)
+    elif epi == "sigmoid":
+        kw = dict(bias=bias, act=ACT_SIGMOID); ref = torch.sigmoid(ref + bias)
+    elif epi == "rowscale_resmod":
+        S = 2 if M % 2 == 0 else 1
+        res = rnd(S, N, dtype=torch.bfloat16, seed=36); rs = (torch.arange(M, device=DEV) % 3).float() * 0.5
+        kw = dict(bias=bias, res=res, res_mod=S, row_scale=rs, rows_per_scale=1); ref = (ref + bias) * rs[:, None] + res.float().repeat(M // S, 1)
+    outs = {}
+    for mode in (1, 0):
+        o.set_option("gemm_smallm", mode)
+        kw2 = dict(kw)
+        if epi == "gelu_aux":
+            kw2["aux_out"] = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        o.counters(reset=True)
+        c = o.gemm(A, W, **kw2)
+        torch.cuda.synchronize()
+        served = N % 16 == 0 and K % 128 == 0
+        assert o.counters()["gemm_smallm"] == (1 if mode and served else 0), (mode, o.counters())
+        outs[mode] = (c, kw2.get("aux_out"))
+    o.set_option("gemm_smallm", 1)
+    c, aux = outs[1]
+    assert rel(c.float(), ref) < TOL[torch.bfloat16]
+    assert rel(c.float(), outs[0][0].float()) < TOL[torch.bfloat16]
+    if aux is not None:
+        assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16] and rel(aux.float(), outs[0][1].float()) < TOL[torch.bfloat16]
