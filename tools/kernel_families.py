@@ -4,7 +4,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 15.0
-fam = [("GEMM", ("gemm256", "gemm_kernel", "gemm_ss", "gemm_pk")), ("attention backward dK/dV", ("mhsa_bwd_dkdv",)), ("attention backward dQ", ("mhsa_bwd_dq",)),
+fam = [("GEMM", ("gemm256", "gemm_kernel", "gemm_ss", "gemm_pk", "gemm_smallm")), ("attention backward dK/dV", ("mhsa_bwd_dkdv",)), ("attention backward dQ", ("mhsa_bwd_dq",)),
        ("attention forward", ("mhsa_fwd",)), ("LayerNorm fwd + bwd", ("ln_fwd", "ln_bwd")), ("split-K reduces", ("splitk_reduce",)),
        ("column sums", ("colsum",)), ("slot attention", ("slotm", "slotf", "slot_")), ("LayerNorm parameter reduce", ("ln_param_reduce",))]
 tot = {k: 0.0 for k, _ in fam}; tot["rest"] = 0.0
