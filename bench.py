@@ -112,13 +112,13 @@ def dominant_kernel_probe(args, device):
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * M * 4 * D * D
     es = 2 if dt == torch.bfloat16 else 4
-    probe = {"name": "gemm256w_kernel<false, 0> four-wave persistent 256x256x64 LDS-DMA: fc1 forward of the encoder block (bias + GELU + saved pre-activation)",
+    probe = {"name": "gemm256p_kernel<false, 0> persistent 256x256x64 LDS-DMA: fc1 forward of the encoder block (bias + GELU + saved pre-activation)",
              "flop_per_launch": fl, "avg_ms": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
              "algorithmic_bytes": (M * D + 4 * D * D + 2 * M * 4 * D) * es}
     if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
         # HBM-side bytes per launch from the committed PMC passes of this same launch (profiles/r3_pmc: 2*FETCH_SIZE + WRITE_SIZE,
         # the gfx950 FETCH_SIZE correction applied; round 2: 1080.4 MB)
-        probe["traffic"] = 1.0645e9
+        probe["traffic"] = 1.0895e9
         probe["traffic_source"] = "profiles/r3_pmc/README.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     return probe
 
@@ -269,7 +269,7 @@ def main():
                                (f" + persistent GEMM grids sized for {args.reserve_cus} fewer CUs (--reserve-cus)" if args.reserve_cus else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
-                   "kernels": "persistent 256x256 GEMM (forward + dgrad; four-wave form for qkv / fc1, eight-wave form with split tail tiles elsewhere), 32x32x16 MFMA attention forward, two-kernel MFMA attention backward, folded slot "
+                   "kernels": "persistent 256x256 GEMM (forward + dgrad; tail tiles of a partial round split between two workgroups), 32x32x16 MFMA attention forward, two-kernel MFMA attention backward, folded slot "
                               "cross-attention (K/V projections on the slot side); one library call per fused region and direction (csrc/regions.hip)"},
         "host_enqueue_ms_per_step": host_idle[len(host_idle) // 2] * 1e3, "host_library_calls_per_step": lib_calls,
         "host_enqueue_method": "one step enqueued on an idle stream, median of 5, outside the timed region (python + fused-region library calls + HIP launches)",

@@ -1991,7 +1991,7 @@ struct GemmKnobs {
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
     int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K)
     int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups
-    int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 1,
+    int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
                        //                                        15 = all four); a served call is not considered for stream-K
     int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent / stream-K grids leave this many CUs free (default 0).  Their static tile
                        //                                        lists assume one resident workgroup per CU of the grid: with K CUs held by another kernel
@@ -2013,7 +2013,7 @@ GemmKnobs& knobs() {
         x.sk_mink = env_int("DEVIAS_GEMM_SK_MINK", 32);
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
         x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
-        x.w4 = env_int("DEVIAS_GEMM_W4", 1);
+        x.w4 = env_int("DEVIAS_GEMM_W4", 0);
         x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 1);
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
         int dev = 0, n = 256;
@@ -2188,11 +2188,11 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         // at K = 768 the same 588-tile grids lose (proj 92 -> 100, dproj 72 -> 80), and grids with < 10 % quantisation loss always lose
         // gemm_w4 is a mask over the four instantiations: 1 = B k-contiguous, no side rows; 2 = B k-contiguous + residual; 4 = B k-strided, no side rows;
         // 8 = B k-strided + saved pre-activation
-        // Default 1 (B k-contiguous without side rows: qkv, fc1).  Timed alone (tools/exp/w4_check.py, the two kernels alternately) the forms with B k-contiguous win
-        // (qkv -11 %, fc1 -9 %, fc2 -8 %; the block's eight forward / dgrad GEMMs -4.9 %, and 0 % against the eight-wave kernel with its tail split), the k-strided
-        // forms are equal.  IN the step (tools/step_gemm_shapes.py on rocprofv3 traces of bench.py, one box): qkv -7 us, fc1 -6 per call; fc2 -3..-10, proj +11, dfc2 +12,
-        // dfc1 +30 / dqkv +14 against the schedules they would replace; bench.py, three interleaved pairs on the final code: mask 0 52.09 / 52.06 / 52.07 ms, mask 1
-        // 51.86 / 51.84 / 51.91 ms; masks 3 and 15 earlier: no gain
+        // Default 0.  Timed alone (tools/exp/w4_check.py, the two kernels alternately) the forms with B k-contiguous win (qkv -11 %, fc1 -9 %, fc2 -8 %; the block's eight
+        // forward / dgrad GEMMs -4.9 %, and 0 % against the eight-wave kernel with its tail split), the k-strided forms are equal.  IN the step the kernels it serves are
+        // faster (tools/step_gemm_shapes.py on rocprofv3 traces, one box: qkv -7 us, fc1 -6 per call) and the step is SLOWER: tools/ab_inproc.py (one process, the option
+        // toggled between blocks of ten steps, A B B A ...): mask 1 +0.33 ms, mask 3 +0.56, mask 15 +0.32 on 51.7 ms.  (Pairs of separate bench.py runs gave -0.21 ms in
+        // one order and +0.33 in the other: process-to-process noise.)
         const int w4_form = (tb ? 2 : 0) + (side != 0 ? 1 : 0);
         const bool w4_ok = kn.persistent && ((kn.w4 >> w4_form) & 1) && pers_ok && nt > gp && a->K >= 128 &&
                            (a->act == DEVIAS_ACT_NONE || a->act == DEVIAS_ACT_GELU || a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU);

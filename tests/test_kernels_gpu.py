@@ -422,7 +422,7 @@ def gemm_options():
     """restores the process-wide kernel-selection options a test changes"""
     o = ops()
     yield o
-    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 0), ("gemm_w4", 1), ("gemm_tail_split", 1), ("gemm_smallm", 1)):
+    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 0), ("gemm_w4", 0), ("gemm_tail_split", 1), ("gemm_smallm", 1)):
         o.set_option(k, v)
 
 
