@@ -1010,12 +1010,13 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
         asm volatile("" : "+v"(lane_k));
         if constexpr (!TB) {
             if (act) ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
-            else {                                         // the other half's waves of a split tail tile: staging only
-                glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
+            else {                                         // the other half's waves of a split tail tile: staging only -- and of B only: the A rows a wave
+                                                           // stages (32 wave + ...) are the rows of ITS half, which nobody multiplies (tail_split >= 2)
+                if (p.tail_split < 2) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
                 glds_tile<false>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
             }
         } else {
-            glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
+            if (act || p.tail_split < 2) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
             glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
             if (act) ktile_generic<false, true>(acc, cur, lane_k, wm, wn);
         }
@@ -1990,7 +1991,8 @@ struct GemmKnobs {
     int sk_mink;       // "gemm_sk_mink"    DEVIAS_GEMM_SK_MINK  ... and at least this many K-tiles per output tile (default 32)
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
     int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K)
-    int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups
+    int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups (1), whose idle waves
+                       //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
     int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
                        //                                        15 = all four); a served call is not considered for stream-K
     int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent / stream-K grids leave this many CUs free (default 0).  Their static tile
@@ -2014,7 +2016,7 @@ GemmKnobs& knobs() {
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
         x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
         x.w4 = env_int("DEVIAS_GEMM_W4", 0);
-        x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 1);
+        x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 2);
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);

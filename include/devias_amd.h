@@ -69,8 +69,8 @@ const char* devias_last_error(void);
 int64_t devias_counter(int32_t id);          /* -1 for an unknown id */
 void devias_counters_reset(void);
 /* Process-wide integer options (initialised once from the DEVIAS_* environment variables of the same meaning): "gemm_epi",
- * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_tail_split" (1, default: the tiles of a persistent launch's last partial round are computed as
- * 128-row halves by two workgroups when at least half the CUs would idle), "gemm_streamk" (0 = never, default; 1 = by policy; 3 = wherever it can run), "gemm_sk_eff",
+ * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_tail_split" (2, default: the tiles of a persistent launch's last partial round are computed as
+ * 128-row halves by two workgroups when at least half the CUs would idle, their idle waves staging no A rows; 1: staging all rows; 0: whole tiles), "gemm_streamk" (0 = never, default; 1 = by policy; 3 = wherever it can run), "gemm_sk_eff",
  * "gemm_sk_mink", "gemm_smallm" (1, default: bf16 products with M <= 128 and B k-contiguous run as ONE launch of the small-M kernel instead of split-K
  * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves, default 0), "gemm_debug", "gemm_reserve_cus" (CUs the persistent GEMM grids
  * leave free for a concurrent kernel, e.g. RCCL's during backward), "attn_cfg", "attn_xcd".  Every choice except gemm_smallm computes the same bits.  0 = ok, DEVIAS_EINVAL = unknown name. */

@@ -422,7 +422,7 @@ def gemm_options():
     """restores the process-wide kernel-selection options a test changes"""
     o = ops()
     yield o
-    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 0), ("gemm_w4", 0), ("gemm_tail_split", 1), ("gemm_smallm", 1)):
+    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 0), ("gemm_w4", 0), ("gemm_tail_split", 2), ("gemm_smallm", 1)):
         o.set_option(k, v)
 
 
@@ -468,11 +468,11 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         kw = dict(act=ACT_DGELU, aux_in=pre); ref = ref * dg
     outs = {}
     serves = _persistent_serves(tb, epi)
-    # stream-K; persistent (eight waves with / without the tail split, four waves); one tile per workgroup with the register-transposed / the LDS-staged epilogue
-    for mode in ("sk", "p", "p0", "w", "0", "0s"):
+    # stream-K; persistent (eight waves with the tail split in both forms / without it, four waves); one tile per workgroup with the register-transposed / the LDS-staged epilogue
+    for mode in ("sk", "p", "p1", "p0", "w", "0", "0s"):
         o.set_option("gemm_streamk", 3 if mode == "sk" else 0)
-        o.set_option("gemm_persistent", 1 if mode in ("sk", "p", "p0", "w") else 0)
-        o.set_option("gemm_tail_split", 0 if mode == "p0" else 1)
+        o.set_option("gemm_persistent", 1 if mode in ("sk", "p", "p1", "p0", "w") else 0)
+        o.set_option("gemm_tail_split", {"p0": 0, "p1": 1}.get(mode, 2))
         o.set_option("gemm_w4", 15 if mode == "w" else 0)
         o.set_option("gemm_epi", 0 if mode.endswith("s") else 1)
         kw2 = dict(kw)
@@ -484,22 +484,22 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         c = o.gemm(A, B, trans_b=tb, **kw2)
         torch.cuda.synchronize()
         cnt = o.counters()
-        want = {"sk": (1, 0, 0), "p": (0, 1, 0), "p0": (0, 1, 0), "w": (0, 1, 0)}.get(mode if serves else "0", (0, 0, 1))
+        want = {"sk": (1, 0, 0), "p": (0, 1, 0), "p1": (0, 1, 0), "p0": (0, 1, 0), "w": (0, 1, 0)}.get(mode if serves else "0", (0, 0, 1))
         assert (cnt["gemm_sk"], cnt["gemm256p"], cnt["gemm256"]) == want, (mode, cnt)
         assert cnt["gemm256w"] == (1 if mode == "w" and serves and K >= 128 else 0), (mode, cnt)       # (one K-tile: the eight-wave kernel)
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
     assert o.streamk_timeouts() == 0
     c, aux, cs = outs["0"]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]
-    for mode in ("sk", "p", "p0", "w", "0s"):
+    for mode in ("sk", "p", "p1", "p0", "w", "0s"):
         assert torch.equal(c, outs[mode][0]), mode
     if aux is not None:
         assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16]
-        for mode in ("sk", "p", "p0", "w", "0s"):
+        for mode in ("sk", "p", "p1", "p0", "w", "0s"):
             assert torch.equal(aux, outs[mode][1]), mode
     if cs is not None:
         assert rel(cs, c.float().sum(0)) < 1e-2                 # sums the fp32 values before bf16 rounding
-        for mode in ("sk", "p", "p0", "w", "0s"):
+        for mode in ("sk", "p", "p1", "p0", "w", "0s"):
             assert rel(cs, outs[mode][2]) < 1e-5, mode
 
 
