@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the DEVIAS slot-ViT training step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a torchrun environment: starts its own N ranks as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = student forward (a1-a13) + fused matching loss (a14) + full backward to every parameter gradient
@@ -123,8 +123,29 @@ def dominant_kernel_probe(args, device):
     return probe
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves, as a CHILD process
+    (`python -m torch.distributed.run`, the launch of docs/TRAIN.md:21-24 on one node), BEFORE this process has made any GPU call
+    (a process that has initialised the GPU must never exec, and does not need to: the parent only relays).  The child's stdout
+    (rank 0's JSON line) and stderr (RCCL banner) are inherited; the parent exits with the child's return code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                           # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     from devias_amd import synth
     from devias_amd.parallel import GradSync, init_distributed_from_env
     from devias_amd.train_loss import TrainLoss
@@ -132,7 +153,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
+    if world > 1 and os.environ.get("DEVIAS_BENCH_TRACE_LAUNCH"):
+        print(f"bench.py rank {rank}/{world} joined the process group ({dist.get_backend()})", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
     device = torch.device("cuda", local % torch.cuda.device_count())     # (ranks > GPUs only happens in the gloo plumbing test)

@@ -344,3 +344,31 @@ def test_slot_model_gradsync_world1_on_gpu():
     got = _slot_hip_grads(dev, [0, 2], sync=lambda m: GradSync(m, bucket_bytes=1 << 20))
     for n in ref:
         assert torch.allclose(got[n], ref[n], rtol=1e-6, atol=1e-9), n
+
+
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts `torch.distributed.run` as a
+    child before any GPU call, both ranks rendezvous (gloo here), and -- this container having no MI355X -- every rank stops at the
+    loud "needs an MI355X" exit AFTER init_process_group; the parent relays the child's non-zero return code."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DEVIAS_DIST_BACKEND"] = "gloo"
+    env["DEVIAS_BENCH_TRACE_LAUNCH"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    err = r.stderr
+    assert "launching 2 ranks" in err and "torch.distributed.run" in err, err[-2000:]
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, err[-2000:]
+        import json
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2
+        return
+    for rank in (0, 1):
+        assert f"bench.py rank {rank}/2 joined the process group" in err, err[-2000:]
+    if not torch.cuda.is_available():
+        assert "needs an MI355X" in err, err[-2000:]
+        assert r.returncode != 0
