@@ -85,7 +85,7 @@ def cpu_baseline(args):
     dt = (time.perf_counter() - t0) / args.cpu_steps
     return {"value": B / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle/ref_cpu.py student fwd+loss+bwd, B={B} clips x {args.cpu_steps} timed steps (+1 warm-up), fp32, "
-                      f"{args.model} {args.frames}x{args.img_size}^2"}
+                      f"{args.model} {args.frames}x{args.img_size}^2, {torch.get_num_threads()} of {os.cpu_count()} host cores (PyTorch CPU kernels stop scaling beyond)"}
 
 
 def dominant_kernel_probe(args, device):

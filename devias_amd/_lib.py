@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DEVIAS_LIB_PATH") or os.path.join(_HERE, "libdevias_amd.so")     # (override: ablation builds of tools/)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 150                # devias_version() of the library these prototypes describe
+ABI_VERSION = 160                # devias_version() of the library these prototypes describe
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4, 5
 
 
@@ -40,7 +40,7 @@ class GemmArgs(Structure):
 
 class LossDims(Structure):
     _fields_ = [(n, c_int32) for n in ("B", "S", "C", "nb", "ns", "D", "G", "N", "nh")] + \
-               [("w_scene", c_float), ("w_mask_pred", c_float), ("w_mask_distill", c_float), ("dtype", c_int32)]
+               [("w_scene", c_float), ("w_mask_pred", c_float), ("w_mask_distill", c_float), ("dtype", c_int32), ("scene_ce", c_int32)]
 
 
 _FP = POINTER(c_float)
@@ -107,6 +107,7 @@ PROTOTYPES = {
     "devias_gemm_streamk_workspace_bytes": (c_int64, []),
     "devias_gemm_streamk_error_offset": (c_int64, []),
     "devias_cast": (c_int, [_P, _I, _P, _I, _L, _P]),
+    "devias_cast_scale": (c_int, [_P, _I, _P, _I, _L, c_float, _P]),
     "devias_patch_im2col": (c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "devias_colsum": (c_int, [_P, _I, _I, _I, _I, _P, _F, _P, _P]),
     "devias_colsum_workspace_bytes": (c_int64, [_I, _I]),
@@ -165,7 +166,7 @@ PROTOTYPES = {
     "devias_policy_wgrad_split": (c_int32, [_I, _I, _I, _I]),
 }
 COUNTERS = {"gemm128_f32": 0, "gemm128_bf16": 1, "gemm_ss": 2, "gemm256": 3, "gemm256p": 4, "splitk_reduce": 5,
-            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10, "gemm_sk": 11, "gemm256w": 12, "gemm_smallm": 13}     # DEVIAS_CNT_*
+            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10, "gemm_sk": 11, "gemm256w": 12, "gemm_smallm": 13, "gemm256d": 14}     # DEVIAS_CNT_*
 OPT_CHUNK = 16384          # DEVIAS_OPT_CHUNK
 OPT_TENSOR_BYTES = 64      # sizeof(devias_opt_tensor)
 

@@ -1007,12 +1007,7 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
         const int xcd = attn_xcd_flag(B, H);
         devias_count(DEVIAS_CNT_MHSA_FWD_BF16);
 #define FWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
-        if (cfg == 1) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 2, false>), FWD_GRID(128), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
-        else if (cfg == 2) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<4, 4, false>), FWD_GRID(256), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
-        else if (cfg == 3) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 2, false>), FWD_GRID(64), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
-        else if (cfg == 4) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, false>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
-        else if (cfg == 5) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true, 4>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
-        else if (cfg == 6) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        if (cfg == 6) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
         else if (cfg == 7) hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<2>), FWD_GRID(64), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
         // default (measured at B = 32, H = 12, N = 1568, same box): 32x32x16 kernel 302 us against 334-345 us for the 16x16x32 kernel (cfg 6)
         else hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<4>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);

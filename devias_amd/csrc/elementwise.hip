@@ -26,6 +26,19 @@ __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int6
     }
 }
 
+template <typename S, typename D>
+__global__ void cast_scale_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n, int vec, float scale) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        int64_t n4 = n >> 2;
+        for (int64_t i = i0; i < n4; i += stride) store4(dst + 4 * i, load4(src + 4 * i) * scale);
+        for (int64_t i = (n4 << 2) + i0; i < n; i += stride) dst[i] = from_f32<D>(to_f32(src[i]) * scale);
+    } else {
+        for (int64_t i = i0; i < n; i += stride) dst[i] = from_f32<D>(to_f32(src[i]) * scale);
+    }
+}
+
 // ---- im2col -----------------------------------------------------------------------------------------
 // one thread moves 4 consecutive kw pixels (ps % 4 == 0): 16-byte fp32 reads, 8-byte bf16 writes
 template <typename S, typename D>
@@ -278,6 +291,20 @@ extern "C" int devias_cast(const void* src, int32_t sd, void* dst, int32_t dd, i
     else if (sd == DEVIAS_BF16 && dd == DEVIAS_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), g, b, 0, st, (const bf16*)src, (bf16*)dst, n, vec);
     else return devias_set_error(DEVIAS_EINVAL, "devias_cast: bad dtypes %d -> %d", sd, dd);
     DEVIAS_CHECK_LAUNCH("devias_cast");
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_cast_scale(const void* src, int32_t sd, void* dst, int32_t dd, int64_t n, float scale, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DEVIAS_REQUIRE(src && dst && n >= 0, "devias_cast_scale: bad args");
+    if (n == 0) return DEVIAS_OK;
+    int vec = aligned16(src) && aligned16(dst);
+    dim3 g(grid_for(n, 4)), b(256);
+    if (sd == DEVIAS_F32 && dd == DEVIAS_F32) hipLaunchKernelGGL((cast_scale_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n, vec, scale);
+    else if (sd == DEVIAS_BF16 && dd == DEVIAS_F32) hipLaunchKernelGGL((cast_scale_kernel<bf16, float>), g, b, 0, st, (const bf16*)src, (float*)dst, n, vec, scale);
+    else if (sd == DEVIAS_F32 && dd == DEVIAS_BF16) hipLaunchKernelGGL((cast_scale_kernel<float, bf16>), g, b, 0, st, (const float*)src, (bf16*)dst, n, vec, scale);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_cast_scale: bad dtypes %d -> %d", sd, dd);
+    DEVIAS_CHECK_LAUNCH("devias_cast_scale");
     return DEVIAS_OK;
 }
 

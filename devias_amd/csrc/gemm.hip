@@ -39,6 +39,10 @@ struct GemmP {
     int tail_split;       // gemm256p_kernel: split the tiles of the last partial round between two workgroups (128-row halves)
     int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
     float* sk_part; unsigned long long* sk_flag; unsigned long long sk_epoch;   // stream-K kernel: partial slots, flags (+ error word), this launch's tag
+    // dynamic tile queue of gemm256p_kernel<.., true>: this launch's 8 per-XCD queue heads (one per 128-byte line, all zero when the launch starts),
+    // the ring slot this launch zeroes for a later one, and the item list of a queue (nwhole whole tiles, then the halves of the split tail tiles)
+    // for the two queue lengths that occur: [0] = queues of ntiles / 8 + 1 tiles, [1] = of ntiles / 8
+    unsigned int* tq; unsigned int* tq_clear; int tq_nwhole[2], tq_items[2];
 };
 
 #ifdef DEVIAS_GEMM_DEBUG
@@ -913,9 +917,37 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
 // Tile order: XCD x (block ids congruent to x mod 8) owns the same contiguous range of logical tiles as in xcd_remap; its G/8 workgroups
 // stride through it together, so at any moment an XCD works on ~32 consecutive tiles (operand panels shared in its L2).
 // =====================================================================================================================
-template <bool TB, int SIDE>
+// ---- dynamic tile queue (DYN): the published-item word and the dequeue -----------------------------------------------------------------
+// Ring of queue-head slots in the code object (zero at load): launch n uses slot n % TQ_RING and zeroes slot (n + TQ_RING / 2) % TQ_RING for the launch
+// that will use it TQ_RING / 2 launches later (stream order makes the zeroes land long before; no reset pass, no host memset).
+enum { TQ_RING = 64, TQ_LINE = 32 /* uint32 per head: one 128-byte line each */, TQ_NONE = 0x0fffffff };
+__device__ unsigned int g_tile_queue[TQ_RING][8][TQ_LINE];
+
+// one returning agent-scope add by lane 0 of the calling wave, issued from inline asm under a hand-set EXEC mask: invisible to the compiler's wait insertion
+// (a visible pending load would turn the K loop's counted waits into vmcnt(0) drains); the ticket is usable after the caller's next s_waitcnt vmcnt(0)
+__device__ __forceinline__ void tq_issue(unsigned& ticket, unsigned int* heads, int queue) {
+    const unsigned voff = (unsigned)queue * (TQ_LINE * 4), one = 1u;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                 : "+v"(ticket), "=&s"(save) : "v"(voff), "v"(one), "s"(heads) : "memory");
+}
+__device__ __forceinline__ void tq_publish(char* word, unsigned seq, int code) {
+    const unsigned v = ((seq & 15u) << 28) | ((unsigned)code & 0x0fffffffu);
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)word;
+    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
+}
+// the item published for position `seq` of this workgroup's item stream: >= 0 (queue << 20 | index), TQ_NONE, or -2 = not published (yet)
+__device__ __forceinline__ int tq_read(const char* word, unsigned seq) {
+    unsigned v;
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)word;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    v = __builtin_amdgcn_readfirstlane(v);
+    return (v >> 28) == (seq & 15u) ? (int)(v & 0x0fffffffu) : -2;
+}
+
+template <bool TB, int SIDE, bool DYN>
 __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2 + (DYN ? 16 : 0)];     // (+ the published next item: ONE LDS object, see the stream-K note)
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef DEVIAS_GEMM_DEBUG
     const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
@@ -933,7 +965,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     const int cnt = q + (xcd < r ? 1 : 0);
     const int li0 = blockIdx.x >> 3;
     int li = li0;
-    if (li >= cnt) return;
+    if constexpr (!DYN) { if (li >= cnt) return; }
     auto coords = [&](int l, int& m0, int& n0) {
         int tm, tn;
         tile_coords(base + l, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
@@ -945,7 +977,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     // tile's K loop takes a bit more than half its time; every output element is computed by the same wave code as before (bitwise equal).
     const int rfull = cnt / stride, rem = cnt - rfull * stride;
     const bool split = p.tail_split != 0 && rfull >= 1 && rem > 0 && 2 * rem <= stride;
-    // this workgroup's k-th tile: (logical index, half: -1 = whole tile); false = none
+    // STATIC list (DYN = false): this workgroup's k-th tile: (logical index, half: -1 = whole tile); false = none
     auto tile_at = [&](int k, int& l, int& half) -> bool {
         half = -1;
         if (k < rfull) { l = li0 + k * stride; return true; }
@@ -955,23 +987,50 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
         l = rfull * stride + li0;
         return true;
     };
+    // DYNAMIC queue (DYN = true).  Item i of XCD queue y: the whole tile base_y + i for i < nwhole_y, then the two 128-row halves of each tail tile (the same
+    // items the static list hands out; only WHO computes an item is decided at run time).  A workgroup pulls from its own XCD's queue (operand panels stay
+    // shared in that L2) and, once that is empty, from the next XCDs' in turn: a CU that another kernel holds (RCCL's during backward) or slows down just
+    // pulls fewer items -- the workgroup that finds no CU until the others have finished finds every queue empty and leaves.  Which workgroup computes a tile
+    // does not change a bit of it.  Everything happens at the TILE SWITCH, where the accumulators are dead (the K loop is the static kernel's, untouched):
+    // a workgroup always holds its current item and the next one (whose first K-tile the stream prefetches); the dequeue for the one after that is issued
+    // by wave 0 when `next` becomes known and has a whole tile's time to return; at the switch wave 0 reads the ticket, publishes the item through the LDS
+    // word behind the ring, issues the following dequeue, and after one more barrier every wave decodes it.  Only a workgroup's first two items, and
+    // probes of further queues at the very end of a launch, are waited for.
+    char* const tq_word = smem + 2 * STAGE2;
+    auto qgeom = [&](int y, int& qbase, int& nwhole, int& items) {
+        qbase = y < r ? y * (q + 1) : r * (q + 1) + (y - r) * q;
+        nwhole = y < r ? p.tq_nwhole[0] : p.tq_nwhole[1];
+        items = y < r ? p.tq_items[0] : p.tq_items[1];
+    };
+    auto decode = [&](int code, int& m0, int& n0, int& half) {
+        const int y = code >> 20, i = code & 0xfffff;
+        int qbase, nwhole, items;
+        qgeom(y, qbase, nwhole, items);
+        const int l = i < nwhole ? i : nwhole + ((i - nwhole) >> 1);
+        half = i < nwhole ? -1 : ((i - nwhole) & 1);
+        int tm, tn;
+        tile_coords(qbase + l, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+        m0 = tm * T2; n0 = tn * T2;
+    };
+    int fq = xcd, ftried = 0;                              // wave 0: the queue being pulled from, queues seen empty
+    unsigned ticket = 0, seq = 0;                          // seq = items published to this workgroup so far
+    // wave 0, after a wait that covers the dequeue: found item (>= 0), TQ_NONE (all eight queues empty), or -2 = that queue was empty, try the next one
+    auto settle = [&]() -> int {
+        const int t = (int)__builtin_amdgcn_readfirstlane(ticket);
+        int qbase, nwhole, items;
+        qgeom(fq, qbase, nwhole, items);
+        if (t < items) return (fq << 20) | t;
+        fq = (fq + 1) & 7;
+        return ++ftried >= 8 ? (int)TQ_NONE : -2;
+    };
+    if constexpr (DYN) {
+        if (blockIdx.x == 0 && tid < 8)                    // (from asm: the compiler's wait insertion never sees a store pending)
+            asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"((unsigned)tid * (TQ_LINE * 4)), "v"(0u), "s"(p.tq_clear) : "memory");
+    }
     int tk = 0, half = -1, halfn = -1;
-    int m0, n0;
-    (void)tile_at(0, li, half);
-    coords(li, m0, n0);
-    glds_tile<false>(A, p.lda, m0, 0, smem, wave, lane);
-    glds_tile<TB>(B, p.ldb, n0, 0, smem + 32768, wave, lane);
-    int ln = li;
-    bool has_next = tile_at(1, ln, halfn);
-    int m0n = m0, n0n = n0;
-    if (has_next) coords(ln, m0n, n0n);
-    bool act = half < 0 || wm == half;                    // (wave-uniform)
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int m0 = 0, n0 = 0, m0n = 0, n0n = 0;
+    bool has_next = false;
+    int ncode = -2;
 #ifdef DEVIAS_GEMM_DEBUG
     // gemm_debug & 8: thread 0 logs (100 MHz clock << 4 | code) into ws + 64 * blockIdx.x: 1 = first K-tile of a tile about to be multiplied,
     // 2 = K loop done, 3 = epilogue done (stores issued), 4 = first K-iteration of the next tile done (its wait passed)
@@ -992,61 +1051,130 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
 #else
 #define PSTAMP(c)
 #endif
-    // ONE flat loop over the K-tile stream (ring stage = g & 1); the wait for K-tile g + 1 sits at the END of iteration g so that the loop has
-    // no first-iteration special case (a peeled copy is where the compiler re-inserts full vmcnt drains)
-    for (int g = 0, kt = 0;; ++g) {
-        __builtin_amdgcn_s_barrier();                      // K-tile g has landed for every wave, and everyone is done reading stage (g + 1) & 1
-        asm volatile("" ::: "memory");
-        if (kt == 0) { PSTAMP(1); PSTAMP(9); }
-        char* cur = smem + (g & 1) * STAGE2;
-        char* nxt = smem + ((g + 1) & 1) * STAGE2;
-        // source of K-tile g + 1: this tile's next one, or the next tile's first; at the very end a harmless re-read
-        const bool same = kt + 1 < nk;
-        const int am = (same || !has_next) ? m0 : m0n, bn = (same || !has_next) ? n0 : n0n;
-        const int kn = same ? (kt + 1) * 64 : (has_next ? 0 : kt * 64);
-        // the lane id is recomputed per K-tile (v_mbcnt) and made opaque: the per-lane LDS / LDS-DMA offsets derived from it are then cheap VALU work of
-        // every iteration instead of registers that stay live across the epilogue, whose register peak is the kernel's (-14 registers)
-        int lane_k = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        asm volatile("" : "+v"(lane_k));
-        if constexpr (!TB) {
-            if (act) ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
-            else {                                         // the other half's waves of a split tail tile: staging only -- and of B only: the A rows a wave
-                                                           // stages (32 wave + ...) are the rows of ITS half, which nobody multiplies (tail_split >= 2)
-                if (p.tail_split < 2) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
-                glds_tile<false>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
-            }
+    f32x4 acc[8][4];
+    // wave 0: pull until an item is found or all eight queues are empty, each dequeue waited for (the first item of a workgroup; later ones only when
+    // the dequeue issued under the K loop had not found one in time -- fewer K-tiles per tile than queues left to probe, at the very end of a launch)
+    auto pull_waited = [&](int c) -> int {
+        while (c == -2) {
+            tq_issue(ticket, p.tq, fq);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
+            c = settle();
+        }
+        return c;
+    };
+    {
+        if constexpr (!DYN) {
+            (void)tile_at(0, li, half);
+            coords(li, m0, n0);
         } else {
-            if (act || p.tail_split < 2) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
-            glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
-            if (act) ktile_generic<false, true>(acc, cur, lane_k, wm, wn);
+            if (wave == 0) {                               // the first two items: waited for; then the third is requested
+                const int c0 = pull_waited(-2);
+                const int c1 = c0 == (int)TQ_NONE ? c0 : pull_waited(ftried >= 8 ? (int)TQ_NONE : -2);
+                tq_publish(tq_word, 0, c0);
+                tq_publish(tq_word + 4, 1, c1);
+                if (c1 != (int)TQ_NONE && ftried < 8) tq_issue(ticket, p.tq, fq);
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int code = tq_read(tq_word, 0);
+            if (code == (int)TQ_NONE) return;              // every queue was empty: this workgroup came too late to be needed
+            decode(code, m0, n0, half);
+            ncode = tq_read(tq_word + 4, 1);
+            has_next = ncode != (int)TQ_NONE;
+            m0n = m0; n0n = n0;
+            if (has_next) decode(ncode, m0n, n0n, halfn);
+            seq = 2;
         }
-        if (same) {
-            ++kt;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA for K-tile g + 1 has landed
-            if (kt == 1) PSTAMP(4);
-            continue;
+        glds_tile<false>(A, p.lda, m0, 0, smem, wave, lane);
+        glds_tile<TB>(B, p.ldb, n0, 0, smem + 32768, wave, lane);
+        if constexpr (!DYN) {
+            int ln = li;
+            has_next = tile_at(1, ln, halfn);
+            m0n = m0; n0n = n0;
+            if (has_next) coords(ln, m0n, n0n);
         }
-        PSTAMP(2); PSTAMP(10);
-        int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
-        if (act) epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
-        if (!has_next) break;
-        // the epilogue issued >= 16 stores per wave AFTER the DMA of the next tile's first K-tile: wait for the DMA only, the stores drain under the next MFMAs
-        // (a tile with a successor is a whole tile: every wave has run the epilogue)
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        PSTAMP(3);
-        kt = 0;
-        ++tk;
-        li = ln; m0 = m0n; n0 = n0n; half = halfn;
-        act = half < 0 || wm == half;
-        has_next = tile_at(tk + 1, ln, halfn);
-        if (has_next) coords(ln, m0n, n0n);
+        bool act = half < 0 || wm == half;                    // (wave-uniform)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ONE flat loop over the K-tile stream (ring stage = g & 1); the wait for K-tile g + 1 sits at the END of iteration g so that the loop has
+        // no first-iteration special case (a peeled copy is where the compiler re-inserts full vmcnt drains)
+        for (int g = 0, kt = 0;; ++g) {
+            __builtin_amdgcn_s_barrier();                      // K-tile g has landed for every wave, and everyone is done reading stage (g + 1) & 1
+            asm volatile("" ::: "memory");
+            if (kt == 0) { PSTAMP(1); PSTAMP(9); }
+            char* cur = smem + (g & 1) * STAGE2;
+            char* nxt = smem + ((g + 1) & 1) * STAGE2;
+            // source of K-tile g + 1: this tile's next one, or the next tile's first; at the very end a harmless re-read
+            const bool same = kt + 1 < nk;
+            const int am = (same || !has_next) ? m0 : m0n, bn = (same || !has_next) ? n0 : n0n;
+            const int kn = same ? (kt + 1) * 64 : (has_next ? 0 : kt * 64);
+            // the lane id is recomputed per K-tile (v_mbcnt) and made opaque: the per-lane LDS / LDS-DMA offsets derived from it are then cheap VALU work of
+            // every iteration instead of registers that stay live across the epilogue, whose register peak is the kernel's (-14 registers)
+            int lane_k = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane_k));
+            if constexpr (!TB) {
+                if (act) ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
+                else {                                         // the other half's waves of a split tail tile: staging only -- and of B only: the A rows a wave
+                                                               // stages (32 wave + ...) are the rows of ITS half, which nobody multiplies (tail_split >= 2)
+                    if (p.tail_split < 2) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
+                    glds_tile<false>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
+                }
+            } else {
+                if (act || p.tail_split < 2) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
+                glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
+                if (act) ktile_generic<false, true>(acc, cur, lane_k, wm, wn);
+            }
+            if (same) {
+                ++kt;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA for K-tile g + 1 has landed (and, DYN, wave 0's dequeue has returned)
+                if (kt == 1) PSTAMP(4);
+                continue;
+            }
+            PSTAMP(2); PSTAMP(10);
+            int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
+            if (act) epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
+            if (!has_next) break;
+            // the epilogue issued >= 16 stores per wave AFTER the DMA of the next tile's first K-tile: wait for the DMA only, the stores drain under the next MFMAs.
+            // (Static list: a tile with a successor is a whole tile, every wave has run the epilogue.  Dynamic queue: a half tile can be followed by an item
+            // pulled from another XCD's queue; the waves that only staged it have no stores behind their DMA and wait for everything.)
+            if (DYN && !act) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            PSTAMP(3);
+            kt = 0;
+            ++tk;
+            m0 = m0n; n0 = n0n; half = halfn;
+            act = half < 0 || wm == half;
+            if constexpr (!DYN) {
+                int ln = li;
+                has_next = tile_at(tk + 1, ln, halfn);
+                if (has_next) coords(ln, m0n, n0n);
+            } else {
+                // the item after `next`: its dequeue was issued a tile ago and every K-iteration's vmcnt(0) since has covered it (nk >= 2, checked by the host)
+                if (wave == 0) {
+                    asm volatile("" : "+v"(ticket));           // (the ticket is read here, not where the compiler last saw it written)
+                    int c = ftried >= 8 ? (int)TQ_NONE : settle();
+                    if (c == -2) c = pull_waited(ftried >= 8 ? (int)TQ_NONE : -2);
+                    tq_publish(tq_word, seq, c);
+                    if (c != (int)TQ_NONE && ftried < 8) tq_issue(ticket, p.tq, fq);
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                ncode = tq_read(tq_word, seq);
+                ++seq;
+                has_next = ncode != (int)TQ_NONE;
+                if (has_next) decode(ncode, m0n, n0n, halfn);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing re-read must land before the LDS is released
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing re-read must land before the LDS is released
 }
 
 
@@ -1995,6 +2123,8 @@ struct GemmKnobs {
                        //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
     int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
                        //                                        15 = all four); a served call is not considered for stream-K
+    int dynamic;       // "gemm_dynamic"    DEVIAS_GEMM_DYNAMIC  1 (default): the persistent kernel's workgroups pull their tiles from per-XCD queues at run time
+                       //                                        (robust to CUs held or slowed by a concurrent kernel); 0 = the static per-workgroup tile lists
     int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent / stream-K grids leave this many CUs free (default 0).  Their static tile
                        //                                        lists assume one resident workgroup per CU of the grid: with K CUs held by another kernel
                        //                                        (RCCL during backward at N > 1) the K workgroups that find no CU run AFTER the others --
@@ -2015,6 +2145,7 @@ GemmKnobs& knobs() {
         x.sk_mink = env_int("DEVIAS_GEMM_SK_MINK", 32);
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
         x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
+        x.dynamic = env_int("DEVIAS_GEMM_DYNAMIC", 1);
         x.w4 = env_int("DEVIAS_GEMM_W4", 0);
         x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 2);
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
@@ -2027,6 +2158,21 @@ GemmKnobs& knobs() {
     return k;
 }
 }  // namespace
+
+// device address of the tile-queue ring of the CURRENT device's copy of the code object (resolved once per device)
+static unsigned int* tile_queue_base() {
+    static std::atomic<unsigned int*> cache[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    unsigned int* b = cache[dev].load(std::memory_order_acquire);
+    if (!b) {
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tile_queue)) != hipSuccess || !sym) { (void)hipGetLastError(); return nullptr; }
+        b = reinterpret_cast<unsigned int*>(sym);
+        cache[dev].store(b, std::memory_order_release);
+    }
+    return b;
+}
 
 // CUs the big-tile grids may count on: the device's, minus the reserve (option gemm_reserve_cus), in whole XCD rows
 extern "C" int32_t devias_policy_gemm_cus(void) {
@@ -2049,6 +2195,7 @@ int devias_gemm_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_tail_split")) k.tail_split = value;
     else if (!strcmp(name, "gemm_smallm")) k.smallm = value;
     else if (!strcmp(name, "gemm_reserve_cus")) k.reserve = value < 0 ? 0 : value;
+    else if (!strcmp(name, "gemm_dynamic")) k.dynamic = value;
     else return 0;
     return 1;
 }
@@ -2109,6 +2256,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     p.tail_split = kn.tail_split;
     p.epi_swap = kn.epi_swap;
     p.sk_part = nullptr; p.sk_flag = nullptr; p.sk_epoch = 0;
+    p.tq = nullptr; p.tq_clear = nullptr; p.tq_nwhole[0] = p.tq_nwhole[1] = p.tq_items[0] = p.tq_items[1] = 0;
     // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
     // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
     p.group_m = kn.group_m > 0 ? kn.group_m : ((!a->trans_a && a->N >= 2048) ? 8 : 1);
@@ -2179,9 +2327,11 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         const bool pers_ok = !ta && split == 1 && !p.c_f32 && p.epi_swap && gp >= 8 && !(a->res && dact) && (!tb ? side != 2 : side != 1) &&
                              (!a->row_scale || p.rows_per_scale >= 128) && !(side == 2 && a->bias) && !(side == 1 && a->colsum) &&
                              !(side != 0 && a->aux_out);
-#define PERS_LAUNCH(KERNEL) do { \
-            if (!tb) { if (side == 0) hipLaunchKernelGGL((KERNEL<false, 0>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<false, 1>), grid, block, 0, st, p); } \
-            else { if (side == 0) hipLaunchKernelGGL((KERNEL<true, 0>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<true, 2>), grid, block, 0, st, p); } } while (0)
+#define PERS_LAUNCH(KERNEL, ...) do { \
+            if (!tb) { if (side == 0) hipLaunchKernelGGL((KERNEL<false, 0 __VA_ARGS__>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<false, 1 __VA_ARGS__>), grid, block, 0, st, p); } \
+            else { if (side == 0) hipLaunchKernelGGL((KERNEL<true, 0 __VA_ARGS__>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<true, 2 __VA_ARGS__>), grid, block, 0, st, p); } } while (0)
+#define COMMA_TRUE , true
+#define COMMA_FALSE , false
         // stream-K form: the caller lent a partial-slot workspace, every XCD group has at least one tile per workgroup, and the tile count is
         // not a multiple of the grid (otherwise it degenerates to the persistent kernel's schedule)
         // stream-K form: the caller lent a partial-slot workspace, every XCD group has at least one tile per workgroup, and (policy, measured at
@@ -2215,7 +2365,27 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
             devias_count(DEVIAS_CNT_GEMM256W);
         } else if (kn.persistent && pers_ok && nt > gp) {
             dim3 grid(gp), block(NT2);
-            PERS_LAUNCH(gemm256p_kernel);
+            unsigned int* tq = (kn.dynamic && a->K >= 128) ? tile_queue_base() : nullptr;      // (>= 2 K-tiles per tile: their waits cover the dequeue)
+            if (tq) {
+                // dynamic tile queue (default): the item list of an XCD queue of cnt tiles -- whole tiles, then the halves of a split partial round --
+                // for the two queue lengths that occur; this launch's ring slot and the one it zeroes
+                static std::atomic<unsigned> seq{0};
+                const unsigned n = seq.fetch_add(1);
+                p.tq = tq + (size_t)(n % TQ_RING) * 8 * TQ_LINE;
+                p.tq_clear = tq + (size_t)((n + TQ_RING / 2) % TQ_RING) * 8 * TQ_LINE;
+                const int stride = gp >> 3;
+                for (int v = 0; v < 2; ++v) {
+                    const int cnt = (nt >> 3) + (v == 0 ? 1 : 0);
+                    const int rfull = cnt / stride, rem = cnt - rfull * stride;
+                    const bool split = kn.tail_split != 0 && rfull >= 1 && rem > 0 && 2 * rem <= stride;
+                    p.tq_nwhole[v] = split ? rfull * stride : cnt;
+                    p.tq_items[v] = split ? rfull * stride + 2 * rem : cnt;
+                }
+                PERS_LAUNCH(gemm256p_kernel, COMMA_TRUE);
+                devias_count(DEVIAS_CNT_GEMM256D);
+            } else {
+                PERS_LAUNCH(gemm256p_kernel, COMMA_FALSE);
+            }
             devias_count(DEVIAS_CNT_GEMM256P);
         } else {
             dim3 grid(nt, p.split_k), block(NT2);

@@ -1,4 +1,4 @@
-// Slot selection + TrainLoss ('matching', KL scene criterion) for gfx950: one workgroup per sample, everything on
+// Slot selection + TrainLoss ('matching', scene criterion KL or CE) for gfx950: one workgroup per sample, everything on
 // the device (the reference does B SciPy calls on the host plus six .item() syncs per step,
 // utils/loss/train_loss.py:112-122,183-187).  All statistics in fp32; reductions are wave shuffles + a 4-wave LDS combine.
 #include "common.h"
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(devias_loss_dims d, const
     const T* zi = Z + ((int64_t)b * S + is) * C;
     const T* zj = Z + ((int64_t)b * S + js) * C;
     const float act = s_lse[is] - to_f32(zi[y]);                               // CE, :150
-    // KL(T || softmax(Z_j)) with 'batchmean' on a 1-D input => / C  (:159-164)
+    // scene_criterion 'KL': KL(T || softmax(Z_j)) with 'batchmean' on a 1-D input => / C, times w_scene (:159-164);
+    // 'CE': cross-entropy of slot j* against the teacher's argmax class, NOT weighted (:155-156)
     float kl = 0.f;
     for (int c = threadIdx.x; c < C; c += 256) {
         float lt = (c < d.nb ? ts.pad : teacher[(int64_t)b * d.ns + c - d.nb]) - ts.lse;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(devias_loss_dims d, const
         kl += expf(lt) * (lt - lz);
         out_logits[(int64_t)b * C + c] = zi[c];
     }
-    kl = block_sum(kl, sm) * d.w_scene / (float)C;
+    kl = d.scene_ce ? s_lse[js] - to_f32(zj[st]) : block_sum(kl, sm) * d.w_scene / (float)C;
     // BCE-with-logits on the already-sigmoided prediction (double sigmoid, :146-149)
     float mp = 0.f;
     const T* mrow = maskp + ((int64_t)b * S + is) * d.G;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(devias_loss_dims d, const
     row_stats(Z + ((int64_t)b * S + is) * C, C, sm, mx, lse_i);
     row_stats(Z + ((int64_t)b * S + js) * C, C, sm, mx, lse_j);
     const float wk = d.w_scene / (float)C;
+    const int st = d.nb + ts.argmax;
     for (int s = 0; s < S; ++s) {
         const T* z = Z + ((int64_t)b * S + s) * C;
         T* dz = dZ + ((int64_t)b * S + s) * C;
@@ -214,8 +216,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(devias_loss_dims d, const
             float v = 0.f;
             if (s == is) v += g * (expf(to_f32(z[c]) - lse_i) - (c == y ? 1.f : 0.f));
             if (s == js) {
-                float lt = (c < d.nb ? ts.pad : teacher[(int64_t)b * d.ns + c - d.nb]) - ts.lse;
-                v += g * wk * (expf(to_f32(z[c]) - lse_j) - expf(lt));
+                if (d.scene_ce) v += g * (expf(to_f32(z[c]) - lse_j) - (c == st ? 1.f : 0.f));
+                else {
+                    float lt = (c < d.nb ? ts.pad : teacher[(int64_t)b * d.ns + c - d.nb]) - ts.lse;
+                    v += g * wk * (expf(to_f32(z[c]) - lse_j) - expf(lt));
+                }
             }
             dz[c] = from_f32<T>(v);
         }

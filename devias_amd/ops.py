@@ -180,11 +180,16 @@ def wgrad(dY: torch.Tensor, X: torch.Tensor, out: Optional[torch.Tensor] = None,
     return gemm(dY, X, trans_a=True, trans_b=True, out=out, out_f32=True, beta=beta, split_k=sk)
 
 
-def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """out = (dtype) src, or (dtype)(scale * src) when `scale` is given (out may be src for fp32 -> fp32)."""
     _chk(src, "cast.src")
     if out is None:
         out = torch.empty(src.shape, dtype=dtype, device=src.device)
     _chk(out, "cast.out", dtype)
+    if scale is not None:
+        _lib.check(_lib.load().devias_cast_scale(src.data_ptr(), dt_code(src.dtype), out.data_ptr(), dt_code(dtype), src.numel(), float(scale), _stream()),
+                   "devias_cast_scale")
+        return out
     _lib.check(_lib.load().devias_cast(src.data_ptr(), dt_code(src.dtype), out.data_ptr(), dt_code(dtype), src.numel(), _stream()),
                "devias_cast")
     return out
@@ -419,7 +424,7 @@ def slot_select(slots_head: torch.Tensor, B: int, S: int, nb: int) -> torch.Tens
     return idx
 
 
-def _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_md):
+def _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_md, scene_ce=False):
     d = _lib.LossDims()
     d.B = B
     d.S = slots_head.shape[0] // B
@@ -429,16 +434,17 @@ def _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_
     d.nh = attn.shape[0] // B
     d.w_scene, d.w_mask_pred, d.w_mask_distill = w_scene, w_mp, w_md
     d.dtype = dt_code(slots_head.dtype)
+    d.scene_ce = 1 if scene_ce else 0
     return d
 
 
-def head_match_loss_fwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN, nb, w_scene, w_mp, w_md):
+def head_match_loss_fwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN, nb, w_scene, w_mp, w_md, scene_ce=False):
     B = target.shape[0]
     for t, n, dt in ((slots_head, "slots_head", None), (slots, "slots", slots_head.dtype), (maskp, "maskp", slots_head.dtype),
                      (attn, "attn", torch.float32), (teacher, "teacher", torch.float32), (target, "target", torch.int64),
                      (fg, "fg", torch.float32), (fgN, "fgN", torch.float32)):
         _chk(t, "head_match_loss_fwd." + n, dt)
-    d = _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_md)
+    d = _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_md, scene_ce)
     dev = slots_head.device
     losses = torch.empty((6,), dtype=torch.float32, device=dev)
     match = torch.empty((B, 2), dtype=torch.int32, device=dev)
@@ -451,10 +457,10 @@ def head_match_loss_fwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN
     return losses, match, logits
 
 
-def head_match_loss_bwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN, match, g_total, nb, w_scene, w_mp, w_md):
+def head_match_loss_bwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN, match, g_total, nb, w_scene, w_mp, w_md, scene_ce=False):
     B = target.shape[0]
     _chk(g_total, "head_match_loss_bwd.g_total", torch.float32)
-    d = _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_md)
+    d = _loss_dims(slots_head, slots, maskp, attn, teacher, B, nb, w_scene, w_mp, w_md, scene_ce)
     dZ = torch.empty_like(slots_head)
     dslots = torch.empty_like(slots)
     dmask = torch.empty_like(maskp)

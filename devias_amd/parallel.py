@@ -61,8 +61,18 @@ class GradSync:
         self.flat: List[torch.Tensor] = []
         self._view = {}
         self._where = {}
+        # every bucket is a slice of ONE allocation (each starting on a 256-byte boundary): a bucket is still its own collective, but the mean's
+        # 1/world scale (and the widening of a bf16 wire format) is ONE launch over all of them in finish()
+        sizes = [sum(p.numel() for p in b) for b in self.buckets]
+        starts, tot = [], 0
+        for n in sizes:
+            starts.append(tot)
+            tot += (n + 63) // 64 * 64
+        self._all = torch.zeros(tot, dtype=torch.float32, device=params[0].device)
+        self._starts, self._sizes = starts, sizes
+        self._all_comm = None                          # bf16 wire image of _all (comm_dtype = bf16 only)
         for bi, b in enumerate(self.buckets):
-            flat = torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
+            flat = self._all[starts[bi]:starts[bi] + sizes[bi]]
             self.flat.append(flat)
             off = 0
             for p in b:
@@ -145,7 +155,9 @@ class GradSync:
         if self.comm_dtype == torch.float32:
             return flat
         if self._comm[bi] is None:
-            self._comm[bi] = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            if self._all_comm is None:
+                self._all_comm = torch.zeros(self._all.numel(), dtype=torch.bfloat16, device=flat.device)
+            self._comm[bi] = self._all_comm[self._starts[bi]:self._starts[bi] + self._sizes[bi]]
         if flat.is_cuda:
             from . import ops
             ops.cast(flat, torch.bfloat16, out=self._comm[bi])
@@ -184,16 +196,22 @@ class GradSync:
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         scale = (1.0 / self.world) if (self.world > 1 and self.average) else 1.0
-        for w, bi, buf in self._works:
-            flat = self.flat[bi]
-            if buf is not flat:                         # bf16 wire format: widen the sum back into the fp32 bucket
-                if flat.is_cuda:
-                    from . import ops
-                    ops.cast(buf, torch.float32, out=flat)
-                else:
+        wire = self.comm_dtype != torch.float32 and len(self._works) > 0
+        if self._all.is_cuda:
+            # every bucket was reduced this step (finish() launches the ones backward did not), so the widening of a bf16 wire format and the
+            # mean's 1/world are one library launch over the whole allocation (the padding between buckets is zeros on both sides)
+            from . import ops
+            if wire:
+                ops.cast(self._all_comm, torch.float32, out=self._all, scale=scale)
+            elif scale != 1.0:
+                ops.cast(self._all, torch.float32, out=self._all, scale=scale)
+        else:
+            for w, bi, buf in self._works:
+                flat = self.flat[bi]
+                if buf is not flat:                     # bf16 wire format: widen the sum back into the fp32 bucket
                     flat.copy_(buf)
-            if scale != 1.0:
-                flat.mul_(scale)
+                if scale != 1.0:
+                    flat.mul_(scale)
         self.reset()
 
     def remove(self):

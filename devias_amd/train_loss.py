@@ -13,11 +13,11 @@ LOSS_NAMES = ("action_loss", "scene_loss", "cosine_loss", "mask_prediction_loss"
 
 class HeadMatchLossFn(Function):
     @staticmethod
-    def forward(ctx, slots_head, slots, maskp, attn, teacher, target, fg, fgN, nb, w_scene, w_mp, w_md):
+    def forward(ctx, slots_head, slots, maskp, attn, teacher, target, fg, fgN, nb, w_scene, w_mp, w_md, scene_ce=False):
         slots_head, slots, maskp, attn = (t.contiguous() for t in (slots_head, slots, maskp, attn))
-        losses, match, logits = ops.head_match_loss_fwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN, nb, w_scene, w_mp, w_md)
+        losses, match, logits = ops.head_match_loss_fwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN, nb, w_scene, w_mp, w_md, scene_ce)
         ctx.saved = (slots_head, slots, maskp, attn, teacher, target, fg, fgN, match)
-        ctx.w = (nb, w_scene, w_mp, w_md)
+        ctx.w = (nb, w_scene, w_mp, w_md, scene_ce)
         ctx.mark_non_differentiable(losses, match, logits)
         total = losses[5:6].clone()
         return total, losses, match, logits
@@ -25,15 +25,15 @@ class HeadMatchLossFn(Function):
     @staticmethod
     def backward(ctx, g_total, *_):
         slots_head, slots, maskp, attn, teacher, target, fg, fgN, match = ctx.saved
-        nb, w_scene, w_mp, w_md = ctx.w
+        nb, w_scene, w_mp, w_md, scene_ce = ctx.w
         g = g_total.reshape(1).float().contiguous()
         dZ, dslots, dmask, dattn = ops.head_match_loss_bwd(slots_head, slots, maskp, attn, teacher, target, fg, fgN, match, g,
-                                                           nb, w_scene, w_mp, w_md)
-        return dZ, dslots, dmask, dattn, None, None, None, None, None, None, None, None
+                                                           nb, w_scene, w_mp, w_md, scene_ce)
+        return dZ, dslots, dmask, dattn, None, None, None, None, None, None, None, None, None
 
 
 class TrainLoss(nn.Module):
-    """Drop-in for utils.loss.train_loss.TrainLoss ('matching' + scene_criterion 'KL').
+    """Drop-in for utils.loss.train_loss.TrainLoss ('matching'; scene_criterion 'KL' or 'CE').
 
     forward(model, student_output, teacher_outputs, target, fg_mask) -> (total_loss[1], action_logit[B,C], loss_dict)
     `loss_dict` holds Python floats like the reference (MetricLogger asserts float, utils/utils.py:94), which costs ONE
@@ -45,8 +45,8 @@ class TrainLoss(nn.Module):
         super().__init__()
         if slot_matching_method != "matching":
             raise NotImplementedError("only the 'matching' branch is reachable with the slot model (SURVEY.md §2.1 #5)")
-        if scene_criterion != "KL":
-            raise NotImplementedError("scene_criterion='CE' is not used by the DEVIAS recipe; only 'KL' is built")
+        if scene_criterion not in ("KL", "CE"):                 # the reference silently adds no scene term for anything else (:155-158)
+            raise ValueError(f"scene_criterion must be 'KL' or 'CE' (run_slot_finetuning.py:57), got {scene_criterion!r}")
         self.criterion = criterion            # accepted, never used in the matching branch (as in the reference)
         self.scene_criterion = scene_criterion
         self.num_action_classes = num_action_classes
@@ -69,7 +69,7 @@ class TrainLoss(nn.Module):
         target = target.to(device=dev, dtype=torch.int64).contiguous()
         total, losses, match, logits = HeadMatchLossFn.apply(
             slots_head, slots, mask_predictions, attn, teacher, target, fg, fgN, self.num_action_classes,
-            self.scene_loss_weight, self.mask_prediction_loss_weight, self.mask_distill_loss_weight)
+            self.scene_loss_weight, self.mask_prediction_loss_weight, self.mask_distill_loss_weight, self.scene_criterion == "CE")
         self.last_match = match
         if self.sync_loss_dict:
             vals = losses.tolist()

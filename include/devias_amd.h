@@ -62,7 +62,9 @@ const char* devias_last_error(void);
 #define DEVIAS_CNT_MHSA_BWD_F32 9
 #define DEVIAS_CNT_GEMM_SK 11        /* 256x256 persistent kernel, stream-K schedule */
 #define DEVIAS_CNT_GEMM_SMALLM 13     /* small-M kernel (M <= 128, bf16, B k-contiguous): one launch instead of split-K product + reduce */
-#define DEVIAS_CNT_GEMM256W 12       /* 256x256 persistent kernel, four-wave form (one wave per SIMD, accumulators in AGPRs): the default persistent kernel;
+#define DEVIAS_CNT_GEMM256W 12       /* 256x256 persistent kernel, four-wave form (one wave per SIMD, accumulators in AGPRs; option gemm_w4, off by
+                                        default); every such launch also counts as DEVIAS_CNT_GEMM256P */
+#define DEVIAS_CNT_GEMM256D 14       /* 256x256 persistent kernel pulling its tiles from the per-XCD dynamic queues (option gemm_dynamic, on by default);
                                         every such launch also counts as DEVIAS_CNT_GEMM256P */
 #define DEVIAS_CNT_MHSA_BWD_FUSED 10 /* (retired with ABI 150: always 0) */
 #define DEVIAS_CNT_MAX 16
@@ -72,8 +74,12 @@ void devias_counters_reset(void);
  * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_tail_split" (2, default: the tiles of a persistent launch's last partial round are computed as
  * 128-row halves by two workgroups when at least half the CUs would idle, their idle waves staging no A rows; 1: staging all rows; 0: whole tiles), "gemm_streamk" (0 = never, default; 1 = by policy; 3 = wherever it can run), "gemm_sk_eff",
  * "gemm_sk_mink", "gemm_smallm" (1, default: bf16 products with M <= 128 and B k-contiguous run as ONE launch of the small-M kernel instead of split-K
- * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves, default 0), "gemm_debug", "gemm_reserve_cus" (CUs the persistent GEMM grids
- * leave free for a concurrent kernel, e.g. RCCL's during backward), "attn_cfg", "attn_xcd".  Every choice except gemm_smallm computes the same bits.  0 = ok, DEVIAS_EINVAL = unknown name. */
+ * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves, default 0), "gemm_debug", "gemm_dynamic" (1, default: the workgroups of
+ * the persistent kernel pull their tiles from per-XCD queues at run time instead of walking static lists -- a CU held or slowed by a concurrent kernel, e.g. RCCL's during
+ * backward, just takes fewer tiles; same bits), "gemm_reserve_cus" (CUs the big-tile grids and the weight-gradient split-K sizing leave free for such a kernel),
+ * "attn_cfg", "attn_xcd".  Every choice computes the same bits EXCEPT gemm_smallm (different K summation order) and gemm_reserve_cus (like the device's CU count it
+ * sets the split-K factor of the weight-gradient GEMMs, hence their fp32 summation order: runs with different reserves -- or N = 1 against N > 1 runs that set one --
+ * agree to rounding, not bitwise).  0 = ok, DEVIAS_EINVAL = unknown name. */
 int devias_set_option(const char* name, int32_t value);
 
 /* In-place SUM all-reduce of one flat gradient bucket over the caller's RCCL communicator (`nccl_comm` is an ncclComm_t; dtype DEVIAS_F32 or
@@ -153,6 +159,10 @@ int64_t devias_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
  * ------------------------------------------------------------------------------------------------- */
 /* dst[i] = (T_dst) src[i]; dtype codes as above. Used for the per-step bf16 weight copies and video input. */
 int devias_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream);
+/* dst[i] = (T_dst)(scale * (float) src[i]); fp32 -> fp32 (dst may be src), bf16 -> fp32, fp32 -> bf16.  The 1/world mean of the
+ * all-reduced gradient buckets -- DDP's gradient averaging, run_slot_finetuning.py:552-563 -- fused with the widening of the
+ * bf16 wire format; ONE launch over all buckets (they are slices of one allocation, devias_amd/parallel.py). (ABI 160) */
+int devias_cast_scale(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, float scale, void* stream);
 /* Tubelet im2col for PatchEmbed (nn.Conv3d k=s=(ts,ps,ps), modeling_slot.py:167-177; layout SURVEY.md §9):
  *   out[(b*Np + (t'*g + h')*g + w'), ((c*ts + kt)*ps + kh)*ps + kw] = x[b, c, ts*t'+kt, ps*h'+kh, ps*w'+kw]
  * x is [B,C,T,H,W] of dtype x_dtype, out is [B*Np, C*ts*ps*ps] of dtype out_dtype. */
@@ -260,9 +270,11 @@ int devias_slot_select(const void* slots_head, int32_t dtype, int32_t B, int32_t
                        int32_t* idx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * TrainLoss 'matching' branch, scene_criterion 'KL' (utils/loss/train_loss.py:85-187), one launch, no host sync:
- * per-sample S x 2 assignment (== scipy linear_sum_assignment, :112-122), CE(action), KL to the padded teacher
- * logits * w_scene ('batchmean' on a 1-D input => /C), mask-distill MSE on the head-mean slot attention,
+ * TrainLoss 'matching' branch (utils/loss/train_loss.py:85-187), one launch, no host sync:
+ * per-sample S x 2 assignment (== scipy linear_sum_assignment, :112-122), CE(action), scene term by `scene_ce`:
+ * 0 = scene_criterion 'KL', KL to the padded teacher logits * w_scene ('batchmean' on a 1-D input => /C, :158-164);
+ * 1 = scene_criterion 'CE', cross-entropy against the teacher's argmax class, w_scene NOT applied (:155-156);
+ * mask-distill MSE on the head-mean slot attention,
  * BCE-with-logits on the (already sigmoided) mask prediction, slot cosine loss.
  *   slots_head T [B*S,C]; slots T [B*S,D]; maskp T [B*S,G]; attn fp32 [B*nh,S,N]; teacher fp32 [B,ns];
  *   target int64 [B]; fg fp32 [B,G]; fgN fp32 [B,N]
@@ -275,6 +287,7 @@ typedef struct {
     int32_t B, S, C, nb, ns, D, G, N, nh;
     float w_scene, w_mask_pred, w_mask_distill;
     int32_t dtype;
+    int32_t scene_ce;                /* ABI 160 */
 } devias_loss_dims;
 int devias_head_match_loss_fwd(const devias_loss_dims* d, const void* slots_head, const void* slots, const void* maskp,
                                const float* attn, const float* teacher, const int64_t* target, const float* fg,

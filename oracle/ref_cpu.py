@@ -226,8 +226,8 @@ def match_slots(cost: torch.Tensor):
 
 def train_loss(cfg: SlotViTConfig, student_output, teacher_scene_logit: torch.Tensor, target: torch.Tensor,
                fg_mask, scene_loss_weight: float = 4000.0, mask_prediction_loss_weight: float = 1.0,
-               mask_distill_loss_weight: float = 1.0):
-    """TrainLoss.forward 'matching' branch, scene_criterion='KL' -- utils/loss/train_loss.py:85-187.
+               mask_distill_loss_weight: float = 1.0, scene_criterion: str = "KL"):
+    """TrainLoss.forward 'matching' branch, scene_criterion 'KL' (the recipe) or 'CE' -- utils/loss/train_loss.py:85-187.
     Returns (total_loss[1], matched action logits [B,C], dict of 5 floats, (i*, j*) index tensors)."""
     _, (_, _, attn), (slots_head, slots, mask_predictions) = student_output
     bs = target.shape[0]
@@ -254,8 +254,11 @@ def train_loss(cfg: SlotViTConfig, student_output, teacher_scene_logit: torch.Te
         mp = mp + F.binary_cross_entropy_with_logits(M[b, i], fg196[b]) * mask_prediction_loss_weight  # :146-149
         act = act + F.cross_entropy(Z[b, i], target[b])                                           # :150
         rows.append(Z[b, i])
-        scn = scn + F.kl_div(F.log_softmax(Z[b, j], dim=-1), F.log_softmax(Tpad[b], dim=-1),
-                             reduction="batchmean", log_target=True) * scene_loss_weight            # :159-164
+        if scene_criterion == "CE":
+            scn = scn + F.cross_entropy(Z[b, j], scene_target[b])                                  # :155-156 (no scene_loss_weight)
+        else:
+            scn = scn + F.kl_div(F.log_softmax(Z[b, j], dim=-1), F.log_softmax(Tpad[b], dim=-1),
+                                 reduction="batchmean", log_target=True) * scene_loss_weight        # :159-164
     act, scn, mp, md = act / bs, scn / bs, mp / bs, md / bs                                        # :168-171
     sl = F.normalize(slots.reshape(bs, S, -1), p=2, dim=2)                                         # :173-178
     cs = torch.bmm(sl, sl.transpose(1, 2)) * (1 - torch.eye(S, dtype=sl.dtype))

@@ -406,6 +406,52 @@ def generate_knn(ref):
     print("[knn]", out["cases"])
 
 
+def generate_loss_criteria(ref):
+    """The reference's TrainLoss itself (utils/loss/train_loss.py:85-187) on seeded student outputs, for BOTH scene criteria
+    ('KL' of the recipes, 'CE' of `run_slot_finetuning.py --scene_criterion CE`): inputs, the five loss terms, the matched logits
+    and the gradients with respect to the four differentiable inputs.  The oracle's `train_loss` is checked against it here."""
+    _, _, _, _, TrainLoss = ref
+    fx = {}
+    for S in (2, 3):
+        B, nb, ns, D, G, N, nh = 4, 400, 365, 768, 196, 392, 4
+        g = torch.Generator().manual_seed(4100 + S)
+        base = dict(slots_head=torch.randn(B * S, nb + ns, generator=g) * 2.0, slots=torch.randn(B * S, D, generator=g),
+                    maskp=torch.rand(B * S, G, generator=g), attn=torch.rand(B * nh, S, N, generator=g),
+                    teacher=torch.randn(B, ns, generator=g) * 3.0, target=torch.randint(0, nb, (B,), generator=g),
+                    fg=torch.randint(0, 257, (B, G), generator=g).float() / 256.0, fgN=torch.randint(0, 257, (B, N), generator=g).float() / 256.0)
+        for k, v in base.items():
+            fx[f"s{S}.{k}"] = v.numpy()
+        cfg = ref_cpu.SlotViTConfig(all_frames=8, num_latents=S)
+        for crit_name in ("KL", "CE"):
+            leaves = {k: base[k].clone().requires_grad_(True) for k in ("slots_head", "slots", "maskp", "attn")}
+            out = (None, (None, None, leaves["attn"]), (leaves["slots_head"], leaves["slots"], leaves["maskp"]))
+            crit = TrainLoss(criterion=None, scene_criterion=crit_name, num_action_classes=nb, slot_matching_method="matching",
+                             mask_prediction_loss_weight=1.0, mask_distill_loss_weight=3.0, scene_loss_weight=2000)
+            total, logits, ld = crit(None, out, (None, base["teacher"].clone()), base["target"], fg_mask=(base["fg"], base["fgN"]))
+            total.backward()
+            ol = {k: base[k].clone().requires_grad_(True) for k in leaves}
+            oout = (None, (None, None, ol["attn"]), (ol["slots_head"], ol["slots"], ol["maskp"]))
+            ototal, ologits, old, oidx = ref_cpu.train_loss(cfg, oout, base["teacher"].clone(), base["target"], (base["fg"], base["fgN"]),
+                                                            scene_loss_weight=2000, mask_prediction_loss_weight=1.0,
+                                                            mask_distill_loss_weight=3.0, scene_criterion=crit_name)
+            ototal.backward()
+            errs = {"total": rel_err(ototal, total), "logits": rel_err(ologits, logits)}
+            errs.update({"d" + k: rel_err(ol[k].grad, leaves[k].grad) for k in leaves})
+            errs.update({k: abs(old[k] - ld[k]) / max(abs(ld[k]), 1e-30) for k in ld})
+            print(f"[loss_criteria S={S} {crit_name}] oracle vs reference: " + ", ".join(f"{k}={v:.1e}" for k, v in errs.items()), ld)
+            assert max(errs.values()) < 2e-6, errs
+            pre = f"s{S}.{crit_name}."
+            fx[pre + "total"] = np.array(float(total.detach().double()))
+            fx[pre + "losses"] = np.array([float(ld[k]) for k in ("action_loss", "scene_loss", "cosine_loss", "mask_prediction_loss", "mask_distill_loss")])
+            fx[pre + "logits"] = logits.detach().numpy()
+            fx[pre + "match"] = np.stack([oidx[0].numpy(), oidx[1].numpy()], axis=1)
+            for k in leaves:
+                fx[pre + "d" + k] = leaves[k].grad.numpy()
+    path = os.path.join(ROOT, "tests", "golden", "loss_criteria.npz")
+    np.savez_compressed(path, **fx)
+    print(f"[loss_criteria] wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -425,6 +471,8 @@ def main():
         generate_fame(ref)
     if args.only in (None, "knn"):
         generate_knn(ref)
+    if args.only in (None, "loss"):
+        generate_loss_criteria(ref)
 
 
 if __name__ == "__main__":

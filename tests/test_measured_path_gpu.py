@@ -160,8 +160,8 @@ def test_bf16_full_size_step_properties():
 
 
 def test_bf16_full_size_step_beside_the_oracle():
-    """The oracle BESIDE the B = 32 kernels: the full-size bf16 step (M = 50176, the 588-tile stream-K grids live,
-    asserted by the launch counters) is compared with the REFERENCE golden on chunk 0 (clips 0-1 are the `vitb_t16` fixture's inputs) and with
+    """The oracle BESIDE the B = 32 kernels: the full-size bf16 step (M = 50176: the persistent 256x256 kernel with split tail tiles
+    serves every forward / dgrad GEMM and the stream-K kernel none, asserted by the launch counters) is compared with the REFERENCE golden on chunk 0 (clips 0-1 are the `vitb_t16` fixture's inputs) and with
     the CPU oracle's train_step on four more 2-clip chunks spread over the batch: per-slot logits, matched indices, and every term of the
     chunk's loss evaluated with the chunk's own teacher pad-min.  So the schedule that only exists at B = 32 is pinned to the
     reference, not to sibling kernels."""

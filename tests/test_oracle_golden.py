@@ -47,3 +47,26 @@ def test_sinusoid_table_known_values():
     assert torch.allclose(t[0], torch.tensor([0., 1., 0., 1., 0., 1., 0., 1.]))
     assert abs(float(t[1, 0]) - np.sin(1.0)) < 1e-7 and abs(float(t[1, 1]) - np.cos(1.0)) < 1e-7
     assert abs(float(t[3, 2]) - np.sin(3.0 / 10000 ** (2 / 8))) < 1e-7
+
+
+@pytest.mark.parametrize("S", [2, 3])
+@pytest.mark.parametrize("crit", ["KL", "CE"])
+def test_oracle_loss_criteria_match_reference_golden(S, crit):
+    """oracle train_loss, both scene criteria, against the reference's own TrainLoss on the committed inputs
+    (tests/golden/loss_criteria.npz, made by make_goldens.py --only loss)."""
+    fx = dict(np.load(gu.GOLDEN_DIR + "/loss_criteria.npz"))
+    t = {k: torch.from_numpy(fx[f"s{S}.{k}"]) for k in ("slots_head", "slots", "maskp", "attn", "teacher", "target", "fg", "fgN")}
+    lv = {k: t[k].clone().requires_grad_(True) for k in ("slots_head", "slots", "maskp", "attn")}
+    cfg = ref_cpu.SlotViTConfig(all_frames=8, num_latents=S)
+    out = (None, (None, None, lv["attn"]), (lv["slots_head"], lv["slots"], lv["maskp"]))
+    total, logits, ld, idx = ref_cpu.train_loss(cfg, out, t["teacher"], t["target"], (t["fg"], t["fgN"]), scene_loss_weight=2000,
+                                                mask_prediction_loss_weight=1.0, mask_distill_loss_weight=3.0, scene_criterion=crit)
+    total.backward()
+    pre = f"s{S}.{crit}."
+    assert abs(float(total) - float(fx[pre + "total"])) < 1e-5 * abs(float(fx[pre + "total"]))
+    got = [ld[k] for k in ("action_loss", "scene_loss", "cosine_loss", "mask_prediction_loss", "mask_distill_loss")]
+    assert np.allclose(got, fx[pre + "losses"], rtol=1e-5, atol=1e-7)
+    assert torch.stack(idx, dim=1).tolist() == fx[pre + "match"].tolist()
+    assert gu.rel(logits.detach(), fx[pre + "logits"]) < 1e-6
+    for k in lv:
+        assert gu.rel(lv[k].grad, fx[pre + "d" + k]) < 1e-5, k

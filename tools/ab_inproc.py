@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B of process-wide kernel options INSIDE one process: blocks of steps timed with HIP events, the option toggled between blocks in the order A B B A A B B A ...
 (no process restarts, no first-run / second-run bias: two separate bench.py runs differ by 0.1-0.3 ms whichever option they carry).
-usage: ab_inproc.py name=a,b [name=a,b ...]   e.g.  ab_inproc.py gemm_w4=0,1 gemm_tail_split=0,1"""
+usage: ab_inproc.py [hog=K] name=a,b [name=a,b ...]   e.g.  ab_inproc.py gemm_w4=0,1 gemm_tail_split=0,1
+hog=K holds K compute units (128 KiB LDS each) on a side stream during every backward of every block that follows on the command line (hog=0 ends it),
+as bench.py --cu-hog does: the stand-in for a concurrent collective's kernels."""
 import os, sys, statistics as st
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,12 +27,21 @@ def main():
     crit = TrainLoss(scene_criterion="KL", num_action_classes=400, slot_matching_method="matching", scene_loss_weight=4000,
                      mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0, sync_loss_dict=False)
 
+    from devias_amd import _lib as _dl
+    hog = [0]
+    hog_stream = torch.cuda.Stream(device=dev)
+
     def step():
         for p in model.parameters():
             p.grad = None
         out = model(x)
         total, logits, ld = crit(model, out, (None, tl), y, fg_mask=fg)
+        if hog[0]:
+            hog_stream.wait_stream(torch.cuda.current_stream(dev))
+            _dl.check(_dl.load().devias_debug_cu_hog(hog[0], 36000, hog_stream.cuda_stream), "devias_debug_cu_hog")
         total.backward()
+        if hog[0]:
+            torch.cuda.current_stream(dev).wait_stream(hog_stream)
 
     for _ in range(8):
         step()
@@ -38,6 +49,12 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for spec in specs:
         name, vals = spec.split("=")
+        if name == "hog":
+            hog[0] = int(vals)
+            print(f"--- {hog[0]} CUs held during every backward from here on", flush=True)
+            for _ in range(3):
+                step()
+            continue
         a, b = (int(v) for v in vals.split(","))
         ts = {a: [], b: []}
         for blk, v in enumerate([a, b, b, a] * 4):
