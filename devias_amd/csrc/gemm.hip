@@ -39,8 +39,8 @@ struct GemmP {
     int tail_split;       // gemm256p_kernel: split the tiles of the last partial round between two workgroups (128-row halves)
     int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
     float* sk_part; unsigned long long* sk_flag; unsigned long long sk_epoch;   // stream-K kernel: partial slots, flags (+ error word), this launch's tag
-    // dynamic tile queue of gemm256p_kernel<.., true>: this launch's 8 per-XCD queue heads (one per 128-byte line, all zero when the launch starts),
-    // the ring slot this launch zeroes for a later one, and the item list of a queue (nwhole whole tiles, then the halves of the split tail tiles)
+    // dynamic tile queue of gemm256p_kernel<.., true>: this launch's queue slot (8 per-XCD heads, one per 128-byte line, + the line of claim masks; all zero
+    // when the launch starts), the ring slot this launch zeroes for a later one, and the item list of a queue (nwhole whole tiles, then the halves of the split tail tiles)
     // for the two queue lengths that occur: [0] = queues of ntiles / 8 + 1 tiles, [1] = of ntiles / 8
     unsigned int* tq; unsigned int* tq_clear; int tq_nwhole[2], tq_items[2];
 };
@@ -917,24 +917,36 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
 // Tile order: XCD x (block ids congruent to x mod 8) owns the same contiguous range of logical tiles as in xcd_remap; its G/8 workgroups
 // stride through it together, so at any moment an XCD works on ~32 consecutive tiles (operand panels shared in its L2).
 // =====================================================================================================================
-// ---- dynamic tile queue (DYN): the published-item word and the dequeue -----------------------------------------------------------------
-// Ring of queue-head slots in the code object (zero at load): launch n uses slot n % TQ_RING and zeroes slot (n + TQ_RING / 2) % TQ_RING for the launch
+// ---- dynamic tile queue (DYN): queue words, the published-item word, the dequeue ---------------------------------------------------------
+// Ring of queue slots in the code object (zero at load): launch n uses slot n % TQ_RING and zeroes slot (n + TQ_RING / 2) % TQ_RING for the launch
 // that will use it TQ_RING / 2 launches later (stream order makes the zeroes land long before; no reset pass, no host memset).
-enum { TQ_RING = 64, TQ_LINE = 32 /* uint32 per head: one 128-byte line each */, TQ_NONE = 0x0fffffff };
-__device__ unsigned int g_tile_queue[TQ_RING][8][TQ_LINE];
+// One slot = 16 lines of 128 bytes (a word that 256 workgroups hit at once is worth a line of its own: one word takes ~88 atomics per microsecond):
+// line y < 8 holds the HEAD of XCD queue y (tickets for the items behind the reserved ones), line 8 + y its CLAIM MASK (bit i = reserved item i is taken).
+enum { TQ_RING = 64, TQ_LINE = 32 /* uint32 per line */, TQ_SLOT = 16 * TQ_LINE, TQ_MASKS = 8 * TQ_LINE * 4 /* byte offset of the first mask */, TQ_NONE = 0x0fffffff };
+__device__ unsigned int g_tile_queue[TQ_RING][TQ_SLOT];
 
-// one returning agent-scope add by lane 0 of the calling wave, issued from inline asm under a hand-set EXEC mask: invisible to the compiler's wait insertion
-// (a visible pending load would turn the K loop's counted waits into vmcnt(0) drains); the ticket is usable after the caller's next s_waitcnt vmcnt(0)
-__device__ __forceinline__ void tq_issue(unsigned& ticket, unsigned int* heads, int queue) {
+// Returning agent-scope atomics by lane 0 (or lanes 0-15) of the calling wave, issued from inline asm under a hand-set EXEC mask: invisible to the compiler's
+// wait insertion (a visible pending load would turn the K loop's counted waits into vmcnt(0) drains); the result is usable after the caller's next
+// s_waitcnt vmcnt(0) that names it.  Wave 0 only, all 64 lanes active at the call.
+__device__ __forceinline__ void tq_issue(unsigned& ticket, unsigned int* slot, int queue) {               // ticket = head[queue]++
     const unsigned voff = (unsigned)queue * (TQ_LINE * 4), one = 1u;
-    unsigned long long save;
-    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
-                 : "+v"(ticket), "=&s"(save) : "v"(voff), "v"(one), "s"(heads) : "memory");
+    asm volatile("s_mov_b64 exec, 1\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(ticket) : "v"(voff), "v"(one), "s"(slot) : "memory");
 }
+__device__ __forceinline__ void tq_issue_claim(unsigned& old, unsigned int* slot, int queue, unsigned bit) {   // old = mask[queue]; mask[queue] |= bit
+    const unsigned voff = TQ_MASKS + (unsigned)queue * (TQ_LINE * 4);
+    asm volatile("s_mov_b64 exec, 1\n\tglobal_atomic_or %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(old) : "v"(voff), "v"(bit), "s"(slot) : "memory");
+}
+__device__ __forceinline__ void tq_issue_peek(unsigned& snap, unsigned int* slot, int lane) {             // lanes 0-7: the heads, 8-15: the masks (add 0)
+    const unsigned voff = (unsigned)(lane & 15) * (TQ_LINE * 4), zero = 0u;
+    asm volatile("s_mov_b64 exec, 0xffff\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(snap) : "v"(voff), "v"(zero), "s"(slot) : "memory");
+}
+// WAIT = false: the readers poll for the tag, nobody needs the write to have completed at any particular point
+template <bool WAIT>
 __device__ __forceinline__ void tq_publish(char* word, unsigned seq, int code) {
     const unsigned v = ((seq & 15u) << 28) | ((unsigned)code & 0x0fffffffu);
     const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)word;
-    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
+    if constexpr (WAIT) asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(addr), "v"(v) : "memory");
+    else asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 // the item published for position `seq` of this workgroup's item stream: >= 0 (queue << 20 | index), TQ_NONE, or -2 = not published (yet)
 __device__ __forceinline__ int tq_read(const char* word, unsigned seq) {
@@ -988,19 +1000,27 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
         return true;
     };
     // DYNAMIC queue (DYN = true).  Item i of XCD queue y: the whole tile base_y + i for i < nwhole_y, then the two 128-row halves of each tail tile (the same
-    // items the static list hands out; only WHO computes an item is decided at run time).  A workgroup pulls from its own XCD's queue (operand panels stay
-    // shared in that L2) and, once that is empty, from the next XCDs' in turn: a CU that another kernel holds (RCCL's during backward) or slows down just
-    // pulls fewer items -- the workgroup that finds no CU until the others have finished finds every queue empty and leaves.  Which workgroup computes a tile
-    // does not change a bit of it.  Everything happens at the TILE SWITCH, where the accumulators are dead (the K loop is the static kernel's, untouched):
-    // a workgroup always holds its current item and the next one (whose first K-tile the stream prefetches); the dequeue for the one after that is issued
-    // by wave 0 when `next` becomes known and has a whole tile's time to return; at the switch wave 0 reads the ticket, publishes the item through the LDS
-    // word behind the ring, issues the following dequeue, and after one more barrier every wave decodes it.  Only a workgroup's first two items, and
-    // probes of further queues at the very end of a launch, are waited for.
+    // items the static list hands out; only WHO computes an item is decided at run time).  Which workgroup computes a tile does not change a bit of it.
+    //   * The first `stride` items of a queue are RESERVED, one per workgroup of that XCD: a workgroup starts on its own (no round trip before the first
+    //     LDS-DMA) and claims it with an atomic OR on the queue's mask word, whose answer arrives with that first K-tile.
+    //   * The items behind them are handed out by tickets of the queue's head word.  A workgroup always holds its current item and the next one (whose
+    //     first K-tile the stream prefetches); the dequeue for the one after is issued by wave 0 during the last K-tile of a tile, is OLDER than that
+    //     iteration's LDS-DMA (so the counted wait of the tile switch covers it) and is read a whole tile later, again under the last K-tile: wave 0
+    //     publishes the item through the LDS word behind the ring and every wave picks it up after its epilogue.  The K loop is the static kernel's.
+    //   * A workgroup whose queue is empty looks at all eight heads and masks at once (one 16-lane instruction), pulls from another XCD's queue, and when
+    //     every head is used up takes reserved items nobody has claimed -- those of workgroups that have not found a CU yet because another kernel holds
+    //     it (RCCL's during backward; bench.py --cu-hog).  Such a workgroup later finds its claim refused and every queue empty, and leaves: a held or
+    //     slowed CU costs its share of the work, not a straggler's tile list.  Only these end-of-launch searches are waited for.
     char* const tq_word = smem + 2 * STAGE2;
+    // the queue geometry and the slot pointer as OPAQUE scalars: otherwise every use re-loads them from the kernel-argument segment (an s_load round
+    // trip on wave 0's critical path once per tile); opaque values stay in SGPRs or in a lane of the spill VGPR (one v_readlane)
+    int nwhole_a = p.tq_nwhole[0], nwhole_b = p.tq_nwhole[1], items_a = p.tq_items[0], items_b = p.tq_items[1];
+    unsigned int* tq = p.tq;
+    if constexpr (DYN) asm volatile("" : "+s"(nwhole_a), "+s"(nwhole_b), "+s"(items_a), "+s"(items_b), "+s"(tq));
     auto qgeom = [&](int y, int& qbase, int& nwhole, int& items) {
         qbase = y < r ? y * (q + 1) : r * (q + 1) + (y - r) * q;
-        nwhole = y < r ? p.tq_nwhole[0] : p.tq_nwhole[1];
-        items = y < r ? p.tq_items[0] : p.tq_items[1];
+        nwhole = y < r ? nwhole_a : nwhole_b;
+        items = y < r ? items_a : items_b;
     };
     auto decode = [&](int code, int& m0, int& n0, int& half) {
         const int y = code >> 20, i = code & 0xfffff;
@@ -1012,19 +1032,57 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
         tile_coords(qbase + l, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
         m0 = tm * T2; n0 = tn * T2;
     };
-    int fq = xcd, ftried = 0;                              // wave 0: the queue being pulled from, queues seen empty
+    int fq = xcd;                                          // wave 0: the queue whose head the outstanding dequeue went to
+    bool fdead = false;                                    // wave 0: nothing is left anywhere
     unsigned ticket = 0, seq = 0;                          // seq = items published to this workgroup so far
-    // wave 0, after a wait that covers the dequeue: found item (>= 0), TQ_NONE (all eight queues empty), or -2 = that queue was empty, try the next one
+    // wave 0, after a wait that covers the dequeue from queue fq: the item (>= 0), or -2 = that queue's head is used up
     auto settle = [&]() -> int {
-        const int t = (int)__builtin_amdgcn_readfirstlane(ticket);
+        const int t = stride + (int)__builtin_amdgcn_readfirstlane(ticket);
         int qbase, nwhole, items;
         qgeom(fq, qbase, nwhole, items);
-        if (t < items) return (fq << 20) | t;
-        fq = (fq + 1) & 7;
-        return ++ftried >= 8 ? (int)TQ_NONE : -2;
+        return t < items ? ((fq << 20) | t) : -2;
+    };
+    // wave 0, waited round trips (end of a launch only): look at every head and mask, pull from the first queue that still has tickets (own XCD's
+    // neighbours first), else claim an unclaimed reserved item; TQ_NONE when there is nothing
+    auto find_elsewhere = [&]() -> int {
+        const int lane_f = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const unsigned wmask = stride >= 32 ? 0xffffffffu : ((1u << stride) - 1u);
+        for (int attempt = 0; attempt < 256 && !fdead; ++attempt) {
+            unsigned snap = 0;
+            tq_issue_peek(snap, tq, lane_f);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(snap) :: "memory");
+            int pick = -1, kind = 0;
+            unsigned bit = 0;
+            for (int d = 1; d <= 8 && pick < 0; ++d) {
+                const int y = (xcd + d) & 7;
+                int qbase, nwhole, items;
+                qgeom(y, qbase, nwhole, items);
+                if (stride + (int)__builtin_amdgcn_readlane(snap, y) < items) pick = y;
+            }
+            for (int d = 0; d < 8 && pick < 0 && !(p.debug & 512); ++d) {     // (gemm_debug & 512: reserved items are not taken over -- bisecting aid)
+                const int y = (xcd + d) & 7;
+                const unsigned avail = ~(unsigned)__builtin_amdgcn_readlane(snap, 8 + y) & wmask;
+                if (avail) { pick = y; kind = 1; bit = avail & (0u - avail); }
+            }
+            if (pick < 0) { fdead = true; break; }
+            if (kind == 0) {
+                fq = pick;
+                tq_issue(ticket, tq, fq);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
+                const int c = settle();
+                if (c != -2) return c;
+            } else {
+                unsigned old = 0;
+                tq_issue_claim(old, tq, pick, bit);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(old) :: "memory");
+                if (!((unsigned)__builtin_amdgcn_readfirstlane(old) & bit)) return (pick << 20) | (int)__builtin_ctz(bit);
+            }
+        }
+        fdead = true;
+        return (int)TQ_NONE;
     };
     if constexpr (DYN) {
-        if (blockIdx.x == 0 && tid < 8)                    // (from asm: the compiler's wait insertion never sees a store pending)
+        if (blockIdx.x == 0 && tid < 16)                   // (from asm: the compiler's wait insertion never sees a store pending)
             asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"((unsigned)tid * (TQ_LINE * 4)), "v"(0u), "s"(p.tq_clear) : "memory");
     }
     int tk = 0, half = -1, halfn = -1;
@@ -1052,38 +1110,18 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
 #define PSTAMP(c)
 #endif
     f32x4 acc[8][4];
-    // wave 0: pull until an item is found or all eight queues are empty, each dequeue waited for (the first item of a workgroup; later ones only when
-    // the dequeue issued under the K loop had not found one in time -- fewer K-tiles per tile than queues left to probe, at the very end of a launch)
-    auto pull_waited = [&](int c) -> int {
-        while (c == -2) {
-            tq_issue(ticket, p.tq, fq);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
-            c = settle();
-        }
-        return c;
-    };
     {
+        unsigned claim = 0;
         if constexpr (!DYN) {
             (void)tile_at(0, li, half);
             coords(li, m0, n0);
         } else {
-            if (wave == 0) {                               // the first two items: waited for; then the third is requested
-                const int c0 = pull_waited(-2);
-                const int c1 = c0 == (int)TQ_NONE ? c0 : pull_waited(ftried >= 8 ? (int)TQ_NONE : -2);
-                tq_publish(tq_word, 0, c0);
-                tq_publish(tq_word + 4, 1, c1);
-                if (c1 != (int)TQ_NONE && ftried < 8) tq_issue(ticket, p.tq, fq);
+            // start on the reserved item; the claim and the dequeue of the second item travel with the first K-tile's LDS-DMA
+            if (wave == 0) {
+                tq_issue_claim(claim, tq, xcd, 1u << li0);
+                tq_issue(ticket, tq, fq);
             }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const int code = tq_read(tq_word, 0);
-            if (code == (int)TQ_NONE) return;              // every queue was empty: this workgroup came too late to be needed
-            decode(code, m0, n0, half);
-            ncode = tq_read(tq_word + 4, 1);
-            has_next = ncode != (int)TQ_NONE;
-            m0n = m0; n0n = n0;
-            if (has_next) decode(ncode, m0n, n0n, halfn);
-            seq = 2;
+            decode((xcd << 20) | li0, m0, n0, half);
         }
         glds_tile<false>(A, p.lda, m0, 0, smem, wave, lane);
         glds_tile<TB>(B, p.ldb, n0, 0, smem + 32768, wave, lane);
@@ -1093,12 +1131,42 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             m0n = m0; n0n = n0;
             if (has_next) coords(ln, m0n, n0n);
         }
-        bool act = half < 0 || wm == half;                    // (wave-uniform)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!DYN) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim), "+v"(ticket) :: "memory");
+            if (wave == 0) {
+                int c0 = ((unsigned)__builtin_amdgcn_readfirstlane(claim) >> li0) & 1u ? -2 : ((xcd << 20) | li0);    // refused: somebody took it while this
+                int c1 = settle();                                                                                   // workgroup was waiting for a CU
+                if (c0 == -2) { c0 = c1 != -2 ? c1 : find_elsewhere(); c1 = -2; }
+                if (c0 == (int)TQ_NONE) c1 = c0;
+                else if (c1 == -2) c1 = find_elsewhere();
+                tq_publish<true>(tq_word, 0, c0);
+                tq_publish<true>(tq_word + 4, 1, c1);
+                if (c1 != (int)TQ_NONE && !fdead) tq_issue(ticket, tq, fq);
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int code = tq_read(tq_word, 0);
+            if (code == (int)TQ_NONE) return;              // every queue was empty: this workgroup came too late to be needed (its DMA has landed)
+            if (code != ((xcd << 20) | li0)) {             // (rare) the reserved item was gone: restage the first K-tile of the item found instead
+                decode(code, m0, n0, half);
+                __builtin_amdgcn_s_barrier();
+                glds_tile<false>(A, p.lda, m0, 0, smem, wave, lane);
+                glds_tile<TB>(B, p.ldb, n0, 0, smem + 32768, wave, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            ncode = tq_read(tq_word + 4, 1);
+            has_next = ncode != (int)TQ_NONE;
+            m0n = m0; n0n = n0;
+            if (has_next) decode(ncode, m0n, n0n, halfn);
+            seq = 2;
+        }
+        bool act = half < 0 || wm == half;                    // (wave-uniform)
         // ONE flat loop over the K-tile stream (ring stage = g & 1); the wait for K-tile g + 1 sits at the END of iteration g so that the loop has
         // no first-iteration special case (a peeled copy is where the compiler re-inserts full vmcnt drains)
         for (int g = 0, kt = 0;; ++g) {
@@ -1115,15 +1183,19 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             // every iteration instead of registers that stay live across the epilogue, whose register peak is the kernel's (-14 registers)
             int lane_k = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             asm volatile("" : "+v"(lane_k));
+            // does K-tile g + 1 need the A rows this wave stages?  Not if it belongs to a half tile of the OTHER wave row (nobody multiplies them; tail_split >= 2).
+            // With the static lists a half tile is a workgroup's last item; with the queues it can have a successor, whose first K-tile is staged by ITS halves
+            // (a wave that multiplies the current tile stages its rows in any case)
+            const bool stage_a = p.tail_split < 2 || act || (DYN && !same && has_next && (halfn < 0 || wm == halfn));
             if constexpr (!TB) {
                 if (act) ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
-                else {                                         // the other half's waves of a split tail tile: staging only -- and of B only: the A rows a wave
+                else {                                       // the other half's waves of a split tail tile: staging only -- and of B only: the A rows a wave
                                                                // stages (32 wave + ...) are the rows of ITS half, which nobody multiplies (tail_split >= 2)
-                    if (p.tail_split < 2) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
+                    if (stage_a) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
                     glds_tile<false>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
                 }
             } else {
-                if (act || p.tail_split < 2) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
+                if (stage_a) glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
                 glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
                 if (act) ktile_generic<false, true>(acc, cur, lane_k, wm, wn);
             }
@@ -1134,6 +1206,18 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
                 continue;
             }
             PSTAMP(2); PSTAMP(10);
+            if constexpr (DYN) {
+                // the item after `next`: its dequeue was issued before the previous tile's epilogue, OLDER than that epilogue's stores, so the counted wait of
+                // that tile switch has covered it.  Wave 0 reads the ticket, publishes the item (read by everyone after the epilogue) and issues the following
+                // dequeue -- here, before the epilogue, not at the switch, so that the switch needs no extra barrier and the K loop is the static kernel's
+                if (has_next && wave == 0) {
+                    asm volatile("" : "+v"(ticket));           // (the ticket is read here, not where the compiler last saw it written)
+                    int c = fdead ? (int)TQ_NONE : settle();
+                    if (c == -2) c = find_elsewhere();
+                    tq_publish<false>(tq_word, seq, c);
+                    if (c != (int)TQ_NONE && !fdead) tq_issue(ticket, tq, fq);
+                }
+            }
             int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
             if (act) epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
@@ -1153,17 +1237,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
                 has_next = tile_at(tk + 1, ln, halfn);
                 if (has_next) coords(ln, m0n, n0n);
             } else {
-                // the item after `next`: its dequeue was issued a tile ago and every K-iteration's vmcnt(0) since has covered it (nk >= 2, checked by the host)
-                if (wave == 0) {
-                    asm volatile("" : "+v"(ticket));           // (the ticket is read here, not where the compiler last saw it written)
-                    int c = ftried >= 8 ? (int)TQ_NONE : settle();
-                    if (c == -2) c = pull_waited(ftried >= 8 ? (int)TQ_NONE : -2);
-                    tq_publish(tq_word, seq, c);
-                    if (c != (int)TQ_NONE && ftried < 8) tq_issue(ticket, p.tq, fq);
-                }
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                ncode = tq_read(tq_word, seq);
+                // published by wave 0 before its epilogue (below the last K-tile's barrier): a formality, but no barrier orders it, so read until the tag matches
+                do { ncode = tq_read(tq_word, seq); } while (ncode == -2);
                 ++seq;
                 has_next = ncode != (int)TQ_NONE;
                 if (has_next) decode(ncode, m0n, n0n, halfn);
@@ -2365,14 +2440,15 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
             devias_count(DEVIAS_CNT_GEMM256W);
         } else if (kn.persistent && pers_ok && nt > gp) {
             dim3 grid(gp), block(NT2);
-            unsigned int* tq = (kn.dynamic && a->K >= 128) ? tile_queue_base() : nullptr;      // (>= 2 K-tiles per tile: their waits cover the dequeue)
+            // dynamic queue: every XCD queue has at least one (reserved) item per workgroup, at most 32 workgroups per XCD (one claim-mask word)
+            unsigned int* tq = (kn.dynamic && a->K >= 128 && (gp >> 3) <= 32 && (nt >> 3) >= (gp >> 3)) ? tile_queue_base() : nullptr;
             if (tq) {
                 // dynamic tile queue (default): the item list of an XCD queue of cnt tiles -- whole tiles, then the halves of a split partial round --
                 // for the two queue lengths that occur; this launch's ring slot and the one it zeroes
                 static std::atomic<unsigned> seq{0};
                 const unsigned n = seq.fetch_add(1);
-                p.tq = tq + (size_t)(n % TQ_RING) * 8 * TQ_LINE;
-                p.tq_clear = tq + (size_t)((n + TQ_RING / 2) % TQ_RING) * 8 * TQ_LINE;
+                p.tq = tq + (size_t)(n % TQ_RING) * TQ_SLOT;
+                p.tq_clear = tq + (size_t)((n + TQ_RING / 2) % TQ_RING) * TQ_SLOT;
                 const int stride = gp >> 3;
                 for (int v = 0; v < 2; ++v) {
                     const int cnt = (nt >> 3) + (v == 0 ? 1 : 0);

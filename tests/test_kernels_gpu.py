@@ -589,6 +589,51 @@ def test_gemm_persistent_kernels_repeatable(gemm_options):
     assert o.streamk_timeouts() == 0
 
 
+def test_gemm_dynamic_queue_with_held_cus(gemm_options):
+    """The reason for the dynamic tile queue: with compute units held by another kernel (RCCL's during backward at N > 1; here the
+    debug hog: 48 workgroups x 128 KiB LDS on a side stream, so that no GEMM workgroup can share their CUs) the persistent kernel's workgroups that find
+    no CU start only when the others have finished.  With static per-workgroup tile lists they then still own a full list (about twice the time); with the
+    queues they find nothing left and exit, the other CUs having pulled their tiles.  Results are bitwise those of the one-tile-per-workgroup kernel either
+    way (also for workgroups that steal from another XCD's queue), and the dynamic launch must be clearly faster under the hog."""
+    o = gemm_options
+    from devias_amd import _lib
+    from devias_amd._lib import ACT_GELU
+    M, D = 256 * 196, 768
+    A = rnd(M, D, dtype=torch.bfloat16, seed=21)
+    W1 = rnd(4 * D, D, dtype=torch.bfloat16, scale=0.05, seed=22)
+    Wt = rnd(D, 3 * D, dtype=torch.bfloat16, scale=0.05, seed=23)
+    b1 = rnd(4 * D, seed=24)
+    o.set_option("gemm_persistent", 0)
+    ref = (o.gemm(A, W1, bias=b1, act=ACT_GELU), o.gemm(A, Wt, trans_b=True))
+    o.set_option("gemm_persistent", 1)
+    side = torch.cuda.Stream()
+    lib = _lib.load()
+    times = {}
+    for dyn in (1, 0, 1, 0):
+        o.set_option("gemm_dynamic", dyn)
+        for _ in range(2):
+            o.gemm(A, W1, bias=b1, act=ACT_GELU)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(side):
+            _lib.check(lib.devias_debug_cu_hog(48, 30000, side.cuda_stream), "devias_debug_cu_hog")     # 30 ms: longer than everything below
+        torch.cuda.current_stream().wait_stream(side) if False else None
+        import time
+        time.sleep(0.002)                                     # the hog is resident before the GEMMs arrive
+        e0.record()
+        outs = []
+        for _ in range(6):
+            outs.append((o.gemm(A, W1, bias=b1, act=ACT_GELU), o.gemm(A, Wt, trans_b=True)))
+        e1.record()
+        torch.cuda.synchronize()
+        times.setdefault(dyn, []).append(e0.elapsed_time(e1))
+        for a, b in outs:
+            assert torch.equal(a, ref[0]) and torch.equal(b, ref[1]), dyn
+    t_dyn, t_static = min(times[1]), min(times[0])
+    print(f"12 persistent GEMM launches with 48 CUs held: static lists {t_static:.2f} ms, dynamic queues {t_dyn:.2f} ms")
+    assert t_dyn < 0.85 * t_static, (t_dyn, t_static)
+
+
 # ------------------------------------------------------------------------------------------------ attention backward: grids, ragged shapes, descriptors
 @pytest.fixture
 def attn_options():
