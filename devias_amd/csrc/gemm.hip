@@ -927,18 +927,21 @@ __device__ unsigned int g_tile_queue[TQ_RING][TQ_SLOT];
 
 // Returning agent-scope atomics by lane 0 (or lanes 0-15) of the calling wave, issued from inline asm under a hand-set EXEC mask: invisible to the compiler's
 // wait insertion (a visible pending load would turn the K loop's counted waits into vmcnt(0) drains); the result is usable after the caller's next
-// s_waitcnt vmcnt(0) that names it.  Wave 0 only, all 64 lanes active at the call.
+// s_waitcnt vmcnt(0) that names it.  Wave 0 only, all 64 lanes active at the call.  Each block starts with s_nop 4: the slot pointer may have just been
+// reloaded from a lane of the SGPR-spill VGPR (v_readlane = a VALU write of an SGPR), and a vector-memory instruction that reads an SGPR written by the
+// VALU needs 5 wait states which the compiler's hazard recogniser does not insert inside inline asm (found as a memory fault at an address with a stale
+// high half in the -DDEVIAS_GEMM_DEBUG build, where the pointer lives in a spill lane).
 __device__ __forceinline__ void tq_issue(unsigned& ticket, unsigned int* slot, int queue) {               // ticket = head[queue]++
     const unsigned voff = (unsigned)queue * (TQ_LINE * 4), one = 1u;
-    asm volatile("s_mov_b64 exec, 1\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(ticket) : "v"(voff), "v"(one), "s"(slot) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(ticket) : "v"(voff), "v"(one), "s"(slot) : "memory");
 }
 __device__ __forceinline__ void tq_issue_claim(unsigned& old, unsigned int* slot, int queue, unsigned bit) {   // old = mask[queue]; mask[queue] |= bit
     const unsigned voff = TQ_MASKS + (unsigned)queue * (TQ_LINE * 4);
-    asm volatile("s_mov_b64 exec, 1\n\tglobal_atomic_or %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(old) : "v"(voff), "v"(bit), "s"(slot) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b64 exec, 1\n\tglobal_atomic_or %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(old) : "v"(voff), "v"(bit), "s"(slot) : "memory");
 }
 __device__ __forceinline__ void tq_issue_peek(unsigned& snap, unsigned int* slot, int lane) {             // lanes 0-7: the heads, 8-15: the masks (add 0)
     const unsigned voff = (unsigned)(lane & 15) * (TQ_LINE * 4), zero = 0u;
-    asm volatile("s_mov_b64 exec, 0xffff\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(snap) : "v"(voff), "v"(zero), "s"(slot) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b64 exec, 0xffff\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(snap) : "v"(voff), "v"(zero), "s"(slot) : "memory");
 }
 // WAIT = false: the readers poll for the tag, nobody needs the write to have completed at any particular point
 template <bool WAIT>
@@ -1083,7 +1086,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     };
     if constexpr (DYN) {
         if (blockIdx.x == 0 && tid < 16)                   // (from asm: the compiler's wait insertion never sees a store pending)
-            asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"((unsigned)tid * (TQ_LINE * 4)), "v"(0u), "s"(p.tq_clear) : "memory");
+            asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 sc1" ::"v"((unsigned)tid * (TQ_LINE * 4)), "v"(0u), "s"(p.tq_clear) : "memory");
     }
     int tk = 0, half = -1, halfn = -1;
     int m0 = 0, n0 = 0, m0n = 0, n0n = 0;
@@ -1206,26 +1209,39 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
                 continue;
             }
             PSTAMP(2); PSTAMP(10);
-            if constexpr (DYN) {
-                // the item after `next`: its dequeue was issued before the previous tile's epilogue, OLDER than that epilogue's stores, so the counted wait of
-                // that tile switch has covered it.  Wave 0 reads the ticket, publishes the item (read by everyone after the epilogue) and issues the following
-                // dequeue -- here, before the epilogue, not at the switch, so that the switch needs no extra barrier and the K loop is the static kernel's
-                if (has_next && wave == 0) {
-                    asm volatile("" : "+v"(ticket));           // (the ticket is read here, not where the compiler last saw it written)
-                    int c = fdead ? (int)TQ_NONE : settle();
-                    if (c == -2) c = find_elsewhere();
-                    tq_publish<false>(tq_word, seq, c);
-                    if (c != (int)TQ_NONE && !fdead) tq_issue(ticket, tq, fq);
-                }
-            }
             int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
             if (act) epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
             if (!has_next) break;
+            int m0x = 0, n0x = 0, halfx = -1;
+            bool issued = false;                               // (wave 0) one dequeue was issued BEHIND the epilogue's stores
+            if constexpr (DYN) {
+                PSTAMP(5);
+                // The item after `next`, found while the epilogue's stores drain (every wave is about to sit in the counted wait below for that long anyway):
+                // its dequeue was issued at the previous tile switch and every K-iteration's vmcnt(0) since has covered it (>= 2 K-tiles per tile, checked by
+                // the host).  Wave 0 reads the ticket, publishes the item and issues the following dequeue; every wave then reads the word -- no barrier
+                // orders that, so until the tag matches -- and decodes it
+                if (wave == 0) {
+                    asm volatile("" : "+v"(ticket));           // (the ticket is read here, not where the compiler last saw it written)
+                    int c = fdead ? (int)TQ_NONE : settle();
+                    if (c == -2) c = find_elsewhere();
+                    tq_publish<false>(tq_word, seq, c);
+                    issued = c != (int)TQ_NONE && !fdead;
+                    if (issued) tq_issue(ticket, tq, fq);
+                }
+                do { ncode = tq_read(tq_word, seq); } while (ncode == -2);
+                ++seq;
+                if (ncode != (int)TQ_NONE) decode(ncode, m0x, n0x, halfx);
+                PSTAMP(6);
+            }
             // the epilogue issued >= 16 stores per wave AFTER the DMA of the next tile's first K-tile: wait for the DMA only, the stores drain under the next MFMAs.
             // (Static list: a tile with a successor is a whole tile, every wave has run the epilogue.  Dynamic queue: a half tile can be followed by an item
             // pulled from another XCD's queue; the waves that only staged it have no stores behind their DMA and wait for everything.)
+            // (wave 0's dequeue is one more operation behind the DMA: counted too, or the wait would be for the first store)
             if (DYN && !act) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !defined(TQ_EXP) || TQ_EXP != 1
+            else if (DYN && issued) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+#endif
             else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             PSTAMP(3);
             kt = 0;
@@ -1237,11 +1253,8 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
                 has_next = tile_at(tk + 1, ln, halfn);
                 if (has_next) coords(ln, m0n, n0n);
             } else {
-                // published by wave 0 before its epilogue (below the last K-tile's barrier): a formality, but no barrier orders it, so read until the tag matches
-                do { ncode = tq_read(tq_word, seq); } while (ncode == -2);
-                ++seq;
                 has_next = ncode != (int)TQ_NONE;
-                if (has_next) decode(ncode, m0n, n0n, halfn);
+                if (has_next) { m0n = m0x; n0n = n0x; halfn = halfx; }
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i)

@@ -66,3 +66,53 @@ def test_layernorm_kernels_do_not_spill():
     sizes = re.findall(r"\.set (\S*ln_(?:fwd|bwd)_kernel\S*)\.private_seg_size, (\d+)", text)
     assert len(sizes) >= 16, len(sizes)
     assert all(int(v) == 0 for _, v in sizes), [(n[-40:], v) for n, v in sizes if int(v)]
+
+
+@pytest.mark.timeout(900)
+def test_inline_asm_vmem_never_reads_an_sgpr_the_valu_just_wrote():
+    """gfx9 hazard: a vector-memory instruction that reads an SGPR written by the VALU (v_readlane / v_readfirstlane -- which is how the compiler
+    reloads a spilled SGPR from a lane of its spill VGPR) needs 5 wait states.  The compiler's hazard recogniser inserts them for its own
+    instructions but not inside inline asm, and this library issues stores and atomics from inline asm with an SGPR-pair base (the deferred epilogue
+    stores, the stream-K partials, the dynamic tile queue's dequeues).  Round 4 found the failure mode on the GPU: a dequeue whose slot pointer had just
+    come out of a spill lane went to an address with a stale high half (memory fault).  This audit walks the ISA of gemm.hip -- release and
+    -DDEVIAS_GEMM_DEBUG builds -- and requires, for every inline-asm vector-memory instruction with an SGPR base, that none of the 5 issue slots before it
+    (s_nop N counts N + 1) holds a VALU write of that SGPR."""
+    src = os.path.join(ROOT, "devias_amd", "csrc", "gemm.hip")
+    vmem = re.compile(r"^\s*(global_(?:store|load|atomic)\w*|buffer_\w+)\s+(.*)$")
+    valu_sgpr_write = re.compile(r"^\s*(v_readlane_b32|v_readfirstlane_b32)\s+s(\d+)\b")
+    for extra in ([], ["-DDEVIAS_GEMM_DEBUG"]):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "gemm.s")
+            r = subprocess.run([build.HIPCC] + list(build.FLAGS) + extra + ["--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            lines = [l.split(";")[0].rstrip() if not l.lstrip().startswith(";;#") else l.strip() for l in open(out).read().split("\n")]
+        inasm, checked, bad = False, 0, []
+        code = []                                      # (text, in_asm) of real instructions, in order
+        for l in lines:
+            if "ASMSTART" in l:
+                inasm = True
+            elif "ASMEND" in l:
+                inasm = False
+            elif l.strip() and not l.strip().endswith(":") and not l.strip().startswith("."):
+                code.append((l.strip(), inasm))
+        for i, (text, ia) in enumerate(code):
+            m = vmem.match(text)
+            if not (ia and m):
+                continue
+            base = re.search(r"\bs\[(\d+):(\d+)\]", m.group(2))
+            if not base:
+                continue
+            checked += 1
+            regs = set(range(int(base.group(1)), int(base.group(2)) + 1))
+            slots, j = 0, i - 1
+            while j >= 0 and slots < 5:
+                t = code[j][0]
+                w = valu_sgpr_write.match(t)
+                if w and int(w.group(2)) in regs:
+                    bad.append((extra, t, text))
+                    break
+                nop = re.match(r"s_nop\s+(\d+)", t)
+                slots += int(nop.group(1)) + 1 if nop else 1
+                j -= 1
+        assert checked > 500, (extra, checked)          # the epilogue stores alone are thousands
+        assert not bad, bad[:5]

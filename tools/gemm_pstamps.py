@@ -34,6 +34,7 @@ assert o.counters()["gemm256p"] >= 3
 d = ws.cpu().numpy().reshape(256, 64)
 t = (d >> 4) / 100.0; code = d & 15
 kl, ep, first, steady, clk = [], [], [], [], []
+ep_a, ep_b, ep_c = [], [], []          # dynamic queue: K loop done -> epilogue stores issued (2 -> 5), dequeue block + decode (5 -> 6), counted wait (6 -> 3)
 t0 = t[:, 0].min()
 for b in range(256):
     raw = [(int(d[b, i] >> 4), int(code[b, i])) for i in range(64) if code[b, i] != 0]
@@ -47,6 +48,9 @@ for b in range(256):
         if (ca, cb) == (1, 4): first.append(tb - ta)
         if (ca, cb) == (4, 2): steady.append(tb - ta)
         if (ca, cb) == (2, 3): ep.append(tb - ta)
+        if (ca, cb) == (2, 5): ep_a.append(tb - ta)
+        if (ca, cb) == (5, 6): ep_b.append(tb - ta)
+        if (ca, cb) == (6, 3): ep_c.append(tb - ta)
 nk = K // 64
 ent = t[:, 63]; first_kt = np.array([t[b, 0] for b in range(256)]); last = np.array([max(t[b, i] for i in range(63) if code[b, i] not in (0, 9, 10)) for b in range(256)])
 span = (last.max() - t0)
@@ -60,4 +64,5 @@ print(f"{which}: N={N} K={K}  kernel span {span:.1f} us, tiles/WG max {int((code
 print(f"  first K-iteration of a tile (incl. wait for the previous tile's stores): med {np.median(first):.2f}  p90 {np.percentile(first, 90):.2f} us")
 print(f"  remaining {nk - 1} K-iterations: med {np.median(steady):.2f} us  -> {np.median(steady) / max(nk - 1, 1):.3f} us per iteration")
 print(f"  shader clock during the K loops: med {np.median(clk):.0f} MHz (p10 {np.percentile(clk, 10):.0f}, p90 {np.percentile(clk, 90):.0f})")
-print(f"  epilogue (K loop done -> stores issued, next tile's first K-tile landed): med {np.median(ep):.2f}  p90 {np.percentile(ep, 90):.2f} us")
+if ep: print(f"  epilogue (K loop done -> stores issued, next tile's first K-tile landed): med {np.median(ep):.2f}  p90 {np.percentile(ep, 90):.2f} us")
+if ep_a: print(f"  dynamic queue: epilogue stores issued {np.median(ep_a):.2f} us, dequeue + publish + read + decode {np.median(ep_b):.2f} (p90 {np.percentile(ep_b, 90):.2f}) us, counted wait {np.median(ep_c):.2f} (p90 {np.percentile(ep_c, 90):.2f}) us")
