@@ -165,6 +165,9 @@ def main():
     if args.reserve_cus:
         from devias_amd import ops as _o
         _o.set_option("gemm_reserve_cus", args.reserve_cus)
+    if args.cu_hog:                                     # another kernel runs beside backward: what GradSync announces for N > 1
+        from devias_amd import ops as _o
+        _o.set_option("gemm_concurrent", 1)
     B = args.batch
     N = model.patch_embed.num_patches
     first = rank * B                                   # rank r owns clips [B r, B r + B) of the global batch (weak scaling)

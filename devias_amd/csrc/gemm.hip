@@ -931,7 +931,10 @@ __device__ unsigned int g_tile_queue[TQ_RING][TQ_SLOT];
 // reloaded from a lane of the SGPR-spill VGPR (v_readlane = a VALU write of an SGPR), and a vector-memory instruction that reads an SGPR written by the
 // VALU needs 5 wait states which the compiler's hazard recogniser does not insert inside inline asm (found as a memory fault at an address with a stale
 // high half in the -DDEVIAS_GEMM_DEBUG build, where the pointer lives in a spill lane).
-__device__ __forceinline__ void tq_issue(unsigned& ticket, unsigned int* slot, int queue) {               // ticket = head[queue]++
+// The dequeue: ticket = head[queue]++, by lane 0.  (Measured and not kept: the same instruction on 16 lanes, the other 15 adding 0 to the other heads and the
+// claim masks, so that the ticket arrives with a snapshot of every queue and an empty-handed workgroup knows without a waited look that nothing is left: the
+// look it saves costs 1.7 us once per workgroup and launch, the 16-fold atomic traffic cost the step +0.4 ms.)
+__device__ __forceinline__ void tq_issue(unsigned& ticket, unsigned int* slot, int queue) {
     const unsigned voff = (unsigned)queue * (TQ_LINE * 4), one = 1u;
     asm volatile("s_nop 4\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1" : "+v"(ticket) : "v"(voff), "v"(one), "s"(slot) : "memory");
 }
@@ -1144,7 +1147,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim), "+v"(ticket) :: "memory");
             if (wave == 0) {
                 int c0 = ((unsigned)__builtin_amdgcn_readfirstlane(claim) >> li0) & 1u ? -2 : ((xcd << 20) | li0);    // refused: somebody took it while this
-                int c1 = settle();                                                                                   // workgroup was waiting for a CU
+                int c1 = settle();                                                                              // workgroup was waiting for a CU
                 if (c0 == -2) { c0 = c1 != -2 ? c1 : find_elsewhere(); c1 = -2; }
                 if (c0 == (int)TQ_NONE) c1 = c0;
                 else if (c1 == -2) c1 = find_elsewhere();
@@ -2211,8 +2214,12 @@ struct GemmKnobs {
                        //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
     int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
                        //                                        15 = all four); a served call is not considered for stream-K
-    int dynamic;       // "gemm_dynamic"    DEVIAS_GEMM_DYNAMIC  1 (default): the persistent kernel's workgroups pull their tiles from per-XCD queues at run time
-                       //                                        (robust to CUs held or slowed by a concurrent kernel); 0 = the static per-workgroup tile lists
+    int dynamic;       // "gemm_dynamic"    DEVIAS_GEMM_DYNAMIC  1: the persistent kernel's workgroups pull their tiles from per-XCD queues at run time (robust to CUs
+                       //                                        held or slowed by a concurrent kernel: -2.5 ms per step with 16 CUs held during backward, profiles/
+                       //                                        r4_cu_hog.txt); 0: the static per-workgroup tile lists (0.3 ms per step faster when the GPU is the
+                       //                                        step's alone); -1 (default): queues exactly when the host has announced concurrent kernels
+    int concurrent;    // "gemm_concurrent" DEVIAS_GEMM_CONCURRENT  the host runs other kernels beside the step's (devias_amd.parallel.GradSync sets it when the
+                       //                                        gradient all-reduce runs on its side stream, bench.py --cu-hog too); default 0
     int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent / stream-K grids leave this many CUs free (default 0).  Their static tile
                        //                                        lists assume one resident workgroup per CU of the grid: with K CUs held by another kernel
                        //                                        (RCCL during backward at N > 1) the K workgroups that find no CU run AFTER the others --
@@ -2233,7 +2240,8 @@ GemmKnobs& knobs() {
         x.sk_mink = env_int("DEVIAS_GEMM_SK_MINK", 32);
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
         x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
-        x.dynamic = env_int("DEVIAS_GEMM_DYNAMIC", 1);
+        x.dynamic = env_int("DEVIAS_GEMM_DYNAMIC", -1);
+        x.concurrent = env_int("DEVIAS_GEMM_CONCURRENT", 0);
         x.w4 = env_int("DEVIAS_GEMM_W4", 0);
         x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 2);
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
@@ -2284,6 +2292,7 @@ int devias_gemm_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_smallm")) k.smallm = value;
     else if (!strcmp(name, "gemm_reserve_cus")) k.reserve = value < 0 ? 0 : value;
     else if (!strcmp(name, "gemm_dynamic")) k.dynamic = value;
+    else if (!strcmp(name, "gemm_concurrent")) k.concurrent = value;
     else return 0;
     return 1;
 }
@@ -2406,7 +2415,10 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         p.tiles_m = a->M / T2; p.tiles_n = a->N / T2;
         const int ta = a->trans_a, tb = a->trans_b;
         const int nt = p.tiles_m * p.tiles_n;
-        const int gp = devias_policy_gemm_cus();
+        // grid of the persistent forms: one workgroup per CU the policy counts on.  With the dynamic queues a reserve is pointless for THEM (a workgroup that
+        // finds no CU pulls nothing): they launch on every CU, and gemm_reserve_cus then only sizes the weight-gradient split-K (one round of the CUs left)
+        const bool dyn = kn.dynamic > 0 || (kn.dynamic < 0 && kn.concurrent != 0);
+        const int gp = (dyn && kn.streamk == 0 && kn.w4 == 0) ? (kn.ncu & ~7) : devias_policy_gemm_cus();
         // persistent form (more than one round of tiles, no split-K, bf16 output): measured per shape at M = 50176 (tools/gemm_block_shapes.py, same
         // box, one-tile-per-workgroup -> persistent): qkv 226 -> 204 us, fc1 278 -> 243, dfc2 + dGELU + colsum 415 -> 349, dfc2 plain 275 -> 248,
         // dproj 81 -> 72; the long-K dgrad shapes unchanged (dfc1 252, dqkv 192)
@@ -2454,7 +2466,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         } else if (kn.persistent && pers_ok && nt > gp) {
             dim3 grid(gp), block(NT2);
             // dynamic queue: every XCD queue has at least one (reserved) item per workgroup, at most 32 workgroups per XCD (one claim-mask word)
-            unsigned int* tq = (kn.dynamic && a->K >= 128 && (gp >> 3) <= 32 && (nt >> 3) >= (gp >> 3)) ? tile_queue_base() : nullptr;
+            unsigned int* tq = (dyn && a->K >= 128 && (gp >> 3) <= 32 && (nt >> 3) >= (gp >> 3)) ? tile_queue_base() : nullptr;
             if (tq) {
                 // dynamic tile queue (default): the item list of an XCD queue of cnt tiles -- whole tiles, then the halves of a split partial round --
                 // for the two queue lengths that occur; this launch's ring slot and the one it zeroes

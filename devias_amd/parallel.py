@@ -87,6 +87,11 @@ class GradSync:
         self._works = []
         self._side = None
         self._accumulate = False
+        if (self.world > 1 or self.simulate) and params[0].is_cuda:
+            # collectives (RCCL's kernels) will run beside backward: the persistent GEMMs pull their tiles from the dynamic queues, so that a CU the
+            # collective holds or slows down takes fewer tiles instead of turning into a straggler (library option gemm_concurrent)
+            from . import ops
+            ops.set_option("gemm_concurrent", 1)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.reset()
 

@@ -74,9 +74,10 @@ void devias_counters_reset(void);
  * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_tail_split" (2, default: the tiles of a persistent launch's last partial round are computed as
  * 128-row halves by two workgroups when at least half the CUs would idle, their idle waves staging no A rows; 1: staging all rows; 0: whole tiles), "gemm_streamk" (0 = never, default; 1 = by policy; 3 = wherever it can run), "gemm_sk_eff",
  * "gemm_sk_mink", "gemm_smallm" (1, default: bf16 products with M <= 128 and B k-contiguous run as ONE launch of the small-M kernel instead of split-K
- * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves, default 0), "gemm_debug", "gemm_dynamic" (1, default: the workgroups of
+ * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves, default 0), "gemm_debug", "gemm_dynamic" (1: the workgroups of
  * the persistent kernel pull their tiles from per-XCD queues at run time instead of walking static lists -- a CU held or slowed by a concurrent kernel, e.g. RCCL's during
- * backward, just takes fewer tiles; same bits), "gemm_reserve_cus" (CUs the big-tile grids and the weight-gradient split-K sizing leave free for such a kernel),
+ * backward, just takes fewer tiles; 0: static lists; -1, default: queues exactly when "gemm_concurrent" is set; same bits either way), "gemm_concurrent" (the host
+ * announces that other kernels run beside the step's: devias_amd.parallel.GradSync sets it for N > 1), "gemm_reserve_cus" (CUs the big-tile grids and the weight-gradient split-K sizing leave free for such a kernel),
  * "attn_cfg", "attn_xcd".  Every choice computes the same bits EXCEPT gemm_smallm (different K summation order) and gemm_reserve_cus (like the device's CU count it
  * sets the split-K factor of the weight-gradient GEMMs, hence their fp32 summation order: runs with different reserves -- or N = 1 against N > 1 runs that set one --
  * agree to rounding, not bitwise).  0 = ok, DEVIAS_EINVAL = unknown name. */

@@ -460,7 +460,7 @@ def gemm_options():
     o = ops()
     yield o
     for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 0), ("gemm_w4", 0), ("gemm_tail_split", 2), ("gemm_smallm", 1),
-                 ("gemm_dynamic", 1)):
+                 ("gemm_dynamic", -1), ("gemm_concurrent", 0)):
         o.set_option(k, v)
 
 
@@ -629,6 +629,14 @@ def test_gemm_dynamic_queue_with_held_cus(gemm_options):
         times.setdefault(dyn, []).append(e0.elapsed_time(e1))
         for a, b in outs:
             assert torch.equal(a, ref[0]) and torch.equal(b, ref[1]), dyn
+    # the default policy (gemm_dynamic = -1): static lists unless the host has announced concurrent kernels (GradSync does, for N > 1)
+    o.set_option("gemm_dynamic", -1)
+    for conc in (0, 1):
+        o.set_option("gemm_concurrent", conc)
+        o.counters(reset=True)
+        assert torch.equal(o.gemm(A, Wt, trans_b=True), ref[1])
+        cnt = o.counters()
+        assert (cnt["gemm256p"], cnt["gemm256d"]) == (1, conc), (conc, cnt)
     t_dyn, t_static = min(times[1]), min(times[0])
     print(f"12 persistent GEMM launches with 48 CUs held: static lists {t_static:.2f} ms, dynamic queues {t_dyn:.2f} ms")
     assert t_dyn < 0.85 * t_static, (t_dyn, t_static)

@@ -63,7 +63,7 @@ def test_oracle_loss_criteria_match_reference_golden(S, crit):
                                                 mask_prediction_loss_weight=1.0, mask_distill_loss_weight=3.0, scene_criterion=crit)
     total.backward()
     pre = f"s{S}.{crit}."
-    assert abs(float(total) - float(fx[pre + "total"])) < 1e-5 * abs(float(fx[pre + "total"]))
+    assert abs(float(total.detach()) - float(fx[pre + "total"])) < 1e-5 * abs(float(fx[pre + "total"]))
     got = [ld[k] for k in ("action_loss", "scene_loss", "cosine_loss", "mask_prediction_loss", "mask_distill_loss")]
     assert np.allclose(got, fx[pre + "losses"], rtol=1e-5, atol=1e-7)
     assert torch.stack(idx, dim=1).tolist() == fx[pre + "match"].tolist()
