@@ -297,9 +297,12 @@ def main():
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
                    "kernels": "persistent 256x256 GEMM (forward + dgrad; tail tiles of a partial round split between two workgroups), 32x32x16 MFMA attention forward, two-kernel MFMA attention backward, folded slot "
                               "cross-attention (K/V projections on the slot side); one library call per fused region and direction (csrc/regions.hip)"},
-        "host_enqueue_ms_per_step": host_idle[len(host_idle) // 2] * 1e3, "host_library_calls_per_step": lib_calls,
-        "host_enqueue_method": "one step enqueued on an idle stream, median of 5, outside the timed region (python + fused-region library calls + HIP launches)",
-        "host_enqueue_ms_per_step_back_to_back": host_enqueue / args.steps * 1e3,
+        # schema 4 (round 4): `host_enqueue_ms_per_step` has its round-1/2 meaning again (host time to enqueue the K timed steps back to back: a full launch
+        # queue throttles the host to the device's pace, so on a device-bound step it reads ~ the step time); the host's own cost is the idle-stream number
+        "schema": 4,
+        "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "host_library_calls_per_step": lib_calls,
+        "host_idle_enqueue_ms_per_step": host_idle[len(host_idle) // 2] * 1e3,
+        "host_idle_enqueue_method": "one step enqueued on an idle stream, median of 5, outside the timed region (python + fused-region library calls + HIP launches)",
         "device_ms_per_step": dev_ms / args.steps, "final_loss": loss_value, "peak_mem_gib": peak_mem,
     }
     if ach is not None:

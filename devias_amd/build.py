@@ -76,7 +76,8 @@ def build_asan(out_path: str) -> str:
     translation units -- api.hip (error strings, options, counters, RCCL / roctx resolution) and regions.hip (argument structs, arena layouts,
     workspace arithmetic of the fused regions) -- compiled with AddressSanitizer + UBSan on the HOST side only, linked with the regular objects
     of the kernel files.  Never run on the GPU box (GPU sanitizers are unavailable there); tests/test_sanitizer_cpu.py drives the
-    argument-validation paths of every entry point through it without touching a device."""
+    argument-validation paths of every entry point through it without launching anything (the workspace-size queries do ask the HIP runtime for the
+    current device's CU count; without a device they fall back to 256)."""
     build(force=False, verbose=False)                  # regular objects of the kernel translation units
     san = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-Xarch_host", "-fno-sanitize-recover=undefined", "-g"]
     objs = []

@@ -35,6 +35,20 @@ extern "C" int32_t devias_policy_gemm_cus(void);             // gemm.hip: CUs th
         if (!(cond)) return devias_set_error(DEVIAS_EINVAL, __VA_ARGS__); \
     } while (0)
 
+// compute units of the CURRENT device (cached per device id: a process that calls a size query before torch.cuda.set_device(local_rank) must not
+// pin device 0's count for the device it later runs on -- ADVICE r3)
+static inline int devias_device_cus() {
+    static int cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cache[dev];
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cache[dev] = v;
+    }
+    return v;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

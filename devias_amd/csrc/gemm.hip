@@ -2181,17 +2181,11 @@ extern "C" int64_t devias_gemm_workspace_bytes(int32_t M, int32_t N, int32_t spl
 
 // partial slots (one 256 x 256 fp32 tile per workgroup of the stream-K grid) + one 64-bit flag per workgroup + the error word
 extern "C" int64_t devias_gemm_streamk_workspace_bytes(void) {
-    int dev = 0, n = 256;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    const int64_t g = n & ~7;
+    const int64_t g = devias_device_cus() & ~7;
     return g * SK_SLOT_BYTES + ((g + 1) * 8 + 255) / 256 * 256;
 }
 extern "C" int64_t devias_gemm_streamk_error_offset(void) {
-    int dev = 0, n = 256;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    const int64_t g = n & ~7;
+    const int64_t g = devias_device_cus() & ~7;
     return g * SK_SLOT_BYTES + g * 8;
 }
 
@@ -2245,10 +2239,7 @@ GemmKnobs& knobs() {
         x.w4 = env_int("DEVIAS_GEMM_W4", 0);
         x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 2);
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
-        int dev = 0, n = 256;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        x.ncu = n;
+        x.ncu = 0;                                        // (unused: the CU count is the current device's at every call, devias_device_cus())
         return x;
     }();
     return k;
@@ -2273,7 +2264,8 @@ static unsigned int* tile_queue_base() {
 // CUs the big-tile grids may count on: the device's, minus the reserve (option gemm_reserve_cus), in whole XCD rows
 extern "C" int32_t devias_policy_gemm_cus(void) {
     const GemmKnobs& k = knobs();
-    return (k.ncu - k.reserve > 8 ? k.ncu - k.reserve : 8) & ~7;
+    const int ncu = devias_device_cus();
+    return (ncu - k.reserve > 8 ? ncu - k.reserve : 8) & ~7;
 }
 
 int devias_gemm_set_option(const char* name, int value) {
@@ -2418,7 +2410,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         // grid of the persistent forms: one workgroup per CU the policy counts on.  With the dynamic queues a reserve is pointless for THEM (a workgroup that
         // finds no CU pulls nothing): they launch on every CU, and gemm_reserve_cus then only sizes the weight-gradient split-K (one round of the CUs left)
         const bool dyn = kn.dynamic > 0 || (kn.dynamic < 0 && kn.concurrent != 0);
-        const int gp = (dyn && kn.streamk == 0 && kn.w4 == 0) ? (kn.ncu & ~7) : devias_policy_gemm_cus();
+        const int gp = (dyn && kn.streamk == 0 && kn.w4 == 0) ? (devias_device_cus() & ~7) : devias_policy_gemm_cus();
         // persistent form (more than one round of tiles, no split-K, bf16 output): measured per shape at M = 50176 (tools/gemm_block_shapes.py, same
         // box, one-tile-per-workgroup -> persistent): qkv 226 -> 204 us, fc1 278 -> 243, dfc2 + dGELU + colsum 415 -> 349, dfc2 plain 275 -> 248,
         // dproj 81 -> 72; the long-K dgrad shapes unchanged (dfc1 252, dqkv 192)

@@ -14,10 +14,7 @@ namespace {
 #define DEVIAS_LNF_WGS_PER_CU 8
 #endif
 enum { LN_WAVES = 4, LN_MAXIT = 16, LNB_MIN_ROWS = 32, LNB_ONE_WG_ROWS = 256, LNF_WGS_PER_CU = DEVIAS_LNF_WGS_PER_CU };
-int ln_ncu() {
-    static int n = [] { int dev = 0, v = 256; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
-    return n;
-}
+int ln_ncu() { return devias_device_cus(); }
 
 
 template <typename T> struct Raw4;

@@ -157,6 +157,18 @@ _WCACHE = _WeightCache()
 _COLSUM_STATS = {"hit": 0, "miss": 0}
 
 
+def _region_state(ctx, who: str, x: torch.Tensor):
+    """The fused-region Functions keep their arena, weight copies and argument struct on `ctx` as raw pointers (not save_for_backward: the arena is
+    written by the library, not by autograd) and drop them after ONE backward.  A second backward (retain_graph=True) or an input modified in place
+    between forward and backward must fail with a message, not with a TypeError on None or silently wrong gradients."""
+    if ctx.keep is None:
+        raise RuntimeError(f"{who}: backward already consumed this region's saved arena; the fused regions support ONE backward per forward "
+                           "(run forward again instead of retain_graph=True)")
+    if x._version != ctx.x_version:
+        raise RuntimeError(f"{who}: the region's input was modified in place between forward and backward (version {ctx.x_version} -> {x._version}); "
+                           "its saved activations no longer match it")
+
+
 def _publish_colsum(dx: torch.Tensor, cs: torch.Tensor) -> None:
     dx._devias_colsum = (cs, dx.data_ptr(), dx._version)
 
@@ -750,6 +762,7 @@ class EncoderBlockRegionFn(Function):
         ctx.args = a
         ctx.meta = meta
         ctx.keep = (keep, save, ds1, ds2, x)
+        ctx.x_version = x._version
         ctx.params = (n1w, n1b, qkvw, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b)
         return x2
 
@@ -757,6 +770,7 @@ class EncoderBlockRegionFn(Function):
     def backward(ctx, dx2):
         B, N, H, eps, cdt = ctx.meta
         lib = _L.load()
+        _region_state(ctx, "EncoderBlockRegionFn", ctx.keep[4] if ctx.keep is not None else None)
         a = ctx.args
         keep, save, ds1, ds2, x = ctx.keep
         (p_n1w, p_n1b, p_qkvw, p_pw, p_pb, p_n2w, p_n2b, p_f1w, p_f1b, p_f2w, p_f2b) = ctx.params
@@ -813,12 +827,14 @@ class HeadRegionFn(Function):
         _L.check(lib.devias_head_fwd(_ct.byref(a), slots.data_ptr(), Z.data_ptr(), Mk.data_ptr(), save.data_ptr(), ops._stream()), "devias_head_fwd")
         ctx.args = a
         ctx.keep = (keep, save, slots, Mk, drop_mask)
+        ctx.x_version = slots._version
         ctx.params = (hw, hb, w0, b0, w2, b2, w4, b4)
         return Z, Mk
 
     @staticmethod
     def backward(ctx, dZ, dM):
         lib = _L.load()
+        _region_state(ctx, "HeadRegionFn", ctx.keep[2] if ctx.keep is not None else None)
         a = ctx.args
         keep, save, slots, Mk, drop_mask = ctx.keep
         hw, hb, w0, b0, w2, b2, w4, b4 = ctx.params
@@ -877,10 +893,13 @@ class AggBlockRegionFn(Function):
         attn_ptr = _ct.c_void_p()
         _L.check(lib.devias_agg_block_fwd(_ct.byref(a), x.data_ptr(), slots.data_ptr(), _ct.byref(attn_ptr), ops._stream()), "devias_agg_block_fwd")
         off = attn_ptr.value - save.data_ptr()
-        attn = save[off:off + B * heads * S * N * 4].view(torch.float32).view(B * heads, S, N)       # the last layer's slot softmax, inside the arena
+        # the last layer's slot softmax is a VIEW of the arena (no copy of 2.4 MB per step): whoever keeps `attn` alive keeps the whole arena alive,
+        # and it is overwritten by nothing (an arena belongs to one forward); clone it to hold it beyond the step
+        attn = save[off:off + B * heads * S * N * 4].view(torch.float32).view(B * heads, S, N)
         ctx.args = a
         ctx.meta = meta
         ctx.keep = (keep, save, x)
+        ctx.x_version = x._version
         ctx.params = (norm_w, norm_b, latents, last_w, last_b, LP)
         return slots, attn
 
@@ -888,6 +907,7 @@ class AggBlockRegionFn(Function):
     def backward(ctx, dslots, dattn):
         B, N, S, depth, tied, heads, dh, eps_enc, eps_agg, cdt = ctx.meta
         lib = _L.load()
+        _region_state(ctx, "AggBlockRegionFn", ctx.keep[2] if ctx.keep is not None else None)
         a = ctx.args
         keep, save, x = ctx.keep
         norm_w, norm_b, latents, last_w, last_b, LP = ctx.params

@@ -650,6 +650,31 @@ def attn_options():
     o.set_option("attn_xcd", 1)
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 100, 3), (1, 1569, 1), (3, 130, 8)])
+def test_mhsa_tail_tiles_read_zero_not_what_lies_behind_the_tensor(B, N, H, attn_options):
+    """The tile DMA of the attention kernels does not clamp rows past N: for the LAST batch entry's ragged tail tile they lie beyond the tensor, and the
+    buffer descriptor's range check (num_records = bytes to the end of qkv / d_o) has to return zeros for them -- not the bytes that happen to follow.
+    Here qkv, o and d_o are prefixes of larger buffers whose remainder is NaN (0 * NaN would poison P.V and dS.Q): forward and backward must be finite and
+    BITWISE equal to the same call on stand-alone tensors."""
+    o = attn_options
+    scale = 0.125
+    qkv = rnd(B * N, 3 * H * 64, dtype=torch.bfloat16, seed=60)
+    d_o = rnd(B * N, H * 64, dtype=torch.bfloat16, seed=61)
+    out, lse = o.mhsa_fwd(qkv, B, N, H, scale)
+    res = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale)
+
+    def prefix_of_nan(t, extra_rows=192):
+        big = torch.full((t.shape[0] + extra_rows, t.shape[1]), float("nan"), dtype=t.dtype, device=t.device)
+        big[:t.shape[0]].copy_(t)
+        return big[:t.shape[0]]                           # contiguous view: same data pointer arithmetic, NaN right behind the last row
+
+    qkv2, d_o2 = prefix_of_nan(qkv), prefix_of_nan(d_o)
+    out2, lse2 = o.mhsa_fwd(qkv2, B, N, H, scale)
+    assert torch.isfinite(out2.float()).all() and torch.equal(out2, out) and torch.equal(lse2, lse)
+    res2 = o.mhsa_bwd(qkv2, prefix_of_nan(out), d_o2, lse, B, N, H, scale)
+    assert torch.isfinite(res2.float()).all() and torch.equal(res2, res)
+
+
 @pytest.mark.parametrize("B,N,H", [(1, 64, 1), (2, 100, 3), (1, 784, 2), (1, 1569, 1), (2, 200, 6), (8, 1568, 12), (3, 130, 8), (2, 6401, 4)])
 @pytest.mark.parametrize("xcd", [1, 0])
 def test_mhsa_bwd_grids_and_ragged_shapes(B, N, H, xcd, attn_options):

@@ -1,5 +1,5 @@
 """AddressSanitizer + UBSan build of the library's host-only translation units (api.hip, regions.hip) driven through the argument-validation
-paths of the C ABI -- no device is touched (validation precedes every launch) and nothing here runs on the GPU box.  SURVEY.md §5 lists the
+paths of the C ABI -- no kernel is launched (validation precedes every launch; the size queries ask the HIP runtime for the current device's CU count, which answers "no device" here and falls back to 256) and nothing here runs on the GPU box.  SURVEY.md §5 lists the
 sanitizer build among the aux subsystems this stack adds (the reference is pure Python and has none)."""
 import glob
 import os
