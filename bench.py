@@ -88,6 +88,59 @@ def cpu_baseline(args):
                       f"{args.model} {args.frames}x{args.img_size}^2, {torch.get_num_threads()} of {os.cpu_count()} host cores (PyTorch CPU kernels stop scaling beyond)"}
 
 
+def pmc_traffic(kernel_substr: str) -> dict:
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r4_pmc/summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes over tools/pmc_probe.py, 2 x FETCH + WRITE with the gfx950 correction) -- quoted only while the profile was taken on the kernel sources this run
+    uses (devias_amd.build.source_hash); otherwise null with the reason (no literal that a kernel change leaves stale)."""
+    path = os.path.join(ROOT, "profiles", "r4_pmc", "summary.json")
+    try:
+        from devias_amd import build
+        prof = json.load(open(path))
+        cur = build.source_hash()
+        hit = [(k, v) for k, v in prof["kernels"].items() if kernel_substr in k and "traffic_bytes" in v]
+        if not hit:
+            return {"traffic": None, "traffic_note": f"{kernel_substr} is not in profiles/r4_pmc/summary.json"}
+        if prof.get("source_hash") != cur:
+            return {"traffic": None, "traffic_note": f"profiles/r4_pmc/summary.json was taken on kernel sources {prof.get('source_hash')}, this run uses {cur}: "
+                                                     f"stale ({hit[0][1]['traffic_bytes']:.4g} B then); re-run tools/runs/r4_pmc.sh"}
+        k, v = hit[0]
+        return {"traffic": v["traffic_bytes"], "traffic_dur_us_under_pmc": v["dur_us"],
+                "traffic_source": f"profiles/r4_pmc/summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; kernel sources {cur})"}
+    except (OSError, ValueError, KeyError) as e:
+        return {"traffic": None, "traffic_note": f"no usable PMC profile: {e}"}
+
+
+def trace_top_kernel_probe(args, device):
+    """The kernel at the top of the step's rocprofv3 trace (profiles/*_kernel_stats.csv row 1): the weight-gradient GEMM gemm256_kernel<true, true, 0>
+    (both operands k-strided, split-K over M, 16 % of the step), timed live on its largest launch, the fc1 weight gradient dW1 = dY^T X."""
+    from devias_amd import ops
+    D = {"vit_base": 768, "vit_small": 384, "vit_large": 1024}[args.model]
+    M = args.batch * (args.frames // 2) * (args.img_size // 16) ** 2
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dy = torch.randn(M, 4 * D, device=device).to(dt)
+    x = torch.randn(M, D, device=device).to(dt)
+    call = lambda: ops.wgrad(dy, x)  # noqa: E731
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    fl = 2.0 * M * 4 * D * D
+    es = 2 if dt == torch.bfloat16 else 4
+    probe = {"name": "gemm256_kernel<true, true, 0> 256x256x64 LDS-DMA, split-K over M + fixed-order slab reduce: fc1 weight gradient (row 1 of the step's kernel trace)",
+             "flop_per_launch": fl, "avg_ms": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
+             "avg_ms_includes": "the split-K reduce launch that follows the product",
+             "algorithmic_bytes": (M * 4 * D + M * D) * es + 4 * D * D * 4}
+    if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
+        probe.update(pmc_traffic("gemm256_kernel<true, true, 0"))
+    return probe
+
+
 def dominant_kernel_probe(args, device):
     """Live HIP-event timing (on torch's current stream = the stream the kernels are launched on) of the dominant kernel
     class, the persistent 256x256 MFMA GEMM, on the fc1 launch of this workload's encoder block."""
@@ -116,10 +169,7 @@ def dominant_kernel_probe(args, device):
              "flop_per_launch": fl, "avg_ms": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
              "algorithmic_bytes": (M * D + 4 * D * D + 2 * M * 4 * D) * es}
     if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
-        # HBM-side bytes per launch from the committed PMC passes of this same launch (profiles/r3_pmc: 2*FETCH_SIZE + WRITE_SIZE,
-        # the gfx950 FETCH_SIZE correction applied; round 2: 1080.4 MB)
-        probe["traffic"] = 1.0895e9
-        probe["traffic_source"] = "profiles/r3_pmc/README.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        probe.update(pmc_traffic("gemm256p_kernel<false, 0"))
     return probe
 
 
@@ -231,9 +281,6 @@ def main():
         host_idle.append(time.perf_counter() - th)
     torch.cuda.synchronize()
     host_idle.sort()
-    from devias_amd import ops as _ops
-    if _ops.streamk_timeouts():
-        raise SystemExit("bench.py: a stream-K GEMM hand-off timed out during the run (results invalid)")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -309,7 +356,8 @@ def main():
         line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
                             "scope": f"whole step per GPU: {gflop} algorithmic GFLOP/clip x {B} clips / step time",
-                            "dominant_kernel": dominant_kernel_probe(args, device)}
+                            "dominant_kernel": dominant_kernel_probe(args, device),
+                            "trace_top_kernel": trace_top_kernel_probe(args, device)}
     if full is not None:
         line["full_step"] = full
     if world == 1 and not args.no_cpu_baseline:

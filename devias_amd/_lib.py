@@ -104,8 +104,6 @@ PROTOTYPES = {
     "devias_set_option": (c_int, [c_char_p, c_int32]),
     "devias_gemm": (c_int, [POINTER(GemmArgs), _P]),
     "devias_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
-    "devias_gemm_streamk_workspace_bytes": (c_int64, []),
-    "devias_gemm_streamk_error_offset": (c_int64, []),
     "devias_cast": (c_int, [_P, _I, _P, _I, _L, _P]),
     "devias_cast_scale": (c_int, [_P, _I, _P, _I, _L, c_float, _P]),
     "devias_patch_im2col": (c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

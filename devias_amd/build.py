@@ -27,6 +27,18 @@ def _flags(src: str):
     return FLAGS
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources, the C ABI header and the compiler flags: identifies the code a library / a profile was built from
+    without needing .git (the GPU box has none).  bench.py quotes PMC traffic only from a profile whose hash matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES) + ["common.h", "roctx_shim.h"]:
+        h.update(name.encode()); h.update(open(os.path.join(CSRC, name), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "devias_amd.h"), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -13,7 +13,6 @@
 #include <utility>
 #include <stdlib.h>
 #include <string.h>
-#include <time.h>
 #include <atomic>
 
 namespace {
@@ -38,7 +37,6 @@ struct GemmP {
                           // 128 = without its pre-activation stores, 256 = without the GELU / dGELU polynomial
     int tail_split;       // gemm256p_kernel: split the tiles of the last partial round between two workgroups (128-row halves)
     int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
-    float* sk_part; unsigned long long* sk_flag; unsigned long long sk_epoch;   // stream-K kernel: partial slots, flags (+ error word), this launch's tag
     // dynamic tile queue of gemm256p_kernel<.., true>: this launch's queue slot (8 per-XCD heads, one per 128-byte line, + the line of claim masks; all zero
     // when the launch starts), the ring slot this launch zeroes for a later one, and the item list of a queue (nwhole whole tiles, then the halves of the split tail tiles)
     // for the two queue lengths that occur: [0] = queues of ntiles / 8 + 1 tiles, [1] = of ntiles / 8
@@ -965,7 +963,7 @@ __device__ __forceinline__ int tq_read(const char* word, unsigned seq) {
 
 template <bool TB, int SIDE, bool DYN>
 __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2 + (DYN ? 16 : 0)];     // (+ the published next item: ONE LDS object, see the stream-K note)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2 + (DYN ? 16 : 0)];     // (+ the published next item: ONE LDS object -- a second __shared__ object makes the compiler fence every LDS read behind the LDS-DMA in flight)
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef DEVIAS_GEMM_DEBUG
     const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
@@ -1265,223 +1263,6 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing re-read must land before the LDS is released
-    }
-}
-
-
-// =====================================================================================================================
-// Stream-K form of the persistent 256 x 256 kernel (gemm256sk_kernel).  Two things bound the data-parallel kernels at the step's shapes:
-// tile-count quantisation (588 tiles on 256 CUs = 3 rounds for 2.3 rounds of work) and the epilogue store bursts -- every CU finishes
-// its tile at the same moment, 256 x (128..256 KiB) hit HBM together while the matrix cores idle, then HBM idles for a whole K loop.
-// Here each XCD group (G/8 workgroups, one per CU) owns the same contiguous tile range as in gemm256p_kernel, but only its first
-// rounds are handed out whole: the LAST sk = W + (cnt mod W) tiles (W = G/8; all of them when cnt < 2 W) are cut along K into W equal
-// contiguous ranges of K-iterations, one per workgroup -- every workgroup does the same number of K-iterations (+-1).  A range covers,
-// in this processing order:
-//   1. the HEAD fragment [0, e) of the tile its end falls into -> the fp32 accumulators go to this workgroup's partial slot, flag published;
-//   2. one whole tile (of the stream-K region, or its first data-parallel tile);
-//   3. the TAIL fragment [b, nk) of the tile its start falls into: the accumulators are INITIALISED from the partial the previous
-//      workgroup (j - 1) published as its first item -- more than a tile's time ago, so the wait is a formality -- and the tile's MFMA
-//      chain is the unsplit one, continued: results are bitwise those of the data-parallel kernels, run to run and kernel to kernel;
-//      (third, not last: at the very end all 256 workgroups would fetch their 256 KiB partials in the same microseconds)
-//   4. the remaining whole tiles: stream-K region, then data-parallel tiles (j, j + W, ...).
-// Head fragments have different lengths, so the workgroups of a group are at different phases of their tiles for the rest of the
-// launch: the store bursts interleave with other CUs' K loops instead of piling up.
-// Hand-off (MI355X_MICROARCH.md, "hand-offs measured with sc1 loads", row 1): 16-byte sc1 stores of the partial by every wave; each
-// wave's next two K-loop waits drain them (vmcnt counts in issue order); after the second workgroup barrier that follows, ONE lane
-// publishes the launch's epoch (a process-wide 64-bit counter: no reset pass, stale memory cannot match) with an agent-scope store;
-// the consumer polls with agent-scope loads (one lane, bounded: 2 s, then the error word is set instead of hanging), workgroup
-// barrier, 16-byte sc1 loads.  A waiter only ever waits for a LOWER workgroup id (dispatched earlier), whose publishing item is its first.
-// =====================================================================================================================
-enum { SK_SLOT_BYTES = 262144, SK_MAX_ITEMS = 128 };
-// the launch's tag, re-read from the scalar kernel arguments where it is needed (kept in a VGPR pair across the K loop it gets spilled)
-__device__ __forceinline__ unsigned long long epoch_here(const GemmP& p) {
-    unsigned lo = (unsigned)p.sk_epoch, hi = (unsigned)(p.sk_epoch >> 32);
-    asm volatile("" : "+s"(lo), "+s"(hi));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-template <bool TB, int SIDE>
-__global__ __launch_bounds__(NT2) void gemm256sk_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2 + SK_MAX_ITEMS * 16];   // operand ring + this workgroup's item list (ONE LDS object:
-                                                                                        // a second one makes the compiler fence every LDS read behind the in-flight LDS-DMA)
-    const int tid = threadIdx.x, lane = tid & 63;
-#ifdef DEVIAS_GEMM_DEBUG
-    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
-#endif
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int nk = p.K / 64;
-    const bf16* A = reinterpret_cast<const bf16*>(p.A);
-    const bf16* B = reinterpret_cast<const bf16*>(p.B);
-    const int xcd = blockIdx.x & 7, W = gridDim.x >> 3, j = blockIdx.x >> 3;
-    const int q = ntiles >> 3, r = ntiles & 7;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int cnt = q + (xcd < r ? 1 : 0);                 // >= W (host)
-    const int sk = cnt >= 2 * W ? W + cnt % W : cnt;       // tiles of the stream-K region: the last sk of the range
-    const int skb = cnt - sk, dp_rounds = skb / W;
-    const int64_t S0 = (int64_t)j * sk * nk / W, S1 = (int64_t)(j + 1) * sk * nk / W;
-    const int b = (int)(S0 % nk), tile_t = (int)(S0 / nk);
-    const int e = (int)(S1 % nk), tile_h = (int)(S1 / nk);
-    const int first_full = (int)((S0 + nk - 1) / nk), nfull = (int)(S1 / nk) - first_full;
-    const int has_head = e > 0 ? 1 : 0, has_tail = b > 0 ? 1 : 0;
-    const int nitems = has_head + nfull + dp_rounds + has_tail;                // <= SK_MAX_ITEMS (host)
-    // the item list of this workgroup, built once by its first threads: {m0, n0, first K-tile, end K-tile | kind << 24};
-    // kind 0 = whole tile, 1 = head fragment -> publish, 2 = tail fragment <- partial.  The loop keeps only the current item in scalars.
-    int4* item_tab = reinterpret_cast<int4*>(smem + 2 * STAGE2);
-    if (tid < nitems) {
-        const int n = tid;
-        int t, kb = 0, ke = nk, kind = 0;
-        const int pos_tail = has_head + ((nfull + dp_rounds) > 0 ? 1 : 0);
-        if (n < has_head) { t = skb + tile_h; ke = e; kind = 1; }
-        else if (has_tail && n == pos_tail) { t = skb + tile_t; kb = b; kind = 2; }
-        else {
-            const int w = n - has_head - ((has_tail && n > pos_tail) ? 1 : 0);    // index among the whole tiles: stream-K region first, then j, j + W, ...
-            t = w < nfull ? skb + first_full + w : j + W * (w - nfull);
-        }
-        int tm, tn;
-        tile_coords(base + t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-        item_tab[n] = int4{tm * T2, tn * T2, kb, ke | (kind << 24)};
-    }
-    __syncthreads();
-    auto item = [&](int n, int& m0, int& n0, int& kb, int& ke, int& kind) {
-        const int4 it = item_tab[n];
-        m0 = __builtin_amdgcn_readfirstlane(it.x); n0 = __builtin_amdgcn_readfirstlane(it.y);
-        kb = __builtin_amdgcn_readfirstlane(it.z);
-        const int w = __builtin_amdgcn_readfirstlane(it.w);
-        ke = w & 0xffffff; kind = w >> 24;
-    };
-    int m0, n0, kb, ke, kind;
-    item(0, m0, n0, kb, ke, kind);
-    glds_tile<false>(A, p.lda, m0, kb * 64, smem, wave, lane);
-    glds_tile<TB>(B, p.ldb, n0, kb * 64, smem + 32768, wave, lane);
-    int ni = 1;                                            // index of the next item
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int pub = 0;                                           // > 0: workgroup barriers left before this workgroup's partial may be published
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef DEVIAS_GEMM_DEBUG
-    // gemm_debug & 8: thread 0 logs (100 MHz clock << 4 | code) into ws + 64 * blockIdx.x: 1 = an item's first K-tile about to be multiplied, 2 = its K loop done,
-    // 3 = epilogue / partial store issued, 5 = about to wait for the predecessor's partial, 6 = partial loaded
-    int nlog = 0;
-    auto sstamp = [&](int code) {
-        if (GDBG(8) && tid == 0 && nlog < 64) {
-            const unsigned long long v = (__builtin_amdgcn_s_memrealtime() << 4) | (unsigned long long)code;
-            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)nlog * 8), "v"(v), "s"(reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 64) : "memory");
-        }
-        ++nlog;
-    };
-#define SSTAMP(c) sstamp(c)
-    if (GDBG(8) && tid == 0) {           // slot 63: the workgroup's entry time
-        const unsigned long long v = (t_entry << 4) | 7ull;
-        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)63 * 8), "v"(v), "s"(reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 64) : "memory");
-    }
-#else
-#define SSTAMP(c)
-#endif
-    for (int g = 0, kt = kb;; ++g) {
-        __builtin_amdgcn_s_barrier();                      // K-tile g has landed for every wave, and everyone is done reading stage (g + 1) & 1
-        asm volatile("" ::: "memory");
-        if (pub > 0) {                                     // (pub is wave-uniform: scalar)
-            pub = __builtin_amdgcn_readfirstlane(pub - 1);
-            if (pub == 0 && (wave == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)) __hip_atomic_store(p.sk_flag + blockIdx.x, epoch_here(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (kt == kb) SSTAMP(1);
-        char* cur = smem + (g & 1) * STAGE2;
-        char* nxt = smem + ((g + 1) & 1) * STAGE2;
-        // source of K-tile g + 1: this item's next one, or the next item's first; at the very end a harmless re-read
-        const bool same = kt + 1 < ke;
-        const bool has_next = ni < nitems;
-        int am = m0, bn = n0, kn = (same ? kt + 1 : kt) * 64;
-        if (!same && has_next) {                           // (one LDS read per item)
-            const int4 it = item_tab[ni];
-            am = __builtin_amdgcn_readfirstlane(it.x); bn = __builtin_amdgcn_readfirstlane(it.y);
-            kn = __builtin_amdgcn_readfirstlane(it.z) * 64;
-        }
-        // the lane id is recomputed per K-tile (v_mbcnt) and made opaque: the per-lane LDS / LDS-DMA offsets derived from it are then cheap VALU work of
-        // every iteration instead of registers that stay live across the epilogue, whose register peak is the kernel's
-        int lane_k = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        asm volatile("" : "+v"(lane_k));
-        if constexpr (!TB) {
-            ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
-        } else {
-            glds_tile<false>(A, p.lda, am, kn, nxt, wave, lane_k);
-            glds_tile<true>(B, p.ldb, bn, kn, nxt + 32768, wave, lane_k);
-            ktile_generic<false, true>(acc, cur, lane_k, wm, wn);
-        }
-        if (same) {
-            ++kt;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's LDS-DMA for K-tile g + 1 has landed
-            continue;
-        }
-        SSTAMP(2);
-        if (kind == 1) {
-            // head fragment: the fp32 accumulators, fragment order (1 KiB per instruction), write-through
-            const char* slot = reinterpret_cast<const char*>(p.sk_part) + (int64_t)blockIdx.x * SK_SLOT_BYTES + wave * 32768;
-            uint32_t vb = (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 16;
-            asm volatile("" : "+v"(vb));                   // opaque: the 32 store offsets are computed here, not hoisted out of the K loop as 32 live registers
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(vb + (uint32_t)(i * 4 + jj) * 1024), "v"(*reinterpret_cast<const u32x4*>(&acc[i][jj])),
-                                 "s"(slot) : "memory");
-            pub = 2;
-        } else {
-            // the lane id is recomputed (v_mbcnt), not kept: neither it nor the epilogue's per-lane address arithmetic occupies registers across the K loop
-            int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            asm volatile("" : "+v"(lane_e));
-            epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
-        }
-        SSTAMP(3);
-        if (!has_next) break;
-        // >= 16 stores per wave were issued AFTER the DMA of the next item's first K-tile: wait for the DMA only, the stores drain under the next MFMAs
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        item(ni, m0, n0, kb, ke, kind);
-        kt = kb;
-        ++ni;
-        if (kind == 2) {
-            // tail fragment: continue the chain the previous workgroup of this group started (its slot, its flag)
-            SSTAMP(5);
-            if ((wave == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)) {
-                const unsigned long long* f = p.sk_flag + (blockIdx.x - 8);
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                const unsigned long long want = epoch_here(p);
-                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {       // 2 s of the 100 MHz counter: flag it, do not hang
-                        __hip_atomic_store(p.sk_flag + gridDim.x, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.sk_part) + (int64_t)(blockIdx.x - 8) * SK_SLOT_BYTES, 0, SK_SLOT_BYTES, 0x00020000);
-            uint32_t vb = (uint32_t)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 16;
-            asm volatile("" : "+v"(vb));                   // opaque, as above
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vb, (wave * 32 + i * 4 + jj) * 1024, 16);
-                    acc[i][jj] = *reinterpret_cast<const f32x4*>(&v);
-                }
-            __builtin_amdgcn_s_waitcnt(0x0F70);            // (once per workgroup: also drains the previous tile's stores)
-            SSTAMP(6);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing re-read must land before the LDS is released; partial stores are drained
-    if (pub > 0) {                                         // (a head fragment followed by fewer than two K-iterations)
-        __syncthreads();
-        if ((wave == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)) __hip_atomic_store(p.sk_flag + blockIdx.x, epoch_here(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2179,16 +1960,6 @@ extern "C" int64_t devias_gemm_workspace_bytes(int32_t M, int32_t N, int32_t spl
     return split_k > 1 ? (int64_t)split_k * M * N * 4 : 0;
 }
 
-// partial slots (one 256 x 256 fp32 tile per workgroup of the stream-K grid) + one 64-bit flag per workgroup + the error word
-extern "C" int64_t devias_gemm_streamk_workspace_bytes(void) {
-    const int64_t g = devias_device_cus() & ~7;
-    return g * SK_SLOT_BYTES + ((g + 1) * 8 + 255) / 256 * 256;
-}
-extern "C" int64_t devias_gemm_streamk_error_offset(void) {
-    const int64_t g = devias_device_cus() & ~7;
-    return g * SK_SLOT_BYTES + g * 8;
-}
-
 // ---- process-wide options: read from the environment ONCE, changeable at run time through devias_set_option (tests, A/B tools) --------
 namespace {
 struct GemmKnobs {
@@ -2197,24 +1968,19 @@ struct GemmKnobs {
     int use_ss;        // "gemm_ss"         DEVIAS_GEMM_SS       -1 = measured policy, 0 = never, 1 = prefer the single-stage 256x128 kernel for k-strided layouts
     int group_m;       // "gemm_groupm"     DEVIAS_GEMM_GROUPM   0 = measured policy, > 0 forces the rasterisation group height
     int persistent;    // "gemm_persistent" DEVIAS_GEMM_PERSIST  != 0: persistent 256x256 kernel where it applies (default), 0 = one tile per workgroup
-    int streamk;       // "gemm_streamk"    DEVIAS_GEMM_SK       stream-K form of the persistent kernel (needs args.sk_ws): 0 = never (default since the tail split: in the
-                       //                                        step, three interleaved bench.py pairs, 51.35 ms with the policy vs 51.20 without), 1 = by policy,
-                       //                                        3 = wherever it can run (tests)
-    int sk_eff;        // "gemm_sk_eff"     DEVIAS_GEMM_SK_EFF   policy: tiles / (rounds * workgroups) below this many percent (default 80) ...
-    int sk_mink;       // "gemm_sk_mink"    DEVIAS_GEMM_SK_MINK  ... and at least this many K-tiles per output tile (default 32)
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
     int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K)
     int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups (1), whose idle waves
                        //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
     int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
-                       //                                        15 = all four); a served call is not considered for stream-K
+                       //                                        15 = all four; -1, default: all four where K >= 1024 and N >= 1024)
     int dynamic;       // "gemm_dynamic"    DEVIAS_GEMM_DYNAMIC  1: the persistent kernel's workgroups pull their tiles from per-XCD queues at run time (robust to CUs
                        //                                        held or slowed by a concurrent kernel: -2.5 ms per step with 16 CUs held during backward, profiles/
                        //                                        r4_cu_hog.txt); 0: the static per-workgroup tile lists (0.3 ms per step faster when the GPU is the
                        //                                        step's alone); -1 (default): queues exactly when the host has announced concurrent kernels
     int concurrent;    // "gemm_concurrent" DEVIAS_GEMM_CONCURRENT  the host runs other kernels beside the step's (devias_amd.parallel.GradSync sets it when the
                        //                                        gradient all-reduce runs on its side stream, bench.py --cu-hog too); default 0
-    int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent / stream-K grids leave this many CUs free (default 0).  Their static tile
+    int reserve;       // "gemm_reserve_cus" DEVIAS_GEMM_RESERVE_CUS  the persistent grids leave this many CUs free (default 0).  Their static tile
                        //                                        lists assume one resident workgroup per CU of the grid: with K CUs held by another kernel
                        //                                        (RCCL during backward at N > 1) the K workgroups that find no CU run AFTER the others --
                        //                                        a doubled tail, measured +17 % on the step with 8-32 CUs held (bench.py --cu-hog)
@@ -2229,14 +1995,11 @@ GemmKnobs& knobs() {
         x.use_ss = env_int("DEVIAS_GEMM_SS", -1);
         x.group_m = env_int("DEVIAS_GEMM_GROUPM", 0);
         x.persistent = env_int("DEVIAS_GEMM_PERSIST", 1);
-        x.streamk = env_int("DEVIAS_GEMM_SK", 0);
-        x.sk_eff = env_int("DEVIAS_GEMM_SK_EFF", 80);
-        x.sk_mink = env_int("DEVIAS_GEMM_SK_MINK", 32);
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
         x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
         x.dynamic = env_int("DEVIAS_GEMM_DYNAMIC", -1);
         x.concurrent = env_int("DEVIAS_GEMM_CONCURRENT", 0);
-        x.w4 = env_int("DEVIAS_GEMM_W4", 0);
+        x.w4 = env_int("DEVIAS_GEMM_W4", -1);
         x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 2);
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
         x.ncu = 0;                                        // (unused: the CU count is the current device's at every call, devias_device_cus())
@@ -2275,9 +2038,6 @@ int devias_gemm_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_ss")) k.use_ss = value;
     else if (!strcmp(name, "gemm_groupm")) k.group_m = value;
     else if (!strcmp(name, "gemm_persistent")) k.persistent = value;
-    else if (!strcmp(name, "gemm_streamk")) k.streamk = value;
-    else if (!strcmp(name, "gemm_sk_eff")) k.sk_eff = value;
-    else if (!strcmp(name, "gemm_sk_mink")) k.sk_mink = value;
     else if (!strcmp(name, "gemm_debug")) k.debug = value;
     else if (!strcmp(name, "gemm_w4")) k.w4 = value;
     else if (!strcmp(name, "gemm_tail_split")) k.tail_split = value;
@@ -2344,7 +2104,6 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     p.debug = kn.debug;
     p.tail_split = kn.tail_split;
     p.epi_swap = kn.epi_swap;
-    p.sk_part = nullptr; p.sk_flag = nullptr; p.sk_epoch = 0;
     p.tq = nullptr; p.tq_clear = nullptr; p.tq_nwhole[0] = p.tq_nwhole[1] = p.tq_items[0] = p.tq_items[1] = 0;
     // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
     // weight panel set of a group stays in the XCD's L2); narrow ones and the wgrad reductions are best n-fastest
@@ -2410,7 +2169,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         // grid of the persistent forms: one workgroup per CU the policy counts on.  With the dynamic queues a reserve is pointless for THEM (a workgroup that
         // finds no CU pulls nothing): they launch on every CU, and gemm_reserve_cus then only sizes the weight-gradient split-K (one round of the CUs left)
         const bool dyn = kn.dynamic > 0 || (kn.dynamic < 0 && kn.concurrent != 0);
-        const int gp = (dyn && kn.streamk == 0 && kn.w4 == 0) ? (devias_device_cus() & ~7) : devias_policy_gemm_cus();
+        const int gp = dyn ? (devias_device_cus() & ~7) : devias_policy_gemm_cus();
         // persistent form (more than one round of tiles, no split-K, bf16 output): measured per shape at M = 50176 (tools/gemm_block_shapes.py, same
         // box, one-tile-per-workgroup -> persistent): qkv 226 -> 204 us, fc1 278 -> 243, dfc2 + dGELU + colsum 415 -> 349, dfc2 plain 275 -> 248,
         // dproj 81 -> 72; the long-K dgrad shapes unchanged (dfc1 252, dqkv 192)
@@ -2424,33 +2183,20 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
             else { if (side == 0) hipLaunchKernelGGL((KERNEL<true, 0 __VA_ARGS__>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<true, 2 __VA_ARGS__>), grid, block, 0, st, p); } } while (0)
 #define COMMA_TRUE , true
 #define COMMA_FALSE , false
-        // stream-K form: the caller lent a partial-slot workspace, every XCD group has at least one tile per workgroup, and the tile count is
-        // not a multiple of the grid (otherwise it degenerates to the persistent kernel's schedule)
-        // stream-K form: the caller lent a partial-slot workspace, every XCD group has at least one tile per workgroup, and (policy, measured at
-        // M = 50176 with tools/gemm_block_shapes.py) whole rounds would idle more than (100 - sk_eff) % of the chip while K is long enough to
-        // amortise the hand-off (one 256 KiB partial written and read per workgroup, ~8 us): fc2 275 -> 263 us, dfc1 252 -> 239, dqkv 192 -> 183;
-        // at K = 768 the same 588-tile grids lose (proj 92 -> 100, dproj 72 -> 80), and grids with < 10 % quantisation loss always lose
-        // gemm_w4 is a mask over the four instantiations: 1 = B k-contiguous, no side rows; 2 = B k-contiguous + residual; 4 = B k-strided, no side rows;
-        // 8 = B k-strided + saved pre-activation
-        // Default 0.  Timed alone (tools/exp/w4_check.py, the two kernels alternately) the forms with B k-contiguous win (qkv -11 %, fc1 -9 %, fc2 -8 %; the block's eight
-        // forward / dgrad GEMMs -4.9 %, and 0 % against the eight-wave kernel with its tail split), the k-strided forms are equal.  IN the step the kernels it serves are
-        // faster (tools/step_gemm_shapes.py on rocprofv3 traces, one box: qkv -7 us, fc1 -6 per call) and the step is SLOWER: tools/ab_inproc.py (one process, the option
-        // toggled between blocks of ten steps, A B B A ...): mask 1 +0.33 ms, mask 3 +0.56, mask 15 +0.32 on 51.7 ms.  (Pairs of separate bench.py runs gave -0.21 ms in
-        // one order and +0.33 in the other: process-to-process noise.)
+        // Four-wave form (gemm256w_kernel).  gemm_w4 is a mask over its four instantiations: 1 = B k-contiguous, no side rows; 2 = B k-contiguous + residual;
+        // 4 = B k-strided, no side rows; 8 = B k-strided + saved pre-activation; -1 (default) = all four where K >= 1024 and N >= 1024 (every GEMM of ViT-L, none of ViT-B).  Measured IN the step, one process,
+        // the option toggled between blocks of ten steps (tools/ab_inproc.py, profiles/r4_dormant_kernels.txt): ViT-L/16 16x224^2 (K = 1024 / 4096) -3.0 ms of
+        // 155.8 with all four forms, -2.4 with the k-contiguous two; ViT-B/16 32x320^2 (6400 tokens) -0.4 of 94.3; ViT-B/16 16x224^2 +-0.0 of 53.4 (round 3: +0.3):
+        // with "all four where K >= 1024" (ViT-B: fc2, dfc1, dqkv) ViT-B 16x224^2 +0.06 / +0.11 ms, 6400 tokens -0.5, ViT-L -2.45: where the K loop dominates
+        // the store drain it wins, at ViT-B's shapes its faster launches are paid back by the clock the part then grants the next kernels.  Timed alone it wins on every k-contiguous shape (qkv -11 %, fc1 -9 %, fc2 -8 %).  It walks static tile lists: when the host
+        // announces concurrent kernels the eight-wave kernel with the dynamic queues serves instead.
+        // (The stream-K schedule of rounds 2-3 -- gemm256sk_kernel, options gemm_streamk / gemm_sk_* -- is gone: in the same A/B it gained nothing on any
+        // BASELINE configuration once the tail split existed: ViT-L -0.2 ms of 153.7 (noise), 6400 tokens +1.5 ms, ViT-B +-0.0; git history has it.)
         const int w4_form = (tb ? 2 : 0) + (side != 0 ? 1 : 0);
-        const bool w4_ok = kn.persistent && ((kn.w4 >> w4_form) & 1) && pers_ok && nt > gp && a->K >= 128 &&
+        const int w4_mask = kn.w4 >= 0 ? kn.w4 : ((a->K >= 1024 && a->N >= 1024) ? 15 : 0);
+        const bool w4_ok = kn.persistent && !dyn && ((w4_mask >> w4_form) & 1) && pers_ok && nt > gp && a->K >= 128 &&
                            (a->act == DEVIAS_ACT_NONE || a->act == DEVIAS_ACT_GELU || a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU);
-        const bool sk_policy = kn.streamk >= 3 || (!w4_ok && (int64_t)nt * 100 < (int64_t)cdiv(nt, gp) * gp * kn.sk_eff && a->K >= 64 * kn.sk_mink);
-        if (pers_ok && kn.streamk && a->sk_ws && aligned16(a->sk_ws) && a->sk_ws_bytes >= devias_gemm_streamk_workspace_bytes() &&
-            (nt >> 3) >= (gp >> 3) && nt % gp != 0 && sk_policy && ((nt >> 3) + 1) / (gp >> 3) + 4 <= SK_MAX_ITEMS) {
-            static std::atomic<unsigned long long> epoch{((unsigned long long)time(nullptr) << 24) | 1ull};
-            p.sk_part = reinterpret_cast<float*>(a->sk_ws);
-            p.sk_flag = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a->sk_ws) + (int64_t)gp * SK_SLOT_BYTES);
-            p.sk_epoch = ++epoch;
-            dim3 grid(gp), block(NT2);
-            PERS_LAUNCH(gemm256sk_kernel);
-            devias_count(DEVIAS_CNT_GEMM_SK);
-        } else if (w4_ok) {
+        if (w4_ok) {
             dim3 grid(gp), block(NTW);
             PERS_LAUNCH(gemm256w_kernel);
             devias_count(DEVIAS_CNT_GEMM256P);

@@ -49,7 +49,7 @@ struct Ctx {
     void* st;
 };
 
-// C[M,N] = epi(op(A) op(B)) with the Python host's automatic choices (small-M split-K, stream-K scratch for big bf16 outputs)
+// C[M,N] = epi(op(A) op(B)) with the Python host's automatic choices (small-M split-K)
 struct Epi {
     const float* bias = nullptr; int act = DEVIAS_ACT_NONE;
     const void* aux_in = nullptr; void* aux_out = nullptr;
@@ -69,7 +69,6 @@ int gemm(const Ctx& c, const void* A, const void* B, void* C, int M, int N, int 
     if (split_k == 1) split_k = small_m_split(M, N, K, trans_a);
     if (e.colsum) { split_k = 1; a.colsum = e.colsum; a.colsum_beta = e.colsum_beta; a.ws = c.ws; }
     a.split_k = split_k;
-    if (split_k == 1 && c.dtype == DEVIAS_BF16 && !trans_a && !c_f32 && (int64_t)M * N >= ((int64_t)1 << 24)) { a.sk_ws = c.sk_ws; a.sk_ws_bytes = c.sk_ws_bytes; }
     if (split_k > 1) {
         if (devias_gemm_workspace_bytes(M, N, split_k) > c.ws_bytes) return devias_set_error(DEVIAS_EINVAL, "fused region: workspace too small for a split-K GEMM (%d x %d x %d)", M, N, split_k);
         a.ws = c.ws;

@@ -754,9 +754,6 @@ class EncoderBlockRegionFn(Function):
         a.ds1 = ds1.data_ptr() if ds1 is not None else None
         a.ds2 = ds2.data_ptr() if ds2 is not None else None
         a.save, a.ws, a.ws_bytes = save.data_ptr(), ws.data_ptr(), ws.numel() * 4
-        if cdt == torch.bfloat16:
-            sk = ops.streamk_workspace(dev)
-            a.sk_ws, a.sk_ws_bytes = sk.data_ptr(), sk.numel()
         x2 = torch.empty_like(x)
         _L.check(lib.devias_encoder_block_fwd(_ct.byref(a), x.data_ptr(), x2.data_ptr(), ops._stream()), "devias_encoder_block_fwd")
         ctx.args = a

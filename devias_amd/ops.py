@@ -51,30 +51,6 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-_sk_workspaces = {}
-
-
-def streamk_workspace(device) -> torch.Tensor:
-    """partial-tile slots + hand-off flags of the stream-K GEMM schedule, one buffer per (device, stream); zeroed once so that the
-    hand-off error word (streamk_timeouts) reads 0 until a hand-off times out"""
-    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
-    ws = _sk_workspaces.get(key)
-    if ws is None:
-        ws = torch.zeros(_lib.load().devias_gemm_streamk_workspace_bytes(), dtype=torch.uint8, device=device)
-        _sk_workspaces[key] = ws
-    return ws
-
-
-def streamk_timeouts() -> int:
-    """number of stream-K workspaces whose hand-off error word is set (0 in a healthy process)"""
-    off = _lib.load().devias_gemm_streamk_error_offset()
-    return sum(int(ws[off:off + 8].view(torch.int64).item() != 0) for ws in _sk_workspaces.values())
-
-
-def device_info(device: int = 0):
-    out = (ctypes.c_int64 * 5)()
-    _lib.check(_lib.load().devias_device_info(device, out), "devias_device_info")
-    return {"cus": out[0], "clock_khz": out[1], "lds_per_block": out[2], "wave": out[3], "gfx": out[4]}
 
 
 def set_option(name: str, value: int) -> None:
@@ -162,9 +138,6 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         nbytes = max(((M + 127) // 128) * N * 4, _lib.load().devias_colsum_workspace_bytes(M, N))
         a.ws = workspace(nbytes, A.device).data_ptr()
     a.split_k = split_k
-    if split_k == 1 and A.dtype == torch.bfloat16 and not trans_a and not out_f32 and M * N >= (1 << 24):
-        sk_ws = streamk_workspace(A.device)         # lets the library pick the stream-K schedule (devias_gemm_args.sk_ws)
-        a.sk_ws, a.sk_ws_bytes = sk_ws.data_ptr(), sk_ws.numel()
     if split_k > 1:
         nbytes = _lib.load().devias_gemm_workspace_bytes(M, N, split_k)
         a.ws = workspace(nbytes, A.device).data_ptr()

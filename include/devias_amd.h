@@ -44,7 +44,7 @@ extern "C" {
 #define DEVIAS_ACT_DRELU 5     /* backward: v = aux_in > 0 ? v : 0 with aux_in = saved ReLU output */
 
 int devias_version(void);          /* 100 + additions: 110 = multi-tensor optimizer entry points, 120 = devias_fame_*, 130 = counters + options,
-                                    140 = stream-K GEMM schedule (devias_gemm_args grew by sk_ws / sk_ws_bytes: recompile callers), devias_allreduce_bucket,
+                                    140 = (stream-K GEMM schedule, retired in 160; devias_gemm_args grew by sk_ws / sk_ws_bytes: recompile callers), devias_allreduce_bucket,
                                     150 = fused regions (devias_encoder_block_* / devias_agg_block_* / devias_head_*), devias_range_* */
 const char* devias_last_error(void);
 /* Launch counters: one per kernel family, incremented by the host side of each entry point (process-wide, relaxed atomics).
@@ -60,7 +60,7 @@ const char* devias_last_error(void);
 #define DEVIAS_CNT_MHSA_BWD_BF16 7   /* MFMA backward, two kernels (dQ; dK/dV) */
 #define DEVIAS_CNT_MHSA_FWD_F32 8    /* VALU parity kernels */
 #define DEVIAS_CNT_MHSA_BWD_F32 9
-#define DEVIAS_CNT_GEMM_SK 11        /* 256x256 persistent kernel, stream-K schedule */
+#define DEVIAS_CNT_GEMM_SK 11        /* (retired with ABI 160: always 0) */
 #define DEVIAS_CNT_GEMM_SMALLM 13     /* small-M kernel (M <= 128, bf16, B k-contiguous): one launch instead of split-K product + reduce */
 #define DEVIAS_CNT_GEMM256W 12       /* 256x256 persistent kernel, four-wave form (one wave per SIMD, accumulators in AGPRs; option gemm_w4, off by
                                         default); every such launch also counts as DEVIAS_CNT_GEMM256P */
@@ -72,9 +72,8 @@ int64_t devias_counter(int32_t id);          /* -1 for an unknown id */
 void devias_counters_reset(void);
 /* Process-wide integer options (initialised once from the DEVIAS_* environment variables of the same meaning): "gemm_epi",
  * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_tail_split" (2, default: the tiles of a persistent launch's last partial round are computed as
- * 128-row halves by two workgroups when at least half the CUs would idle, their idle waves staging no A rows; 1: staging all rows; 0: whole tiles), "gemm_streamk" (0 = never, default; 1 = by policy; 3 = wherever it can run), "gemm_sk_eff",
- * "gemm_sk_mink", "gemm_smallm" (1, default: bf16 products with M <= 128 and B k-contiguous run as ONE launch of the small-M kernel instead of split-K
- * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves, default 0), "gemm_debug", "gemm_dynamic" (1: the workgroups of
+ * 128-row halves by two workgroups when at least half the CUs would idle, their idle waves staging no A rows; 1: staging all rows; 0: whole tiles), "gemm_smallm" (1, default: bf16 products with M <= 128 and B k-contiguous run as ONE launch of the small-M kernel instead of split-K
+ * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves; -1, default: all four where K >= 1024 and N >= 1024, i.e. every GEMM of ViT-L and none of ViT-B), "gemm_debug", "gemm_dynamic" (1: the workgroups of
  * the persistent kernel pull their tiles from per-XCD queues at run time instead of walking static lists -- a CU held or slowed by a concurrent kernel, e.g. RCCL's during
  * backward, just takes fewer tiles; 0: static lists; -1, default: queues exactly when "gemm_concurrent" is set; same bits either way), "gemm_concurrent" (the host
  * announces that other kernels run beside the step's: devias_amd.parallel.GradSync sets it for N > 1), "gemm_reserve_cus" (CUs the big-tile grids and the weight-gradient split-K sizing leave free for such a kernel),
@@ -142,16 +141,10 @@ typedef struct {
                                  C + i*stride_c (element strides).  bias / activation epilogues only (no split_k, res, aux, colsum).  Used for the
                                  per-head composite slot-attention weights and the per-clip context gradient of the folded slot attention. */
     int64_t stride_a, stride_b, stride_c;
-    void* sk_ws;              /* optional scratch of devias_gemm_streamk_workspace_bytes() bytes (16-byte aligned), private to launches of this stream:
-                                 lets large bf16 GEMMs run the stream-K schedule (balanced K-iterations per CU, bitwise the same results).  Contents
-                                 need no initialisation; the 64-bit word at devias_gemm_streamk_error_offset() is set non-zero if a hand-off
-                                 ever timed out (2 s; never observed -- the result of that launch is then invalid) */
-    int64_t sk_ws_bytes;
+    void* sk_ws;              /* ignored since ABI 160 (was: scratch of the stream-K schedule, retired in round 4 -- it gained nothing on any BASELINE */
+    int64_t sk_ws_bytes;      /* configuration once the persistent kernel split its tail tiles); kept so that the struct layout of ABI 140-150 callers stands */
 } devias_gemm_args;
 int devias_gemm(const devias_gemm_args* args, void* stream);
-int64_t devias_gemm_streamk_workspace_bytes(void);
-/* byte offset, inside sk_ws, of the 64-bit hand-off error word (zero it once after allocating the scratch if you want to read it) */
-int64_t devias_gemm_streamk_error_offset(void);
 /* bytes of workspace devias_gemm needs for the given split_k (0 when split_k <= 1) */
 int64_t devias_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 
@@ -373,7 +366,7 @@ int devias_fame_mix(const float* video, const uint8_t* binmask, int32_t mask_str
  * the library ~40 times per step instead of ~750 (one ctypes hop per fused region).  All memory is caller-owned:
  *   save     what backward re-reads (opaque layout; written by *_fwd, read by *_bwd; size from *_save_bytes)
  *   scratch  backward temporaries (dead when the call's work has run; size from *_scratch_bytes)
- *   ws       fp32 kernel workspace (split-K slabs, partial sums; size from *_workspace_bytes), sk_ws: see devias_gemm_args
+ *   ws       fp32 kernel workspace (split-K slabs, partial sums; size from *_workspace_bytes)
  * Gradient destinations are fp32 and may point anywhere (e.g. into a flat data-parallel gradient bucket).
  *
  * Encoder block = Block.forward of model/modeling_slot.py:142-152 (LayerNorm -> QKV Linear with q_bias | 0 | v_bias (:97-101) -> MHSA core
@@ -390,7 +383,7 @@ typedef struct {
     const float *ds1, *ds2;              /* optional fp32 [B]: per-sample stochastic-depth factors (0 or 1/keep) of the two branches */
     void* save;                          /* devias_encoder_block_save_bytes() */
     float* ws; int64_t ws_bytes;         /* devias_encoder_block_workspace_bytes() */
-    void* sk_ws; int64_t sk_ws_bytes;    /* optional stream-K scratch (devias_gemm_args.sk_ws) */
+    void* sk_ws; int64_t sk_ws_bytes;    /* ignored since ABI 160 (devias_gemm_args.sk_ws) */
 } devias_block_args;
 typedef struct {
     float *dn1w, *dn1b, *dWqkv, *dbqkv /* [3D]: dq_bias | (k: unused) | dv_bias */, *dWp, *dbp, *dn2w, *dn2b, *dW1, *db1, *dW2, *db2;

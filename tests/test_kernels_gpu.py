@@ -459,7 +459,7 @@ def gemm_options():
     """restores the process-wide kernel-selection options a test changes"""
     o = ops()
     yield o
-    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_streamk", 0), ("gemm_w4", 0), ("gemm_tail_split", 2), ("gemm_smallm", 1),
+    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_w4", -1), ("gemm_tail_split", 2), ("gemm_smallm", 1),
                  ("gemm_dynamic", -1), ("gemm_concurrent", 0)):
         o.set_option(k, v)
 
@@ -476,13 +476,11 @@ def _persistent_serves(tb, epi):
                                    (256 * 196, 768, 448), (256 * 196, 2304, 192)])
 def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
     """gemm256p_kernel (persistent: K-tile stream across tile boundaries, asm-issued epilogue stores left in flight; its workgroups pull their tiles
-    from the per-XCD dynamic queues by default -- modes p / p1 / p0 -- or walk the static lists -- ps / ps0), gemm256w_kernel (its
-    four-wave form: one wave per SIMD, accumulators in literal AGPRs, two K-tiles of LDS-DMA in flight; the default) and gemm256sk_kernel
-    (the eight-wave kernel with the stream-K schedule: split tiles handed from one workgroup to the next as fp32 partials, the chain continued)
-    against the fp32 op on the bf16-rounded inputs; the same call through the one-tile-per-workgroup kernel, with both epilogues,
-    must agree BITWISE (same MFMA order, same fp32 epilogue arithmetic).  Tile counts are not multiples of the CU count (all-stream-K
-    ranges and ranges with 1 and 5 data-parallel rounds), K covers one to twelve K-tiles, and the counters assert which kernel
-    served each call."""
+    from the per-XCD dynamic queues -- modes p / p1 / p0 -- or walk the static lists -- ps / ps0) and gemm256w_kernel (its four-wave form: one
+    wave per SIMD, accumulators in literal AGPRs, two K-tiles of LDS-DMA in flight; the default where K >= 1024 and N >= 1024) against the fp32 op on the
+    bf16-rounded inputs; the same call through the one-tile-per-workgroup kernel, with both epilogues, must agree BITWISE (same MFMA order, same
+    fp32 epilogue arithmetic).  Tile counts are not multiples of the CU count (partial rounds of 1 to 5 rounds), K covers one to twelve K-tiles,
+    and the counters assert which kernel served each call."""
     o = gemm_options
     from devias_amd._lib import ACT_DGELU, ACT_GELU
     A = rnd(M, K, dtype=torch.bfloat16, seed=1)
@@ -507,12 +505,11 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         kw = dict(act=ACT_DGELU, aux_in=pre); ref = ref * dg
     outs = {}
     serves = _persistent_serves(tb, epi)
-    # stream-K; persistent (eight waves with the tail split in both forms / without it, four waves); one tile per workgroup with the register-transposed / the LDS-staged epilogue
-    for mode in ("sk", "p", "p1", "p0", "ps", "ps0", "w", "0", "0s"):
-        o.set_option("gemm_streamk", 3 if mode == "sk" else 0)
-        o.set_option("gemm_persistent", 1 if mode in ("sk", "p", "p1", "p0", "ps", "ps0", "w") else 0)
+    # persistent (eight waves with the tail split in both forms / without it, four waves); one tile per workgroup with the register-transposed / the LDS-staged epilogue
+    for mode in ("p", "p1", "p0", "ps", "ps0", "w", "0", "0s"):
+        o.set_option("gemm_persistent", 1 if mode in ("p", "p1", "p0", "ps", "ps0", "w") else 0)
         o.set_option("gemm_tail_split", {"p0": 0, "ps0": 0, "p1": 1}.get(mode, 2))
-        o.set_option("gemm_dynamic", 0 if mode in ("ps", "ps0") else 1)
+        o.set_option("gemm_dynamic", 0 if mode in ("ps", "ps0", "w") else 1)          # (the four-wave kernel walks static lists: the queues take precedence)
         o.set_option("gemm_w4", 15 if mode == "w" else 0)
         o.set_option("gemm_epi", 0 if mode == "0s" else 1)
         kw2 = dict(kw)
@@ -524,30 +521,29 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         c = o.gemm(A, B, trans_b=tb, **kw2)
         torch.cuda.synchronize()
         cnt = o.counters()
-        want = {"sk": (1, 0, 0), "p": (0, 1, 0), "p1": (0, 1, 0), "p0": (0, 1, 0), "ps": (0, 1, 0), "ps0": (0, 1, 0), "w": (0, 1, 0)}.get(mode if serves else "0", (0, 0, 1))
-        assert (cnt["gemm_sk"], cnt["gemm256p"], cnt["gemm256"]) == want, (mode, cnt)
+        want = (1, 0) if (serves and mode not in ("0", "0s")) else (0, 1)
+        assert (cnt["gemm256p"], cnt["gemm256"]) == want and cnt["gemm_sk"] == 0, (mode, cnt)
         assert cnt["gemm256d"] == (1 if mode in ("p", "p1", "p0") and serves and K >= 128 else 0), (mode, cnt)   # (one K-tile per tile: the static list)
         assert cnt["gemm256w"] == (1 if mode == "w" and serves and K >= 128 else 0), (mode, cnt)       # (one K-tile: the eight-wave kernel)
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
-    assert o.streamk_timeouts() == 0
     c, aux, cs = outs["0"]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]
-    for mode in ("sk", "p", "p1", "p0", "ps", "ps0", "w", "0s"):
+    for mode in ("p", "p1", "p0", "ps", "ps0", "w", "0s"):
         assert torch.equal(c, outs[mode][0]), mode
     if aux is not None:
         assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16]
-        for mode in ("sk", "p", "p1", "p0", "ps", "ps0", "w", "0s"):
+        for mode in ("p", "p1", "p0", "ps", "ps0", "w", "0s"):
             assert torch.equal(aux, outs[mode][1]), mode
     if cs is not None:
         assert rel(cs, c.float().sum(0)) < 1e-2                 # sums the fp32 values before bf16 rounding
-        for mode in ("sk", "p", "p1", "p0", "ps", "ps0", "w", "0s"):
+        for mode in ("p", "p1", "p0", "ps", "ps0", "w", "0s"):
             assert rel(cs, outs[mode][2]) < 1e-5, mode
 
 
 def test_gemm_persistent_kernels_repeatable(gemm_options):
-    """the persistent kernels' hand-placed waits (asm-issued stores behind counted vmcnt, raw barriers) and the stream-K hand-off
-    (write-through partials, flag after two drained waits) are a race surface: the same launches repeated 30 times under a concurrent
-    memory-bound stream must give bitwise the results of the one-tile-per-workgroup kernel every time, in both schedules"""
+    """the persistent kernels' hand-placed waits (asm-issued stores behind counted vmcnt, raw barriers) and the dynamic queue's protocol (async
+    dequeues, the published-item word, claims) are a race surface: the same launches repeated 30 times under a concurrent memory-bound stream must
+    give bitwise the results of the one-tile-per-workgroup kernel every time, in every form"""
     o = gemm_options
     from devias_amd._lib import ACT_DGELU, ACT_GELU
     M, D = 256 * 196, 768
@@ -569,9 +565,8 @@ def test_gemm_persistent_kernels_repeatable(gemm_options):
     ref = run()
     junk = torch.empty(64 << 20, device=DEV)
     side = torch.cuda.Stream()
-    for sk, w4, dyn in ((0, 0, 1), (0, 0, 0), (0, 15, 1), (3, 0, 1)):
+    for w4, dyn in ((0, 1), (0, 0), (15, 0)):
         o.set_option("gemm_persistent", 1)
-        o.set_option("gemm_streamk", sk)                  # 3: stream-K whatever the quantisation loss
         o.set_option("gemm_w4", w4)
         o.set_option("gemm_dynamic", dyn)                 # 1: tiles pulled from the per-XCD queues (120 launches: the ring of queue slots wraps), 0: static lists
         o.counters(reset=True)
@@ -580,13 +575,12 @@ def test_gemm_persistent_kernels_repeatable(gemm_options):
                 junk.add_(1.0)                            # uneven memory load next to the GEMMs
             got = run()
             for a, b in zip(got[:5], ref[:5]):
-                assert torch.equal(a, b), (sk, w4, dyn, it)
+                assert torch.equal(a, b), (w4, dyn, it)
             assert rel(got[5], ref[5]) < 1e-5
         torch.cuda.synchronize()
         cnt = o.counters()
-        assert (cnt["gemm_sk"], cnt["gemm256p"], cnt["gemm256w"]) == ((120, 0, 0) if sk else (0, 120, 120 if w4 else 0)), cnt
-        assert cnt["gemm256d"] == (120 if dyn and not sk and not w4 else 0), cnt
-    assert o.streamk_timeouts() == 0
+        assert (cnt["gemm256p"], cnt["gemm256w"]) == (120, 120 if w4 else 0), cnt
+        assert cnt["gemm256d"] == (120 if dyn and not w4 else 0), cnt
 
 
 def test_gemm_dynamic_queue_with_held_cus(gemm_options):

@@ -137,7 +137,6 @@ def test_bf16_full_size_step_properties():
     # M = 50176: the four forward and four dgrad GEMMs of a block run on the eight-wave persistent kernel (tail tiles split; the stream-K schedule and the
     # four-wave kernel are options); the four wgrads split K on the one-tile-per-workgroup kernel
     assert cnt["gemm256p"] >= 12 * 8 and cnt["gemm_sk"] == 0 and cnt["gemm256w"] == 0 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_bwd_bf16"] == 12 and cnt["gemm128_f32"] == 0, cnt
-    assert ops.streamk_timeouts() == 0
     sh1 = out1[2][0].detach().clone()
     out2, t2, g2 = step(model, x, y, tl, fg)
     assert torch.isfinite(t1).all() and all(torch.isfinite(g).all() for g in g1.values())
@@ -183,7 +182,6 @@ def test_bf16_full_size_step_beside_the_oracle():
     torch.cuda.synchronize()
     cnt = ops.counters()
     assert cnt["gemm_sk"] == 0 and cnt["gemm256p"] >= 12 * 8 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_fwd_bf16"] == 12 and cnt["mhsa_bwd_bf16"] == 12, cnt
-    assert ops.streamk_timeouts() == 0
     sh = out[2][0].detach().float().cpu()
     # chunk 0: the reference's own numbers
     e0 = gu.rel(sh[:2 * S], fx["slots_head"])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of process-wide kernel options INSIDE one process: blocks of steps timed with HIP events, the option toggled between blocks in the order A B B A A B B A ...
 (no process restarts, no first-run / second-run bias: two separate bench.py runs differ by 0.1-0.3 ms whichever option they carry).
-usage: ab_inproc.py [hog=K] name=a,b [name=a,b ...]   e.g.  ab_inproc.py gemm_w4=0,1 gemm_tail_split=0,1
+usage: ab_inproc.py [bench.py flags] [hog=K] name=a,b [name=a,b ...]   e.g.  ab_inproc.py --model vit_large gemm_w4=0,1 gemm_tail_split=0,1
 hog=K holds K compute units (128 KiB LDS each) on a side stream during every backward of every block that follows on the command line (hog=0 ends it),
 as bench.py --cu-hog does: the stand-in for a concurrent collective's kernels."""
 import os, sys, statistics as st
@@ -11,8 +11,8 @@ import bench
 
 
 def main():
-    specs = [a for a in sys.argv[1:] if "=" in a]
-    sys.argv = [sys.argv[0]]
+    specs = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
+    sys.argv = [sys.argv[0]] + [a for a in sys.argv[1:] if a.startswith("--") or ("=" not in a)]     # bench.py flags pass through (--model vit_large --batch 32 ...)
     args = bench.parse()
     dev = torch.device("cuda", 0)
     from devias_amd import synth, ops

@@ -19,7 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     b1 = torch.randn(F, device="cuda") * 0.1
     hpre = bf(M, F)
     db1 = torch.zeros(F, device="cuda")
-    o.set_option("gemm_persistent", 0); o.set_option("gemm_streamk", 0)
+    o.set_option("gemm_persistent", 0);
     for bits in (0, 256, 128, 64, 64 | 128, 64 | 128 | 256, 2):
         o.set_option("gemm_debug", bits)
         t1 = timeit(lambda: o.gemm(u, W1, bias=b1, act=ACT_GELU, aux_out=hpre), iters=20)

@@ -16,7 +16,7 @@ out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 res = torch.randn(M, N, device="cuda").bfloat16()
 ws = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
-o.set_option("gemm_streamk", 0); o.set_option("gemm_persistent", 2); o.set_option("gemm_debug", 8)
+o.set_option("gemm_persistent", 2); o.set_option("gemm_debug", 8)
 if len(sys.argv) > 2: o.set_option("gemm_dynamic", int(sys.argv[2]))
 def call():
     g = _lib.GemmArgs()
