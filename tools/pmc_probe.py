@@ -18,7 +18,7 @@ g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
 qp = (torch.randn(B * 2, 4 * D, device=dev) * 0.5).to(bf)
 for it in range(3):
     o.gemm(x, w1, bias=bias, act=o.ACT_GELU, aux_out=pre)            # fc1 forward (gemm256p_kernel<false, 0>: persistent, B k-contiguous)
-    o.gemm(dy, w1, trans_b=True)                                       # fc1 dgrad   (gemm256sk_kernel<true, 0>: 588 tiles, K = 3072 -> stream-K)
+    o.gemm(dy, w1, trans_b=True)                                       # fc1 dgrad   (gemm256p_kernel<true, 0>: 588 tiles, K = 3072, tail tiles split)
     o.wgrad(dy, x)                                                     # fc1 wgrad   (gemm256_kernel<true, true> + split-K reduce)
     out, lse = o.mhsa_fwd(qkv, B, N, H, 0.125)
     o.mhsa_bwd(qkv, out, out, lse, B, N, H, 0.125)
