@@ -54,7 +54,7 @@ class BlockArgs(Structure):          # devias_block_args
 
 class BlockGrads(Structure):         # devias_block_grads
     _fields_ = [(n, c_void_p) for n in ("dn1w", "dn1b", "dWqkv", "dbqkv", "dWp", "dbp", "dn2w", "dn2b", "dW1", "db1", "dW2", "db2", "dx_colsum")] + \
-               [("db2_done", c_int32)]
+               [("db2_done", c_int32), ("dbq", c_void_p), ("dbv", c_void_p)]
 
 
 class HeadArgs(Structure):           # devias_head_args

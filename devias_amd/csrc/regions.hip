@@ -186,7 +186,7 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
                                         void* scratch, int64_t scratch_bytes, void* stream) {
     RUN(block_check(a, "devias_encoder_block_bwd"));
     DEVIAS_REQUIRE(x && dx2 && dx && g && scratch && aligned16(scratch), "devias_encoder_block_bwd: null / unaligned argument");
-    DEVIAS_REQUIRE(g->dn1w && g->dn1b && g->dWqkv && g->dbqkv && g->dWp && g->dbp && g->dn2w && g->dn2b && g->dW1 && g->db1 && g->dW2 && g->dx_colsum &&
+    DEVIAS_REQUIRE(g->dn1w && g->dn1b && g->dWqkv && (g->dbqkv || (g->dbq && g->dbv)) && g->dWp && g->dbp && g->dn2w && g->dn2b && g->dW1 && g->db1 && g->dW2 && g->dx_colsum &&
                    (g->db2 || g->db2_done), "devias_encoder_block_bwd: null gradient destination");
     const int B = a->B, N = a->N, D = a->D, H = a->H, hid = a->hidden, M = B * N;
     DEVIAS_REQUIRE(scratch_bytes >= devias_encoder_block_scratch_bytes(B, N, D, H, hid, a->dtype), "devias_encoder_block_bwd: scratch too small");
@@ -219,7 +219,12 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
     { Epi e; RUN(gemm(c, g1, a->Wp, t.small, M, D, D, D, D, 0, 1, e)); }                                                                        // d_o
     RUN(devias_mhsa_bwd(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, nullptr, stream));                              // dqkv
     RUN(wgrad(c, t.big, s.u, g->dWqkv, M, 3 * D, D));
-    RUN(colsum(c, t.big, M, 3 * D, g->dbqkv));
+    if (g->dbq && g->dbv) {                                                 // q_bias | (k: no bias) | v_bias: the two thirds that exist, each to its own destination
+        RUN(devias_colsum(t.big, c.dtype, M, D, 3 * D, g->dbq, 0.f, c.ws, c.st));
+        RUN(devias_colsum(t.big + (int64_t)2 * D * esize(c.dtype), c.dtype, M, D, 3 * D, g->dbv, 0.f, c.ws, c.st));
+    } else {
+        RUN(colsum(c, t.big, M, 3 * D, g->dbqkv));
+    }
     { Epi e; RUN(gemm(c, t.big, a->Wqkv, t.small, M, D, 3 * D, 3 * D, D, 0, 1, e)); }                                                           // du
     RUN(ln_bwd(c, t.small, x, a->n1w, s.mean1, s.rstd1, t.dx1, dx, g->dn1w, g->dn1b, 0.f, g->dx_colsum, M, D));
     return DEVIAS_OK;

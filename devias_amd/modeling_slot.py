@@ -305,7 +305,7 @@ class EncoderBlockFn(Function):
         x2 = ops.gemm(hact, W2, bias=_f32(f2b), res=x1, row_scale=ds2, rows_per_scale=N)   # x1 + drop_path(mlp(.))
         ctx.meta = meta
         ctx.ds = (ds1, ds2)
-        ctx.params = (n1w, n1b, qkvw, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b)
+        ctx.params = (n1w, n1b, qkvw, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, qb, vb)
         ctx.saved = (x, u, mean1, rstd1, qkv, o, lse, x1, u2, mean2, rstd2, hpre, hact, n1w_, n2w_, Wqkv, Wp, W1, W2)
         return x2
 
@@ -320,7 +320,7 @@ class EncoderBlockFn(Function):
         dev = x.device
         ds1, ds2 = ctx.ds
         lane = _WgradLane(dev)
-        (p_n1w, p_n1b, p_qkvw, p_pw, p_pb, p_n2w, p_n2b, p_f1w, p_f1b, p_f2w, p_f2b) = ctx.params
+        (p_n1w, p_n1b, p_qkvw, p_pw, p_pb, p_n2w, p_n2b, p_f1w, p_f1b, p_f2w, p_f2b, p_qb, p_vb) = ctx.params
         f32 = lambda n: torch.empty((n,), dtype=torch.float32, device=dev)          # noqa: E731
         dst = lambda p_, n: _gout(p_) if _gout(p_) is not None else f32(n)          # noqa: E731  (gradient bucket view, or a fresh buffer)
         # ---- MLP branch (g2 = gradient of the branch output: dx2 scaled by the per-sample stochastic-depth factor, if any)
@@ -351,13 +351,14 @@ class EncoderBlockFn(Function):
         dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale)
         with lane.after_main():
             dWqkv = ops.wgrad(dqkv, u, out=_gout(p_qkvw))
-            dbqkv = ops.colsum(dqkv)
+            dbq = ops.colsum(dqkv, out=_gout(p_qb), cols=(0, D))              # q_bias | (k: no bias) | v_bias, each to its own destination
+            dbv = ops.colsum(dqkv, out=_gout(p_vb), cols=(2 * D, D))
         du = ops.gemm(dqkv, Wqkv, trans_b=True)
         dxs = f32(D)
         dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1, dx_colsum=dxs, dgamma=_gout(p_n1w), dbeta=_gout(p_n1b))
         _publish_colsum(dx, dxs)
-        lane.join(dW2, dW1, dWp, dWqkv, dbqkv)
-        return (dx, dn1w, dn1b, dWqkv, dbqkv[:D], dbqkv[2 * D:], dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None)
+        lane.join(dW2, dW1, dWp, dWqkv, dbq, dbv)
+        return (dx, dn1w, dn1b, dWqkv, dbq, dbv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None)
 
 
 _LAYER_KEYS = ("to_q", "to_k", "to_v", "to_out_w", "to_out_b", "norm_w", "norm_b", "ctx_w", "ctx_b",
@@ -760,7 +761,7 @@ class EncoderBlockRegionFn(Function):
         ctx.meta = meta
         ctx.keep = (keep, save, ds1, ds2, x)
         ctx.x_version = x._version
-        ctx.params = (n1w, n1b, qkvw, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b)
+        ctx.params = (n1w, n1b, qkvw, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, qb, vb)
         return x2
 
     @staticmethod
@@ -770,17 +771,19 @@ class EncoderBlockRegionFn(Function):
         _region_state(ctx, "EncoderBlockRegionFn", ctx.keep[4] if ctx.keep is not None else None)
         a = ctx.args
         keep, save, ds1, ds2, x = ctx.keep
-        (p_n1w, p_n1b, p_qkvw, p_pw, p_pb, p_n2w, p_n2b, p_f1w, p_f1b, p_f2w, p_f2b) = ctx.params
+        (p_n1w, p_n1b, p_qkvw, p_pw, p_pb, p_n2w, p_n2b, p_f1w, p_f1b, p_f2w, p_f2b, p_qb, p_vb) = ctx.params
         dev = x.device
         D, hid = a.D, a.hidden
         dx2 = dx2.contiguous()
         ready = _peek_colsum(dx2) if ds2 is None else None          # colsum(dx2) = fc2 bias gradient, published by the next block's LayerNorm backward
         b2_dst = _gout(p_f2b) if ready is not None else None
-        gd = _GradDest([(p_n1w, (D,)), (p_n1b, (D,)), (p_qkvw, (3 * D, D)), (None, (3 * D,)), (p_pw, (D, D)), (p_pb, (D,)), (p_n2w, (D,)), (p_n2b, (D,)),
+        # (q_bias and v_bias are two parameters: their gradients go to two destinations -- bucket views under GradSync, else pieces of the flat tensor --
+        # instead of one [3D] vector that autograd would have to slice and GradSync to copy: 24 device-to-device copies per step, +1.0 ms)
+        gd = _GradDest([(p_n1w, (D,)), (p_n1b, (D,)), (p_qkvw, (3 * D, D)), (p_qb, (D,)), (p_pw, (D, D)), (p_pb, (D,)), (p_n2w, (D,)), (p_n2b, (D,)),
                         (p_f1w, (hid, D)), (p_f1b, (hid,)), (p_f2w, (D, hid)), (None if ready is not None else p_f2b, (1,) if ready is not None else (D,)),
-                        (None, (D,))], dev)
+                        (None, (D,)), (p_vb, (D,))], dev)
         g = _L.BlockGrads()
-        (g.dn1w, g.dn1b, g.dWqkv, g.dbqkv, g.dWp, g.dbp, g.dn2w, g.dn2b, g.dW1, g.db1, g.dW2, g.db2, g.dx_colsum) = gd.ptrs()
+        (g.dn1w, g.dn1b, g.dWqkv, g.dbq, g.dWp, g.dbp, g.dn2w, g.dn2b, g.dW1, g.db1, g.dW2, g.db2, g.dx_colsum, g.dbv) = gd.ptrs()
         g.db2_done = 1 if ready is not None else 0
         ws = ops.workspace(a.ws_bytes, dev)                 # (the stream's workspace may have been re-allocated larger since forward)
         a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
@@ -790,11 +793,11 @@ class EncoderBlockRegionFn(Function):
         _L.check(lib.devias_encoder_block_bwd(_ct.byref(a), x.data_ptr(), dx2.data_ptr(), dx.data_ptr(), _ct.byref(g), scr.data_ptr(), scr.numel(), ops._stream()),
                  "devias_encoder_block_bwd")
         ctx.keep = ctx.args = None
-        (dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, dxs) = gd.out
+        (dn1w, dn1b, dWqkv, dbq, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, dxs, dbv) = gd.out
         if ready is not None:
             db2 = ready if b2_dst is None else b2_dst.copy_(ready)
         _publish_colsum(dx, dxs)
-        return (dx, dn1w, dn1b, dWqkv, dbqkv[:D], dbqkv[2 * D:], dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None)
+        return (dx, dn1w, dn1b, dWqkv, dbq, dbv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None)
 
 
 class HeadRegionFn(Function):

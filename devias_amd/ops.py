@@ -178,14 +178,17 @@ def patch_im2col(x: torch.Tensor, tubelet: int, patch: int, dtype: torch.dtype) 
     return out
 
 
-def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, beta: float = 0.0, cols: Optional[tuple] = None) -> torch.Tensor:
+    """out[n] = beta * out[n] + sum_m x[m, n]; `cols = (first, count)` sums only that column range of the row-major matrix (row stride = its full width)"""
     _chk(x, "colsum.x")
-    M, N = x.shape
+    M, ld = x.shape
+    c0, N = cols if cols is not None else (0, ld)
+    assert 0 <= c0 and c0 + N <= ld
     if out is None:
         assert beta == 0.0
         out = torch.empty((N,), dtype=torch.float32, device=x.device)
     ws = workspace(_lib.load().devias_colsum_workspace_bytes(M, N), x.device)
-    _lib.check(_lib.load().devias_colsum(x.data_ptr(), dt_code(x.dtype), M, N, N, out.data_ptr(), beta, ws.data_ptr(), _stream()),
+    _lib.check(_lib.load().devias_colsum(x.data_ptr() + c0 * x.element_size(), dt_code(x.dtype), M, N, ld, out.data_ptr(), beta, ws.data_ptr(), _stream()),
                "devias_colsum")
     return out
 

@@ -389,6 +389,9 @@ typedef struct {
     float *dn1w, *dn1b, *dWqkv, *dbqkv /* [3D]: dq_bias | (k: unused) | dv_bias */, *dWp, *dbp, *dn2w, *dn2b, *dW1, *db1, *dW2, *db2;
     float* dx_colsum;                    /* [D]: column sums of dx = the fc2-bias gradient of the PREVIOUS block (or the patch-embed bias gradient) */
     int32_t db2_done;                    /* != 0: the caller already holds colsum(dx2) (the next block's dx_colsum): db2 is not written */
+    float *dbq, *dbv;                    /* ABI 160, optional: when BOTH are non-null the q_bias / v_bias gradients ([D] each: two separate parameters of the
+                                            reference, modeling_slot.py:88-93) are written there -- e.g. straight into a data-parallel gradient bucket -- by two
+                                            column-sum launches over the q and v thirds of dqkv (the k third has no bias), and dbqkv is not used (may be null) */
 } devias_block_grads;
 int64_t devias_encoder_block_save_bytes(int32_t B, int32_t N, int32_t D, int32_t H, int32_t hidden, int32_t dtype);
 int64_t devias_encoder_block_scratch_bytes(int32_t B, int32_t N, int32_t D, int32_t H, int32_t hidden, int32_t dtype);
