@@ -671,6 +671,49 @@ class HeadFn(Function):
         return dslots, dWh, dbh, dW0, db0, dW2, db2, dW4, db4, None
 
 
+class HeadMlpFn(Function):
+    """head_type='mlp' (MLPHead, modeling_slot.py:23-34, 307-313): slots -> (slots_head = fc2(relu(fc1(dropout(slots)))), mask_predictions = MaskPredictor(slots)).
+    Not on any DEVIAS recipe's path (docs/TRAIN.md uses 'linear'), so it is composed from the per-kernel calls (GEMM with the ReLU / dReLU / Sigmoid
+    epilogues, weight gradients, column sums) instead of having a fused region of its own."""
+
+    @staticmethod
+    def forward(ctx, slots, f1w, f1b, f2w, f2b, w0, b0, w2, b2, w4, b4, cdt, drop_mask=None):
+        F1, F2, W0, W2, W4 = (_WCACHE.get(w, cdt) for w in (f1w, f2w, w0, w2, w4))
+        slots = slots.contiguous()
+        xin = ops.mul_mask(slots, drop_mask) if drop_mask is not None else slots          # fc_dropout applies to the head's input only (:393)
+        t = ops.gemm(xin, F1, bias=_f32(f1b), act=ACT_RELU)
+        Z = ops.gemm(t, F2, bias=_f32(f2b))
+        m1 = ops.gemm(slots, W0, bias=_f32(b0), act=ACT_RELU)
+        m2 = ops.gemm(m1, W2, bias=_f32(b2), act=ACT_RELU)
+        Mk = ops.gemm(m2, W4, bias=_f32(b4), act=ACT_SIGMOID)
+        ctx.saved = (slots, xin, t, m1, m2, Mk, F1, F2, W0, W2, W4, drop_mask)
+        return Z, Mk
+
+    @staticmethod
+    def backward(ctx, dZ, dM):
+        if ctx.saved is None:
+            raise RuntimeError("HeadMlpFn: backward already consumed the saved activations (one backward per forward)")
+        slots, xin, t, m1, m2, Mk, F1, F2, W0, W2, W4, drop_mask = ctx.saved
+        ctx.saved = None
+        dZ = dZ.contiguous() if dZ is not None else torch.zeros((slots.shape[0], F2.shape[0]), dtype=slots.dtype, device=slots.device)
+        dM = dM.contiguous() if dM is not None else torch.zeros_like(Mk)
+        dp3 = ops.act_bwd(dM, Mk, ACT_SIGMOID)
+        dW4, db4 = ops.wgrad(dp3, m2), ops.colsum(dp3)
+        dp2 = ops.gemm(dp3, W4, trans_b=True, act=ACT_DRELU, aux_in=m2)
+        dW2, db2 = ops.wgrad(dp2, m1), ops.colsum(dp2)
+        dp1 = ops.gemm(dp2, W2, trans_b=True, act=ACT_DRELU, aux_in=m1)
+        dW0, db0 = ops.wgrad(dp1, slots), ops.colsum(dp1)
+        ds_m = ops.gemm(dp1, W0, trans_b=True)
+        dF2, dbf2 = ops.wgrad(dZ, t), ops.colsum(dZ)
+        dt = ops.gemm(dZ, F2, trans_b=True, act=ACT_DRELU, aux_in=t)
+        dF1, dbf1 = ops.wgrad(dt, xin), ops.colsum(dt)
+        if drop_mask is not None:
+            dslots = ops.mul_mask(ops.gemm(dt, F1, trans_b=True), drop_mask, ds_m)
+        else:
+            dslots = ops.gemm(dt, F1, trans_b=True, res=ds_m)
+        return dslots, dF1, dbf1, dF2, dbf2, dW0, db0, dW2, db2, dW4, db4, None, None
+
+
 # =====================================================================================================
 # fused regions: ONE library call per region and direction (devias_encoder_block_* / devias_agg_block_* / devias_head_*)
 # =====================================================================================================
@@ -1025,6 +1068,16 @@ class PatchEmbed(nn.Module):
                               stride=(self.tubelet_size, patch_size[0], patch_size[1]))
 
 
+class MLPHead(nn.Module):
+    """parameter container of the reference's MLPHead (model/modeling_slot.py:23-34): fc1 -> ReLU -> fc2; the arithmetic runs in HeadMlpFn"""
+
+    def __init__(self, in_dim, out_dim, hidden_dim):
+        super().__init__()
+        self.fc1 = nn.Linear(in_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, out_dim)
+        self.act = nn.ReLU()
+
+
 class MaskPredictor(nn.Module):
     def __init__(self, dim=768, out=196):
         super().__init__()
@@ -1110,8 +1163,8 @@ class VisionTransformer(nn.Module):
             slot_matching_method = slot_matching
         if slot_matching_method not in ('hard_select', 'matching'):
             raise ValueError("incorrent slot_matching_method")
-        if head_type != 'linear':
-            raise NotImplementedError("head_type='mlp' is not used by the DEVIAS recipes; only 'linear' is built")
+        if head_type not in ('linear', 'mlp'):
+            raise ValueError(f"head_type must be 'linear' or 'mlp' (modeling_slot.py:300-313), got {head_type!r}")
         if drop_rate or attn_drop_rate:
             raise NotImplementedError("drop_rate / attn_drop_rate > 0 (dropout inside the encoder blocks) is not implemented in the HIP path: no DEVIAS "
                                       "recipe sets them (docs/TRAIN.md); fc_drop_rate (dropout before the head, UCF-101 / HMDB recipes) is supported")
@@ -1146,11 +1199,19 @@ class VisionTransformer(nn.Module):
                                           input_channels=embed_dim, latent_dim=embed_dim)
         grid = (img_size // patch_size) if not isinstance(img_size, (tuple, list)) else (img_size[0] // patch_size)
         self.mask_predictor = MaskPredictor(embed_dim, grid * grid)
-        self.head = nn.Linear(embed_dim, num_classes + num_scene_classes) if num_classes > 0 else nn.Identity()
-        nn.init.trunc_normal_(self.head.weight, std=.02)
-        self.apply(self._init_weights)
-        self.head.weight.data.mul_(init_scale)
-        self.head.bias.data.mul_(init_scale)
+        if head_type == 'linear':                                                # modeling_slot.py:300-305
+            self.head = nn.Linear(embed_dim, num_classes + num_scene_classes) if num_classes > 0 else nn.Identity()
+            nn.init.trunc_normal_(self.head.weight, std=.02)
+            self.apply(self._init_weights)
+            self.head.weight.data.mul_(init_scale)
+            self.head.bias.data.mul_(init_scale)
+        else:                                                                     # 'mlp': modeling_slot.py:306-313
+            self.head = MLPHead(embed_dim, num_classes + num_scene_classes, hidden_dim=512) if num_classes > 0 else nn.Identity()
+            nn.init.trunc_normal_(self.head.fc1.weight, std=.02)
+            nn.init.trunc_normal_(self.head.fc2.weight, std=.02)
+            self.apply(self._init_weights)
+            self.head.fc2.weight.data.mul_(init_scale)
+            self.head.fc2.bias.data.mul_(init_scale)
         self.set_compute_dtype(compute_dtype)
 
     # ---- reference surface -------------------------------------------------------------------------------
@@ -1244,9 +1305,13 @@ class VisionTransformer(nn.Module):
             # nn.Dropout(fc_drop_rate) on the head's input only (modeling_slot.py:393): element-wise Bernoulli(keep) / keep, drawn like drop_path's masks
             keep = 1.0 - self.fc_drop_rate
             drop_mask = ((keep + torch.rand((B * S, D), device=x.device, dtype=torch.float32)).floor() / keep).contiguous()
-        head_fn = HeadRegionFn if (_REGIONS or drop_mask is not None) else HeadFn
-        head_args = (slots, self.head.weight, self.head.bias, mp[0].weight, mp[0].bias, mp[2].weight, mp[2].bias, mp[4].weight, mp[4].bias, cdt)
-        slots_head, mask_predictions = head_fn.apply(*head_args, drop_mask) if drop_mask is not None else head_fn.apply(*head_args)
+        if self.head_type == 'mlp':
+            slots_head, mask_predictions = HeadMlpFn.apply(slots, self.head.fc1.weight, self.head.fc1.bias, self.head.fc2.weight, self.head.fc2.bias,
+                                                           mp[0].weight, mp[0].bias, mp[2].weight, mp[2].bias, mp[4].weight, mp[4].bias, cdt, drop_mask)
+        else:
+            head_fn = HeadRegionFn if (_REGIONS or drop_mask is not None) else HeadFn
+            head_args = (slots, self.head.weight, self.head.bias, mp[0].weight, mp[0].bias, mp[2].weight, mp[2].bias, mp[4].weight, mp[4].bias, cdt)
+            slots_head, mask_predictions = head_fn.apply(*head_args, drop_mask) if drop_mask is not None else head_fn.apply(*head_args)
         idx = ops.slot_select(slots_head.detach(), B, S, self.num_classes).long()      # modeling_slot.py:395-401
         ar = torch.arange(B, device=x.device)
         sv, hv = slots.view(B, S, D), slots_head.view(B, S, -1)

@@ -219,6 +219,18 @@ def act_bwd(dy: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
     return dx
 
 
+def mul_mask(a: torch.Tensor, mask: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = a * mask (+ b): element-wise dropout with a caller-drawn fp32 mask of 0 / (1/keep) (devias_mul_mask)"""
+    _chk(a, "mul_mask.a"); _chk(mask, "mul_mask.mask", torch.float32)
+    assert mask.numel() == a.numel()
+    if b is not None:
+        _chk(b, "mul_mask.b", a.dtype)
+    y = torch.empty_like(a)
+    _lib.check(_lib.load().devias_mul_mask(a.data_ptr(), mask.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(), dt_code(a.dtype), a.numel(), _stream()),
+               "devias_mul_mask")
+    return y
+
+
 def row_scale(x: torch.Tensor, scale: torch.Tensor, rows_per_scale: int) -> torch.Tensor:
     _chk(x, "row_scale.x"); _chk(scale, "row_scale.scale", torch.float32)
     M, N = x.shape

@@ -50,6 +50,7 @@ class SlotViTConfig:
     eps_encoder: float = 1e-6   # modeling_slot.py:420
     eps_agg: float = 1e-5       # nn.LayerNorm default, agg_block/attention.py:29-30
     mask_hidden: Tuple[int, int] = (512, 256)   # modeling_slot.py:199-203
+    head_type: str = "linear"   # 'linear' (the recipes) or 'mlp' (MLPHead, hidden 512: modeling_slot.py:23-34, 307-313)
 
     @property
     def grid(self) -> int:
@@ -99,7 +100,11 @@ def param_shapes(cfg: SlotViTConfig) -> Dict[str, Tuple[int, ...]]:
     s["mask_predictor.decoder.2.weight"] = (h2, h1); s["mask_predictor.decoder.2.bias"] = (h2,)
     s["mask_predictor.decoder.4.weight"] = (cfg.grid * cfg.grid, h2)
     s["mask_predictor.decoder.4.bias"] = (cfg.grid * cfg.grid,)
-    s["head.weight"] = (cfg.head_width, D); s["head.bias"] = (cfg.head_width,)
+    if cfg.head_type == "mlp":
+        s["head.fc1.weight"] = (512, D); s["head.fc1.bias"] = (512,)
+        s["head.fc2.weight"] = (cfg.head_width, 512); s["head.fc2.bias"] = (cfg.head_width,)
+    else:
+        s["head.weight"] = (cfg.head_width, D); s["head.bias"] = (cfg.head_width,)
     return s
 
 
@@ -198,7 +203,10 @@ def student_forward(P, cfg: SlotViTConfig, x: torch.Tensor, taps: Optional[dict]
     slots, attn = agg_block(P, cfg, feats, taps)
     B, S, D = slots.shape
     slots_flat = slots.reshape(-1, D)
-    slots_head = F.linear(slots_flat, P["head.weight"], P["head.bias"])
+    if cfg.head_type == "mlp":                                            # MLPHead: fc2(relu(fc1(x))), modeling_slot.py:30-33
+        slots_head = F.linear(F.relu(F.linear(slots_flat, P["head.fc1.weight"], P["head.fc1.bias"])), P["head.fc2.weight"], P["head.fc2.bias"])
+    else:
+        slots_head = F.linear(slots_flat, P["head.weight"], P["head.bias"])
     probs = F.softmax(slots_head, dim=-1).view(B, S, -1)
     nb = cfg.num_classes
     a_idx = torch.argmax(probs[:, :, :nb].max(dim=-1).values, dim=1)

@@ -76,6 +76,7 @@ CONFIGS = {
     "vitb_t16": (dict(all_frames=16), 2),
     "vits_t8": (dict(all_frames=8, embed_dim=384, num_heads=6), 2),
     "vitb_t8_s4_untied": (dict(all_frames=8, num_latents=4, agg_weights_tie=False, agg_depth=4), 2),
+    "vitb_t8_mlphead": (dict(all_frames=8, head_type="mlp"), 2),          # MLPHead (modeling_slot.py:23-34, 307-313)
 }
 
 
@@ -83,7 +84,7 @@ def build_reference_student(cfg: ref_cpu.SlotViTConfig, reg, ms, AggregationBloc
     if cfg.embed_dim == 768:
         return reg["slot_vit_base_patch16_224"](
             num_classes=cfg.num_classes, all_frames=cfg.all_frames, tubelet_size=cfg.tubelet_size,
-            drop_path_rate=0., init_scale=1e-3, num_latents=cfg.num_latents, head_type="linear",
+            drop_path_rate=0., init_scale=1e-3, num_latents=cfg.num_latents, head_type=cfg.head_type,
             slot_matching_method="matching", agg_weights_tie=cfg.agg_weights_tie, agg_depth=cfg.agg_depth,
             num_scene_classes=cfg.num_scene_classes)
 

@@ -9,7 +9,7 @@ from devias_amd import synth
 from oracle import ref_cpu
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-STUDENT_GOLDENS = ["vitb_t8", "vitb_t16", "vits_t8", "vitb_t8_s4_untied"]
+STUDENT_GOLDENS = ["vitb_t8", "vitb_t16", "vits_t8", "vitb_t8_s4_untied", "vitb_t8_mlphead"]
 
 
 def load(name):

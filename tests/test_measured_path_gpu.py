@@ -26,7 +26,7 @@ def _build(cfg, dtype, **kw):
     m = VisionTransformer(img_size=cfg.img_size, patch_size=16, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4,
                           qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_classes=cfg.num_classes,
                           all_frames=cfg.all_frames, tubelet_size=cfg.tubelet_size, init_scale=1e-3,
-                          num_latents=cfg.num_latents, head_type="linear", slot_matching_method="matching",
+                          num_latents=cfg.num_latents, head_type=cfg.head_type, slot_matching_method="matching",
                           agg_weights_tie=cfg.agg_weights_tie, agg_depth=cfg.agg_depth,
                           num_scene_classes=cfg.num_scene_classes, compute_dtype=dtype, **kw)
     synth.fill_module_(m, seed=0)

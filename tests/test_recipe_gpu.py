@@ -100,3 +100,37 @@ def test_step_at_101_action_classes_vs_oracle(dtype, tol_out, tol_grad):
         gmax = max(float(g.abs().max()) for g in ograds.values())
         worst = max(float((p.grad.cpu().double() - ograds[n].double()).abs().max() / max(float(ograds[n].abs().max()), 1e-6 * gmax)) for n, p in m.named_parameters())
         assert worst < tol_grad, worst
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("drop", [False, True])
+def test_mlp_head_with_and_without_fc_dropout(dtype, tol, drop):
+    """head_type='mlp' (MLPHead fc1 -> ReLU -> fc2, model/modeling_slot.py:23-34) behind nn.Dropout on the head's input (:393), forward and backward against the
+    same arithmetic in fp32 autograd with the SAME mask; the mask predictor sees the un-dropped slots (:392)."""
+    from devias_amd.modeling_slot import HeadMlpFn
+    R, D, C, h1, h2, G = 6, 768, 765, 512, 256, 196
+    shp = {"f1w": (512, D), "f1b": (512,), "f2w": (C, 512), "f2b": (C,), "w0": (h1, D), "b0": (h1,), "w2": (h2, h1), "b2": (h2,), "w4": (G, h2), "b4": (G,)}
+    P = {k: synth.param_values("mlphead." + k, s, seed=3) * (0.05 if len(s) == 2 else 0.1) for k, s in shp.items()}
+    slots = synth.param_values("mlphead.slots", (R, D), seed=4)
+    keep = 0.5
+    mask = ((keep + torch.rand((R, D), generator=torch.Generator().manual_seed(12))).floor() / keep) if drop else None
+    wz, wm = synth.param_values("mlphead.wz", (R, C), seed=5), synth.param_values("mlphead.wm", (R, G), seed=6)
+    if dtype == torch.bfloat16:
+        slots = slots.bfloat16().float()
+        P = {k: (v.bfloat16().float() if v.dim() == 2 else v) for k, v in P.items()}
+    ref = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    s_ref = slots.clone().requires_grad_(True)
+    xin = s_ref * mask if drop else s_ref
+    Z = F.linear(F.relu(F.linear(xin, ref["f1w"], ref["f1b"])), ref["f2w"], ref["f2b"])
+    m = F.relu(F.linear(s_ref, ref["w0"], ref["b0"])); m = F.relu(F.linear(m, ref["w2"], ref["b2"])); Mk = torch.sigmoid(F.linear(m, ref["w4"], ref["b4"]))
+    ((Z * wz).sum() + (Mk * wm).sum()).backward()
+    dev = "cuda"
+    hp = {k: v.to(dev).requires_grad_(True) for k, v in P.items()}
+    s_hip = slots.to(dev).to(dtype).requires_grad_(True)
+    Zh, Mh = HeadMlpFn.apply(s_hip, hp["f1w"], hp["f1b"], hp["f2w"], hp["f2b"], hp["w0"], hp["b0"], hp["w2"], hp["b2"], hp["w4"], hp["b4"], dtype,
+                             mask.to(dev) if drop else None)
+    ((Zh.float() * wz.to(dev)).sum() + (Mh.float() * wm.to(dev)).sum()).backward()
+    assert gu.rel(Zh.detach().float().cpu(), Z.detach()) < tol and gu.rel(Mh.detach().float().cpu(), Mk.detach()) < tol
+    assert gu.rel(s_hip.grad.float().cpu(), s_ref.grad) < tol
+    for k in P:
+        assert gu.rel(hp[k].grad.float().cpu(), ref[k].grad) < tol, k

@@ -99,6 +99,21 @@ def test_vit_b_counts():
     assert sum(p.numel() for p in m.parameters()) == 98413249
 
 
+def test_mlp_head_surface():
+    """head_type='mlp' (MLPHead, model/modeling_slot.py:23-34, 307-313): same parameter names and shapes as the oracle's restatement -- which
+    tests/golden/vitb_t8_mlphead.npz pins to the reference -- and the reference's initialisation (fc2 scaled by init_scale)"""
+    from devias_amd import create_model
+    from oracle import ref_cpu
+    m = create_model("slot_vit_base_patch16_224", num_classes=400, all_frames=8, num_latents=2, slot_matching="matching", agg_weights_tie=True, agg_depth=8,
+                     head_type="mlp", init_scale=0.001)
+    shapes = ref_cpu.param_shapes(ref_cpu.SlotViTConfig(all_frames=8, head_type="mlp"))
+    assert [n for n, _ in m.named_parameters()] == list(shapes.keys())
+    assert all(tuple(p.shape) == shapes[n] for n, p in m.named_parameters())
+    assert float(m.head.fc2.weight.abs().max()) < 1e-3 and float(m.head.fc1.weight.abs().max()) > 1e-3
+    with pytest.raises(ValueError):
+        create_model("slot_vit_base_patch16_224", head_type="conv")
+
+
 def test_forward_without_gpu_fails_loudly():
     from devias_amd import create_model
     m = create_model("slot_vit_small_patch16_224", num_classes=400, all_frames=8, num_latents=2, slot_matching="matching",
