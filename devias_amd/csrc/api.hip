@@ -24,10 +24,13 @@ extern "C" void devias_counters_reset(void) { for (int i = 0; i < DEVIAS_CNT_MAX
 extern "C" int devias_set_option(const char* name, int32_t value) {
     if (!name) return devias_set_error(DEVIAS_EINVAL, "devias_set_option: null name");
     if (devias_gemm_set_option(name, value) || devias_attn_set_option(name, value)) return DEVIAS_OK;
+    if (!strcmp(name, "regions_defer")) { devias_defer_enabled() = value; return DEVIAS_OK; }
     return devias_set_error(DEVIAS_EINVAL, "devias_set_option: unknown option '%s'", name);
 }
 
 extern "C" const char* devias_last_error(void) { return g_err; }
+DeviasDeferList*& devias_defer_slot() { static thread_local DeviasDeferList* slot = nullptr; return slot; }
+int& devias_defer_enabled() { static int on = [] { const char* e = getenv("DEVIAS_REGIONS_DEFER"); return e ? atoi(e) : 1; }(); return on; }
 
 extern "C" int devias_device_info(int device, int64_t* out5) {
     if (!out5) return devias_set_error(DEVIAS_EINVAL, "devias_device_info: null output");

@@ -49,6 +49,23 @@ static inline int devias_device_cus() {
     return v;
 }
 
+// ---- deferred final reductions ---------------------------------------------------------------------------------------------------------
+// LayerNorm backward, the GEMM's column-sum epilogue and devias_colsum all end in the same second stage, out[i] = beta out[i] + sum_p part[p][i] in a
+// fixed order, each as its own 6-12 us launch.  A fused region (csrc/regions.hip) that hands each of them a PRIVATE partial area collects those second
+// stages in a list instead and runs them as ONE launch before it returns (devias_flush_deferred: the same arithmetic in the same order, bitwise).
+struct DeviasReduceJob { const float* part; int nparts; int stride; int n; float* out; float beta; };
+struct DeviasDeferList { enum { MAX = 16 }; DeviasReduceJob jobs[MAX]; int n; };
+DeviasDeferList*& devias_defer_slot();                            // api.hip: thread-local; non-null only while a region is collecting
+int& devias_defer_enabled();                                      // api.hip: option "regions_defer" / DEVIAS_REGIONS_DEFER (1, default; 0 = every second stage its own launch)
+int devias_flush_deferred(DeviasDeferList* l, hipStream_t st);    // elementwise.hip
+// true = the `count` second stages described by `j` were taken over by the collecting region (the caller must NOT launch them)
+static inline bool devias_defer(const DeviasReduceJob* j, int count) {
+    DeviasDeferList* l = devias_defer_slot();
+    if (!l || !devias_defer_enabled() || l->n + count > DeviasDeferList::MAX) return false;
+    for (int i = 0; i < count; ++i) l->jobs[l->n++] = j[i];
+    return true;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

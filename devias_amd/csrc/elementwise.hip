@@ -326,6 +326,37 @@ extern "C" int devias_patch_im2col(const void* x, int32_t xd, void* out, int32_t
     return DEVIAS_OK;
 }
 
+// every deferred second stage of a region in one launch: blockIdx.y = job; the loop and the combine are those of colsum_final_kernel /
+// gemm_colsum_final_kernel / ln_param_reduce_kernel, so the results are bitwise theirs
+struct ReduceJobs { DeviasReduceJob j[DeviasDeferList::MAX]; };
+__global__ void reduce_jobs_kernel(ReduceJobs jobs) {
+    __shared__ float sm[16][64];
+    const DeviasReduceJob& jb = jobs.j[blockIdx.y];
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * 64 >= jb.n) return;                   // (whole block past this job's width)
+    float s = 0.f;
+    if (n < jb.n)
+        for (int i = threadIdx.y; i < jb.nparts; i += 16) s += jb.part[(int64_t)i * jb.stride + n];
+    sm[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && n < jb.n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][threadIdx.x];
+        jb.out[n] = t + (jb.beta != 0.f ? jb.beta * jb.out[n] : 0.f);
+    }
+}
+int devias_flush_deferred(DeviasDeferList* l, hipStream_t st) {
+    if (!l || l->n == 0) return DEVIAS_OK;
+    ReduceJobs jobs;
+    int nmax = 0;
+    for (int i = 0; i < l->n; ++i) { jobs.j[i] = l->jobs[i]; if (l->jobs[i].n > nmax) nmax = l->jobs[i].n; }
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(cdiv(nmax, 64), l->n), dim3(64, 16), 0, st, jobs);
+    l->n = 0;
+    DEVIAS_CHECK_LAUNCH("devias_flush_deferred");
+    return DEVIAS_OK;
+}
+
 extern "C" int64_t devias_colsum_workspace_bytes(int32_t M, int32_t N) { return (int64_t)cdiv(M, CS_ROWS) * N * 4; }
 
 extern "C" int devias_colsum(const void* x, int32_t dtype, int32_t M, int32_t N, int32_t ldx, float* out, float beta,
@@ -340,6 +371,7 @@ extern "C" int devias_colsum(const void* x, int32_t dtype, int32_t M, int32_t N,
     else hipLaunchKernelGGL((colsum_partial_kernel<float>), g, b, 0, st, (const float*)x, M, N, ldx, ws, vec, direct, beta);
     DEVIAS_CHECK_LAUNCH("devias_colsum(partial)");
     if (direct) return DEVIAS_OK;
+    { const DeviasReduceJob j = {ws, nparts, N, N, out, beta}; if (devias_defer(&j, 1)) return DEVIAS_OK; }
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64, 16), 0, st, ws, nparts, N, out, beta);
     DEVIAS_CHECK_LAUNCH("devias_colsum(final)");
     return DEVIAS_OK;

@@ -2245,7 +2245,10 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
     }
     DEVIAS_CHECK_LAUNCH("devias_gemm");
     if (a->colsum) {
-        if (colsum_fused) {
+        const DeviasReduceJob cj = {a->ws, a->M / 128, a->N, a->N, a->colsum, a->colsum_beta};
+        if (colsum_fused && devias_defer(&cj, 1)) {
+            // (second stage taken over by the collecting region)
+        } else if (colsum_fused) {
             hipLaunchKernelGGL(gemm_colsum_final_kernel, dim3(cdiv(a->N, 64)), dim3(64, 16), 0, st, a->ws, a->M / 128, a->N, a->colsum, a->colsum_beta);
             DEVIAS_CHECK_LAUNCH("devias_gemm(colsum)");
         } else {

@@ -315,6 +315,10 @@ extern "C" int devias_layernorm_bwd(const void* dy, const void* x, const float* 
     else return devias_set_error(DEVIAS_EINVAL, "devias_layernorm_bwd: bad dtype %d", dtype);
     DEVIAS_CHECK_LAUNCH("devias_layernorm_bwd");
     if (direct) return DEVIAS_OK;
+    {   // dgamma | dbeta | (dx column sums): three second stages over the [nparts][3D] partials
+        const DeviasReduceJob j[3] = {{ws, nparts, 3 * D, D, dgamma, beta_acc}, {ws + D, nparts, 3 * D, D, dbeta, beta_acc}, {ws + 2 * D, nparts, 3 * D, D, dx_colsum, 0.f}};
+        if (devias_defer(j, dx_colsum ? 3 : 2)) return DEVIAS_OK;
+    }
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(cdiv(3 * D, 64)), dim3(64, 16), 0, st, ws, nparts, D, dgamma, dbeta, dx_colsum, beta_acc);
     DEVIAS_CHECK_LAUNCH("devias_layernorm_bwd(param reduce)");
     return DEVIAS_OK;

@@ -125,6 +125,9 @@ struct BlockSave {
 struct BlockScratch {
     char *big, *small, *dx1, *g;      // big: dhpre [M,hid] then dqkv [M,3D]; small: du2, d_o, du in turn [M,D]; g: the row-scaled copy of a branch gradient (stochastic depth)
     float* delta;
+    // private partial areas of the kernels whose second stage the region runs as ONE launch at its end (common.h: deferred final reductions):
+    // the two LayerNorm backwards, the dfc2 GEMM's column-sum epilogue (db1), and the column sums for db2 / dbp (stochastic depth) / dq_bias / dv_bias
+    float *p_ln2, *p_ln1, *p_db1, *p_b2, *p_bp, *p_q, *p_v;
     int64_t bytes;
     BlockScratch(void* base, int B, int N, int D, int H, int hid, int dtype) {
         const int64_t M = (int64_t)B * N, es = esize(dtype);
@@ -133,6 +136,10 @@ struct BlockScratch {
         auto take = [&](int64_t n) { char* r = reinterpret_cast<char*>(p + (uintptr_t)off); off += al256(n); return r; };
         big = take(M * (hid > 3 * D ? hid : 3 * D) * es); small = take(M * D * es); dx1 = take(M * D * es); g = take(M * D * es);
         delta = (float*)take((int64_t)B * H * N * 4);
+        const int64_t lnw = devias_layernorm_bwd_workspace_bytes((int)M, D), csw = devias_colsum_workspace_bytes((int)M, 3 * D);
+        p_ln2 = (float*)take(lnw); p_ln1 = (float*)take(lnw);
+        p_db1 = (float*)take(max64((int64_t)cdiv(M, 128) * hid * 4, devias_colsum_workspace_bytes((int)M, hid)));
+        p_b2 = (float*)take(csw); p_bp = (float*)take(csw); p_q = (float*)take(csw); p_v = (float*)take(csw);
         bytes = off;
     }
 };
@@ -194,39 +201,47 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
     const BlockSave s(a->save, B, N, D, H, hid, a->dtype);
     const BlockScratch t(scratch, B, N, D, H, hid, a->dtype);
     devias_range r("encoder_block_bwd");
+    // The second stages of this region's partial reductions (two LayerNorm parameter reduces, the column-sum finals of db1 / db2 / dbp / dq_bias / dv_bias:
+    // 5-7 launches of 6-12 us) run as ONE launch at the end: each producer gets a private partial area in the scratch arena (Ctx with that `ws`).
+    DeviasDeferList dl; dl.n = 0;
+    struct Collect { Collect(DeviasDeferList* l) { devias_defer_slot() = l; } ~Collect() { devias_defer_slot() = nullptr; } } collecting(&dl);
+    auto with_ws = [&](float* area) { Ctx k = c; k.ws = area; return k; };
     // ---- MLP branch (g2 = gradient of the branch output: dx2 scaled by the per-sample stochastic-depth factor, if any)
     const void* g2 = dx2;
     if (a->ds2) {
         RUN(devias_row_scale(dx2, a->ds2, N, t.g, a->dtype, M, D, stream));
         g2 = t.g;
-        RUN(colsum(c, g2, M, D, g->db2));
+        RUN(colsum(with_ws(t.p_b2), g2, M, D, g->db2));
     } else if (!g->db2_done) {
-        RUN(colsum(c, dx2, M, D, g->db2));                                    // fc2 bias gradient (the caller had no ready-made column sums of dx2)
+        RUN(colsum(with_ws(t.p_b2), dx2, M, D, g->db2));                       // fc2 bias gradient (the caller had no ready-made column sums of dx2)
     }
     RUN(wgrad(c, g2, s.hact, g->dW2, M, D, hid));
-    { Epi e; e.act = DEVIAS_ACT_DGELU; e.aux_in = s.hpre; e.colsum = g->db1; RUN(gemm(c, g2, a->W2, t.big, M, hid, D, D, hid, 0, 1, e)); }   // (g2 W2) * gelu'(pre); db1 = colsum
+    { Epi e; e.act = DEVIAS_ACT_DGELU; e.aux_in = s.hpre; e.colsum = g->db1; RUN(gemm(with_ws(t.p_db1), g2, a->W2, t.big, M, hid, D, D, hid, 0, 1, e)); }   // (g2 W2) * gelu'(pre); db1 = colsum
     RUN(wgrad(c, t.big, s.u2, g->dW1, M, hid, D));
     { Epi e; RUN(gemm(c, t.big, a->W1, t.small, M, D, hid, hid, D, 0, 1, e)); }                                                                 // du2
-    RUN(ln_bwd(c, t.small, s.x1, a->n2w, s.mean2, s.rstd2, dx2, t.dx1, g->dn2w, g->dn2b, 0.f, g->dbp, M, D));                                  // + residual gradient; dbp = colsum(dx1)
+    // + residual gradient; dbp = colsum(dx1) -- unless stochastic depth rescales dx1 first: then the column sum of the rescaled copy below is dbp (two deferred
+    // jobs must not share a destination: they run side by side)
+    RUN(ln_bwd(with_ws(t.p_ln2), t.small, s.x1, a->n2w, s.mean2, s.rstd2, dx2, t.dx1, g->dn2w, g->dn2b, 0.f, a->ds1 ? nullptr : g->dbp, M, D));
     // ---- attention branch
     const void* g1 = t.dx1;
     if (a->ds1) {
         RUN(devias_row_scale(t.dx1, a->ds1, N, t.g, a->dtype, M, D, stream));
         g1 = t.g;
-        RUN(colsum(c, g1, M, D, g->dbp));
+        RUN(colsum(with_ws(t.p_bp), g1, M, D, g->dbp));
     }
     RUN(wgrad(c, g1, s.o, g->dWp, M, D, D));
     { Epi e; RUN(gemm(c, g1, a->Wp, t.small, M, D, D, D, D, 0, 1, e)); }                                                                        // d_o
     RUN(devias_mhsa_bwd(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, nullptr, stream));                              // dqkv
     RUN(wgrad(c, t.big, s.u, g->dWqkv, M, 3 * D, D));
     if (g->dbq && g->dbv) {                                                 // q_bias | (k: no bias) | v_bias: the two thirds that exist, each to its own destination
-        RUN(devias_colsum(t.big, c.dtype, M, D, 3 * D, g->dbq, 0.f, c.ws, c.st));
-        RUN(devias_colsum(t.big + (int64_t)2 * D * esize(c.dtype), c.dtype, M, D, 3 * D, g->dbv, 0.f, c.ws, c.st));
+        RUN(devias_colsum(t.big, c.dtype, M, D, 3 * D, g->dbq, 0.f, t.p_q, c.st));
+        RUN(devias_colsum(t.big + (int64_t)2 * D * esize(c.dtype), c.dtype, M, D, 3 * D, g->dbv, 0.f, t.p_v, c.st));
     } else {
-        RUN(colsum(c, t.big, M, 3 * D, g->dbqkv));
+        RUN(colsum(with_ws(t.p_q), t.big, M, 3 * D, g->dbqkv));
     }
     { Epi e; RUN(gemm(c, t.big, a->Wqkv, t.small, M, D, 3 * D, 3 * D, D, 0, 1, e)); }                                                           // du
-    RUN(ln_bwd(c, t.small, x, a->n1w, s.mean1, s.rstd1, t.dx1, dx, g->dn1w, g->dn1b, 0.f, g->dx_colsum, M, D));
+    RUN(ln_bwd(with_ws(t.p_ln1), t.small, x, a->n1w, s.mean1, s.rstd1, t.dx1, dx, g->dn1w, g->dn1b, 0.f, g->dx_colsum, M, D));
+    RUN(devias_flush_deferred(&dl, (hipStream_t)stream));
     return DEVIAS_OK;
 }
 

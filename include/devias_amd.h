@@ -77,7 +77,8 @@ void devias_counters_reset(void);
  * the persistent kernel pull their tiles from per-XCD queues at run time instead of walking static lists -- a CU held or slowed by a concurrent kernel, e.g. RCCL's during
  * backward, just takes fewer tiles; 0: static lists; -1, default: queues exactly when "gemm_concurrent" is set; same bits either way), "gemm_concurrent" (the host
  * announces that other kernels run beside the step's: devias_amd.parallel.GradSync sets it for N > 1), "gemm_reserve_cus" (CUs the big-tile grids and the weight-gradient split-K sizing leave free for such a kernel),
- * "attn_cfg", "attn_xcd".  Every choice computes the same bits EXCEPT gemm_smallm (different K summation order) and gemm_reserve_cus (like the device's CU count it
+ * "attn_cfg", "attn_xcd", "regions_defer" (1, default: an encoder block's backward runs the second stages of its partial reductions -- LayerNorm parameter
+ * gradients, bias-gradient column sums -- as ONE launch at its end instead of 5-7).  Every choice computes the same bits EXCEPT gemm_smallm (different K summation order) and gemm_reserve_cus (like the device's CU count it
  * sets the split-K factor of the weight-gradient GEMMs, hence their fp32 summation order: runs with different reserves -- or N = 1 against N > 1 runs that set one --
  * agree to rounding, not bitwise).  0 = ok, DEVIAS_EINVAL = unknown name. */
 int devias_set_option(const char* name, int32_t value);
