@@ -31,6 +31,11 @@ def _worker(rank, world, port, q):
     broadcast_parameters(model)
     sync = GradSync(model, bucket_bytes=512)         # several buckets
     assert len(sync.buckets) > 2
+    # every parameter's place starts on a 256-byte boundary of its bucket (the [5]-element bias in front must not misalign what follows: the
+    # HIP weight-gradient kernels write straight into these views and take their vector paths only for aligned destinations)
+    for p in model.parameters():
+        v, flat = sync._view[p], sync.flat[sync._where[p]]
+        assert (v.data_ptr() - flat.data_ptr()) % 256 == 0 and flat.data_ptr() % 256 == sync._all.data_ptr() % 256
     out = []
     for step in range(2):                             # two steps: buffers are reused, p.grad stays a bucket view
         g = torch.Generator().manual_seed(100 + rank + 10 * step)
