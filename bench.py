@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce (N > 1)")
     ap.add_argument("--force-gradsync", action="store_true", help="N = 1 only: run the whole gradient-bucket path (hooks, events, side stream) with the "
                     "collective replaced by a same-size device copy on the side stream")
+    ap.add_argument("--rccl-world1", action="store_true", help="N = 1 only: a one-rank RCCL process group, every gradient bucket's all-reduce issued through it "
+                    "on the side stream (the backend's own streams and Work handles; RCCL refuses two ranks on one GPU, so this is what a 1-GPU box can run of it)")
     ap.add_argument("--cu-hog", type=int, default=0, help="hold this many CUs (128 KiB LDS each) on a side stream during every backward: stand-in for the CUs "
                     "RCCL's kernels occupy at N > 1")
     ap.add_argument("--reserve-cus", type=int, default=0, help="persistent GEMM grids leave this many CUs free (library option gemm_reserve_cus)")
@@ -228,7 +230,12 @@ def main():
     crit = TrainLoss(scene_criterion="KL", num_action_classes=400, slot_matching_method="matching", scene_loss_weight=4000,
                      mask_prediction_loss_weight=1.0, mask_distill_loss_weight=1.0, sync_loss_dict=False)
     comm_dtype = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
-    sync = GradSync(model, comm_dtype=comm_dtype, simulate=args.force_gradsync) if (world > 1 or args.force_gradsync) else None
+    if args.rccl_world1 and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    sync = (GradSync(model, comm_dtype=comm_dtype, simulate=args.force_gradsync, collective_at_world1=args.rccl_world1)
+            if (world > 1 or args.force_gradsync or args.rccl_world1) else None)
     from devias_amd import _lib as _dl
     hog_stream = torch.cuda.Stream(device=device) if args.cu_hog > 0 else None
 
@@ -338,6 +345,7 @@ def main():
         "config": {"workload": f"slot-{args.model} 16-patch {args.frames}x{args.img_size}^2 ({N} tokens), S=2 slots, tied agg depth 8, "
                                f"B={B} clips/GPU, student fwd + matching loss + bwd" + (f" + RCCL grad all-reduce ({args.comm_dtype} wire format, 64 MiB fp32 buckets, side stream)" if world > 1 else "") +
                                (" + gradient-bucket path with the collective replaced by a device copy (--force-gradsync)" if args.force_gradsync and world == 1 else "") +
+                               (f" + gradient-bucket path over a ONE-rank RCCL group ({args.comm_dtype} wire format, --rccl-world1)" if args.rccl_world1 and world == 1 else "") +
                                (f" + {args.cu_hog} CUs held on a side stream during backward (--cu-hog)" if args.cu_hog else "") +
                                (f" + persistent GEMM grids sized for {args.reserve_cus} fewer CUs (--reserve-cus)" if args.reserve_cus else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
@@ -363,7 +371,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(line))
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 

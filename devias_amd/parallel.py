@@ -33,11 +33,14 @@ def _os_environ_flag(name: str) -> bool:
 
 class GradSync:
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_bytes: int = 64 << 20, average: bool = True,
-                 comm_dtype: torch.dtype = torch.float32, simulate: bool = False, check_unused: bool = False):
+                 comm_dtype: torch.dtype = torch.float32, simulate: bool = False, check_unused: bool = False,
+                 collective_at_world1: bool = False):
         """Build AFTER module.to(device): the flat buckets are allocated on the parameters' device and every parameter gets the view of its
         place in them.  `simulate=True` (world size 1 only): every bucket still goes through the whole hook / event / side-stream path and the
         collective is replaced by a same-size device copy on the side stream (bench.py --force-gradsync: what the bookkeeping and a concurrent
-        bandwidth-bound kernel cost the step, measurable on ONE GPU)."""
+        bandwidth-bound kernel cost the step, measurable on ONE GPU).  `collective_at_world1=True`: a process group of ONE rank still issues every
+        bucket's all-reduce on the side stream (the whole backend path -- ProcessGroupNCCL's streams, its Work handles, the bf16 wire format -- on a
+        1-GPU box; RCCL refuses two ranks on one device)."""
         if comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("GradSync: comm_dtype must be torch.float32 or torch.bfloat16")
         self.pg = process_group
@@ -45,6 +48,7 @@ class GradSync:
         self.average = average
         self.comm_dtype = comm_dtype
         self.simulate = bool(simulate) and self.world == 1
+        self.collective_at_world1 = bool(collective_at_world1) and self.world == 1 and dist.is_initialized()
         self.check_unused = bool(check_unused)
         self._sim_buf = {}
         params = [p for p in module.parameters() if p.requires_grad]
@@ -96,7 +100,7 @@ class GradSync:
         self._works = []
         self._side = None
         self._accumulate = False
-        if (self.world > 1 or self.simulate) and params[0].is_cuda:
+        if (self.world > 1 or self.simulate or self.collective_at_world1) and params[0].is_cuda:
             # collectives (RCCL's kernels) will run beside backward: the persistent GEMMs pull their tiles from the dynamic queues, so that a CU the
             # collective holds or slows down takes fewer tiles instead of turning into a straggler (library option gemm_concurrent)
             from . import ops
@@ -120,7 +124,7 @@ class GradSync:
         if view.device != p.device:
             raise RuntimeError("GradSync: a parameter moved to another device after the buckets were built; rebuild GradSync after model.to(device)")
         bi = self._where[p]
-        if self._launched[bi] and not self._accumulate and (self.world > 1 or self.simulate):
+        if self._launched[bi] and not self._accumulate and (self.world > 1 or self.simulate or self.collective_at_world1):
             # a second backward before finish(): this gradient would be added into a bucket whose all-reduce is already in flight
             raise RuntimeError("GradSync: gradient arrived for a bucket that is already being reduced -- call finish() after every backward "
                                "(or set_accumulate(True) for all micro-batches but the last)")
@@ -137,7 +141,7 @@ class GradSync:
     def _launch(self, bi: int):
         self._launched[bi] = True
         flat = self.flat[bi]
-        if self.world == 1:
+        if self.world == 1 and not self.collective_at_world1:
             if self.simulate and flat.is_cuda:         # stand-in for the collective: the same bytes moved once on the side stream
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=flat.device)

@@ -339,6 +339,48 @@ def test_slot_model_two_ranks_equals_chunked_single_gpu(backend):
             assert err < 1e-5, (backend, n, rank, err)
 
 
+def _rccl_world1_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from devias_amd.parallel import GradSync
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = {}
+    for name, cd in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        made = []
+
+        def mk(m, cd=cd):
+            made.append(GradSync(m, bucket_bytes=1 << 20, comm_dtype=cd, collective_at_world1=True))
+            return made[-1]
+        g = _slot_hip_grads(dev, [0], sync=mk)
+        assert made[0].collective_at_world1 and len(made[0].buckets) > 1
+        out[name] = {n: v.numpy() for n, v in g.items()}
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_gradsync_over_a_one_rank_rccl_group():
+    """The bucket path over the REAL backend on a 1-GPU box (RCCL refuses two ranks on one device): a process group of one rank, every
+    bucket's all-reduce issued from the gradient hooks on the side stream through ProcessGroupNCCL (its streams, Work.wait() on the compute
+    stream), fp32 and bf16 wire formats.  Sum over one rank = the gradient itself: fp32 exactly, bf16 to one rounding."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    ref = _slot_hip_grads(torch.device("cuda", 0), [0])
+    for n, v in ref.items():
+        assert torch.equal(torch.from_numpy(res["fp32"][n]), v), n
+        b = torch.from_numpy(res["bf16"][n])
+        assert torch.equal(b, v.bfloat16().float()), n
+
+
 @pytest.mark.gpu
 def test_slot_model_gradsync_world1_on_gpu():
     """single GPU: the two-chunk gradient accumulated through GradSync's buckets (world 1: no collective, gradients written / accumulated in
