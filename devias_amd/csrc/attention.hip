@@ -82,6 +82,18 @@ __device__ __forceinline__ HeadMap head_map(int nblk, int H, int B, bool xcd) {
     return m;
 }
 
+// ---- attention dropout (Attention.attn_drop, model/modeling_slot.py:90,110: nn.Dropout on the softmax matrix) ---------------------------------
+// The N x N matrix never exists, so neither does its mask: element (b, h, query i, key j) is kept when a 32-bit hash of (seed, b * H + h, i, j) is below
+// keep * 2^32, and kept elements are scaled by 1 / keep.  The same function is evaluated by the forward and by both backward kernels (and restated in
+// numpy by the oracle: oracle/ref_cpu.py attn_drop_mask).  Row sums (the softmax normaliser, logsumexp) are over the UN-dropped probabilities;
+// delta = rowsum(dO * O) with the dropped-out O is still sum_j P_ij dP_ij, so the recompute-from-logsumexp backward carries over with
+// dP_ij = mask_ij (dO_i . V_j) and dV = (P * mask)^T dO.
+struct DropP { uint32_t thresh, s0, s1; float inv_keep; };
+__device__ __forceinline__ uint32_t drop_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ uint32_t drop_rowkey(const DropP& d, uint32_t bh, uint32_t i) { return drop_mix(drop_mix(d.s0 ^ (bh * 0x9E3779B1u)) + d.s1 + i * 0x85EBCA6Bu); }
+// 0 or 1 / keep
+__device__ __forceinline__ float drop_scale(const DropP& d, uint32_t rowkey, uint32_t j) { return drop_mix(rowkey + j * 0xC2B2AE35u) < d.thresh ? d.inv_keep : 0.f; }
+
 // stage a [64][64] bf16 tile: 512 16-byte chunks, 512/NT per thread.  rows >= nrows are zero-filled.
 template <int NT>
 struct TileRegs {
@@ -352,9 +364,9 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     return *reinterpret_cast<const unsigned*>(&t);
 }
 
-template <int NW>
+template <int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse,
-                                                                    int N, int H, float scale, int xcd) {
+                                                                    int N, int H, float scale, int xcd, DropP drop = DropP{}) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];      // two stages of (K row image | V transposed-read image)
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, r32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -367,6 +379,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16*
     const bool active = q0 < N;                                        // (a wave without a valid query only stages and synchronises)
     const float sl2 = scale * LOG2E;
     constexpr float THR = 6.0f;
+    uint32_t rowkey = 0;                                               // DROP: this lane's query row of the mask
+    if constexpr (DROP) rowkey = drop_rowkey(drop, (uint32_t)(b * H + h), (uint32_t)min(q0 + r32, N - 1));
 
     // Q^T as the B operand: lane (hi, query q0 + r32) holds d = 16 ks + 8 hi .. + 8, pre-scaled
     bf16x8 qf[4];
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16*
         }
     };
     // P = exp2(S'), this lane's share of the row sums, and the B operands of O^T += V^T P^T (register pairs (r, r + 1) -> one packed word)
-    auto soft = [&](const f32x16 (&st)[2], bf16x8 (&pf)[2][2]) {
+    auto soft = [&](const f32x16 (&st)[2], bf16x8 (&pf)[2][2], int t) {
         float ls0 = 0.f, ls1 = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -460,6 +474,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16*
                 for (int j = 0; j < 8; j += 2) {
                     const float p0 = fast_exp2(st[kb][8 * s2 + j]), p1 = fast_exp2(st[kb][8 * s2 + j + 1]);
                     ls0 += p0; ls1 += p1;
+                    if constexpr (DROP) {                               // the sums above are of the un-dropped probabilities; O takes the dropped ones
+                        const int r = 8 * s2 + j, key = t * 64 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;      // (r + 1 is key + 1)
+                        w[j >> 1] = cvt_pk_bf16(p0 * drop_scale(drop, rowkey, (uint32_t)key), p1 * drop_scale(drop, rowkey, (uint32_t)key + 1));
+                    } else
                     w[j >> 1] = cvt_pk_bf16(p0, p1);
                 }
                 pf[kb][s2] = *reinterpret_cast<const bf16x8*>(&w);
@@ -504,7 +522,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16*
         bf16x8 pf[2][2];
         s_tile(t, st, t + 1 == nkv && (N & 63) != 0);
         decide(st, t == 0);
-        soft(st, pf);
+        soft(st, pf, t);
         pv_tile(t, pf);
     }
     if (q0 + r32 < N) {
@@ -524,11 +542,11 @@ __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16*
 }
 
 // ======================================= backward dQ (bf16) ==============================================
-template <int QT, int NW>
+template <int QT, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                               int N, int H, float scale, int xcd) {
+                                                               int N, int H, float scale, int xcd, DropP drop = DropP{}) {
     __shared__ __attribute__((aligned(16))) char smem[32768];     // two stages of (K image | V image), filled by LDS-DMA one tile ahead
     char* imgKt = smem;            // K, one image for both uses: row reads (S^T = K Q^T) and transposed reads (dQ^T = K^T dS^T)
     char* imgV = smem + 8192;      // V rows   (dP^T = V dO^T)
@@ -543,9 +561,11 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 
     bf16x8 qf[QT][2], dof[QT][2];
     float lse2[QT], dl[QT];
+    uint32_t rowkey[QT];                                               // DROP: the mask rows of this lane's queries
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         int q = min(q0 + 16 * qt + c, N - 1);
+        rowkey[qt] = DROP ? drop_rowkey(drop, (uint32_t)(b * H + h), (uint32_t)q) : 0u;
         const bf16* orow = o + ((int64_t)b * N + q) * D + h * 64;
         const bf16* dorow = d_o + ((int64_t)b * N + q) * D + h * 64;
         float part = 0.f;
@@ -630,7 +650,12 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
                 for (int r = 0; r < 4; r += 2) {
                     const f32x2 e = f32x2{acc_s[kt][qt][r], acc_s[kt][qt][r + 1]} * sl2v + nl;
                     const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
-                    const f32x2 ds = p * (f32x2{acc_dp[kt][qt][r], acc_dp[kt][qt][r + 1]} - dlv);   // dS^T / scale (scale applied once at the end)
+                    f32x2 dp = {acc_dp[kt][qt][r], acc_dp[kt][qt][r + 1]};
+                    if constexpr (DROP) {                              // dP_ij = mask_ij (dO_i . V_j)
+                        const uint32_t key = (uint32_t)(k0 + 16 * kt + 4 * g + r);
+                        dp = dp * f32x2{drop_scale(drop, rowkey[qt], key), drop_scale(drop, rowkey[qt], key + 1)};
+                    }
+                    const f32x2 ds = p * (dp - dlv);                   // dS^T / scale (scale applied once at the end)
                     acc_s[kt][qt][r] = ds[0]; acc_s[kt][qt][r + 1] = ds[1];
                 }
         }
@@ -660,9 +685,10 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 }
 
 // ======================================= backward dK, dV (bf16) ==========================================
+template <bool DROP = false>
 __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                 bf16* __restrict__ dqkv, int N, int H, float scale, int xcd) {
+                                                                 bf16* __restrict__ dqkv, int N, int H, float scale, int xcd, DropP drop = DropP{}) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 2 * 512];   // two stages of (Q image | dO image) filled by LDS-DMA one tile ahead, + their row statistics
     char* imgQt = smem;             // Q, one image: row reads (S = Q K^T) and transposed reads (dK^T = Q^T dS)
     char* imgOt = smem + 8192;      // dO, one image: row reads (dP = dO V^T) and transposed reads (dV^T = dO^T P)
@@ -762,8 +788,15 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
                 for (int r = 0; r < 4; r += 2) {                                    // packed fp32: two scores per VALU op
                     const f32x2 e = f32x2{acc_s[qt][kt][r], acc_s[qt][kt][r + 1]} * sl2v - f32x2{l4[r], l4[r + 1]};
                     const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
-                    const f32x2 ds = p * (f32x2{acc_dp[qt][kt][r], acc_dp[qt][kt][r + 1]} - f32x2{d4[r], d4[r + 1]});   // dS / scale
-                    acc_s[qt][kt][r] = p[0]; acc_s[qt][kt][r + 1] = p[1];
+                    f32x2 dp = {acc_dp[qt][kt][r], acc_dp[qt][kt][r + 1]}, pd = p;
+                    if constexpr (DROP) {                              // queries 64 t + 16 qt + 4 g + r (+ 1), key key0 + 16 kt + c: dV takes P * mask, dP = mask (dO . V)
+                        const uint32_t q = (uint32_t)min(t * 64 + 16 * qt + 4 * g + r, N - 1), key = (uint32_t)(key0 + 16 * kt + c);
+                        const f32x2 m = {drop_scale(drop, drop_rowkey(drop, (uint32_t)(b * H + h), q), key),
+                                         drop_scale(drop, drop_rowkey(drop, (uint32_t)(b * H + h), (uint32_t)min((int)q + 1, N - 1)), key)};
+                        dp = dp * m; pd = p * m;
+                    }
+                    const f32x2 ds = p * (dp - f32x2{d4[r], d4[r + 1]});   // dS / scale
+                    acc_s[qt][kt][r] = pd[0]; acc_s[qt][kt][r + 1] = pd[1];
                     acc_dp[qt][kt][r] = ds[0]; acc_dp[qt][kt][r + 1] = ds[1];
                 }
         }
@@ -804,8 +837,9 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
 
 // ======================================= fp32 parity kernels ==============================================
 // forward: 128 threads, one query per thread (q and o in registers), K/V tiles of 32 keys broadcast from LDS
+template <bool DROP = false>
 __global__ __launch_bounds__(128) void mhsa_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                           float* __restrict__ lse, int N, int H, float scale) {
+                                                           float* __restrict__ lse, int N, int H, float scale, DropP drop = DropP{}) {
     __shared__ __attribute__((aligned(16))) float sk[32][64];
     __shared__ __attribute__((aligned(16))) float sv[32][64];
     const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -822,6 +856,7 @@ __global__ __launch_bounds__(128) void mhsa_fwd_f32_kernel(const float* __restri
         acc[d] = acc[d + 1] = acc[d + 2] = acc[d + 3] = 0.f;
     }
     float m = -INFINITY, l = 0.f;
+    const uint32_t rowkey = DROP ? drop_rowkey(drop, (uint32_t)(b * H + h), (uint32_t)qc) : 0u;
     for (int k0 = 0; k0 < N; k0 += 32) {
         __syncthreads();
         for (int i = tid; i < 32 * 16; i += 128) {
@@ -841,8 +876,9 @@ __global__ __launch_bounds__(128) void mhsa_fwd_f32_kernel(const float* __restri
             const float alpha = expf(m - mn), p = expf(s - mn);
             m = mn;
             l = l * alpha + p;
+            const float pd = DROP ? p * drop_scale(drop, rowkey, (uint32_t)(k0 + j)) : p;
 #pragma unroll
-            for (int d = 0; d < 64; ++d) acc[d] = acc[d] * alpha + p * sv[j][d];
+            for (int d = 0; d < 64; ++d) acc[d] = acc[d] * alpha + pd * sv[j][d];
         }
     }
     if (q < N) {
@@ -858,10 +894,11 @@ __global__ __launch_bounds__(128) void mhsa_fwd_f32_kernel(const float* __restri
 }
 
 // backward dQ (+ delta): one query per thread
+template <bool DROP = false>
 __global__ __launch_bounds__(128) void mhsa_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                               const float* __restrict__ d_o, const float* __restrict__ lse,
                                                               float* __restrict__ delta, float* __restrict__ dqkv,
-                                                              int N, int H, float scale) {
+                                                              int N, int H, float scale, DropP drop = DropP{}) {
     __shared__ __attribute__((aligned(16))) float sk[32][64];
     __shared__ __attribute__((aligned(16))) float sv[32][64];
     const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -882,6 +919,7 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dq_f32_kernel(const float* __res
         dq[d] = 0.f;
     }
     const float ls = lse[((int64_t)b * H + h) * N + qc];
+    const uint32_t rowkey = DROP ? drop_rowkey(drop, (uint32_t)(b * H + h), (uint32_t)qc) : 0u;
     if (q < N) delta[((int64_t)b * H + h) * N + q] = dl;
     for (int k0 = 0; k0 < N; k0 += 32) {
         __syncthreads();
@@ -899,6 +937,7 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dq_f32_kernel(const float* __res
 #pragma unroll
             for (int d = 0; d < 64; ++d) { s += qr[d] * sk[j][d]; dp += dor[d] * sv[j][d]; }
             const float p = expf(s * scale - ls);
+            if constexpr (DROP) dp *= drop_scale(drop, rowkey, (uint32_t)(k0 + j));
             const float ds = p * (dp - dl) * scale;
 #pragma unroll
             for (int d = 0; d < 64; ++d) dq[d] += ds * sk[j][d];
@@ -912,9 +951,10 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dq_f32_kernel(const float* __res
 }
 
 // backward dK/dV: two threads per key (each owns 32 of the 64 head dims); 128 threads = 64 keys per workgroup
+template <bool DROP = false>
 __global__ __launch_bounds__(128) void mhsa_bwd_dkdv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ d_o,
                                                                 const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                float* __restrict__ dqkv, int N, int H, float scale) {
+                                                                float* __restrict__ dqkv, int N, int H, float scale, DropP drop = DropP{}) {
     __shared__ __attribute__((aligned(16))) float sq[32][64];
     __shared__ __attribute__((aligned(16))) float sdo[32][64];
     __shared__ float sl[32], sd[32];
@@ -956,9 +996,14 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dkdv_f32_kernel(const float* __r
             s += __shfl_xor(s, 1, 64);
             dp += __shfl_xor(dp, 1, 64);
             const float p = expf(s * scale - sl[i]);
+            float pd = p;
+            if constexpr (DROP) {
+                const float mk = drop_scale(drop, drop_rowkey(drop, (uint32_t)(b * H + h), (uint32_t)(q0 + i)), (uint32_t)kc);
+                dp *= mk; pd = p * mk;
+            }
             const float ds = p * (dp - sd[i]) * scale;
 #pragma unroll
-            for (int d = 0; d < 32; ++d) { dv[d] += p * sdo[i][half + d]; dk[d] += ds * sq[i][half + d]; }
+            for (int d = 0; d < 32; ++d) { dv[d] += pd * sdo[i][half + d]; dk[d] += ds * sq[i][half + d]; }
         }
     }
     if (key < N) {
@@ -995,9 +1040,21 @@ static int attn_xcd_flag(int B, int H) {
     return (B << 16) | ((attn_knobs().xcd && ((B * H) % 8 == 0)) ? 1 : 0);
 }
 
-extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
-                               int32_t dtype, void* stream) {
+// keep >= 1: no dropout.  thresh = floor(keep * 2^32) (at most 2^32 - 1), seed = (s1 << 32) | s0
+static bool drop_params(float keep, uint64_t seed, DropP& d) {
+    if (!(keep < 1.0f)) return false;
+    const double t = floor((double)keep * 4294967296.0);
+    d.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    d.s0 = (uint32_t)seed; d.s1 = (uint32_t)(seed >> 32);
+    d.inv_keep = 1.0f / keep;
+    return true;
+}
+
+static int mhsa_fwd_impl(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
+                         int32_t dtype, float keep, uint64_t seed, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    DropP dp{};
+    const bool drop = drop_params(keep, seed, dp);
     DEVIAS_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0, "devias_mhsa_fwd: bad args");
     DEVIAS_REQUIRE(aligned16(qkv) && aligned16(o), "devias_mhsa_fwd: qkv/o must be 16-byte aligned");
     DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_fwd: H and B must be <= 65535");
@@ -1007,27 +1064,40 @@ extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, 
         const int xcd = attn_xcd_flag(B, H);
         devias_count(DEVIAS_CNT_MHSA_FWD_BF16);
 #define FWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
-        if (cfg == 6) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
-        else if (cfg == 7) hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<2>), FWD_GRID(64), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        if (drop) hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd, dp);
+        else if (cfg == 6) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        else if (cfg == 7) hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<2>), FWD_GRID(64), dim3(128), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd, dp);
         // default (measured at B = 32, H = 12, N = 1568, same box): 32x32x16 kernel 302 us against 334-345 us for the 16x16x32 kernel (cfg 6)
-        else hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<4>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
+        else hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<4>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd, dp);
 #undef FWD_GRID
     }
     else if (dtype == DEVIAS_F32) {
         devias_count(DEVIAS_CNT_MHSA_FWD_F32);
-        hipLaunchKernelGGL(mhsa_fwd_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (float*)o, lse, N, H, scale);
+        if (drop) hipLaunchKernelGGL(mhsa_fwd_f32_kernel<true>, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (float*)o, lse, N, H, scale, dp);
+        else hipLaunchKernelGGL(mhsa_fwd_f32_kernel<false>, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (float*)o, lse, N, H, scale, dp);
     } else return devias_set_error(DEVIAS_EINVAL, "devias_mhsa_fwd: bad dtype %d", dtype);
     DEVIAS_CHECK_LAUNCH("devias_mhsa_fwd");
     return DEVIAS_OK;
+}
+extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
+                               int32_t dtype, void* stream) {
+    return mhsa_fwd_impl(qkv, o, lse, B, N, H, scale, dtype, 1.0f, 0, stream);
+}
+extern "C" int devias_mhsa_fwd_dropout(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
+                                       int32_t dtype, float keep, uint64_t seed, void* stream) {
+    DEVIAS_REQUIRE(keep > 0.f && keep <= 1.f, "devias_mhsa_fwd_dropout: keep must be in (0, 1]");
+    return mhsa_fwd_impl(qkv, o, lse, B, N, H, scale, dtype, keep, seed, stream);
 }
 
 // (ABI 140 had a single-pass backward that needed a workspace; it was removed in ABI 150 -- see DESIGN.md -- and the query stays for hosts
 // written against the older header: nothing is needed any more)
 extern "C" int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H) { (void)B; (void)N; (void)H; return 0; }
 
-extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
-                               int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* ws, void* stream) {
+static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                         int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    DropP dp{};
+    const bool drop = drop_params(keep, seed, dp);
     DEVIAS_REQUIRE(qkv && o && d_o && lse && delta && dqkv && B > 0 && N > 0 && H > 0, "devias_mhsa_bwd: bad args");
     DEVIAS_REQUIRE(aligned16(qkv) && aligned16(o) && aligned16(d_o) && aligned16(dqkv), "devias_mhsa_bwd: unaligned pointer");
     DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_bwd: H and B must be <= 65535");
@@ -1035,26 +1105,43 @@ extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, 
         const int cfg = attn_knobs().cfg;
         const int xcd = attn_xcd_flag(B, H);
         devias_count(DEVIAS_CNT_MHSA_BWD_BF16);
-#define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, xcd
+#define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp
 #define BWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
-        if (cfg == 1) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 2>), BWD_GRID(128), dim3(128), 0, st, DQ_ARGS);
+        if (drop) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 4, true>), BWD_GRID(128), dim3(256), 0, st, DQ_ARGS);
+        else if (cfg == 1) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 2>), BWD_GRID(128), dim3(128), 0, st, DQ_ARGS);
         else if (cfg == 2) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 4>), BWD_GRID(256), dim3(256), 0, st, DQ_ARGS);
         else if (cfg == 3) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 2>), BWD_GRID(64), dim3(128), 0, st, DQ_ARGS);
         else hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 4>), BWD_GRID(128), dim3(256), 0, st, DQ_ARGS);
 #undef DQ_ARGS
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");
-        hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
-                           lse, delta, (bf16*)dqkv, N, H, scale, xcd);
+        if (drop) hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<true>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
+                                     lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp);
+        else hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<false>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
+                                lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp);
 #undef BWD_GRID
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv)");
     } else if (dtype == DEVIAS_F32) {
         devias_count(DEVIAS_CNT_MHSA_BWD_F32);
-        hipLaunchKernelGGL(mhsa_bwd_dq_f32_kernel, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)o,
-                           (const float*)d_o, lse, delta, (float*)dqkv, N, H, scale);
+        if (drop) hipLaunchKernelGGL(mhsa_bwd_dq_f32_kernel<true>, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)o,
+                                     (const float*)d_o, lse, delta, (float*)dqkv, N, H, scale, dp);
+        else hipLaunchKernelGGL(mhsa_bwd_dq_f32_kernel<false>, dim3(cdiv(N, 128), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)o,
+                                (const float*)d_o, lse, delta, (float*)dqkv, N, H, scale, dp);
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");
-        hipLaunchKernelGGL(mhsa_bwd_dkdv_f32_kernel, dim3(cdiv(N, 64), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)d_o,
-                           lse, delta, (float*)dqkv, N, H, scale);
+        if (drop) hipLaunchKernelGGL(mhsa_bwd_dkdv_f32_kernel<true>, dim3(cdiv(N, 64), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)d_o,
+                                     lse, delta, (float*)dqkv, N, H, scale, dp);
+        else hipLaunchKernelGGL(mhsa_bwd_dkdv_f32_kernel<false>, dim3(cdiv(N, 64), H, B), dim3(128), 0, st, (const float*)qkv, (const float*)d_o,
+                                lse, delta, (float*)dqkv, N, H, scale, dp);
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv)");
     } else return devias_set_error(DEVIAS_EINVAL, "devias_mhsa_bwd: bad dtype %d", dtype);
     return DEVIAS_OK;
+}
+extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                               int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* ws, void* stream) {
+    (void)ws;
+    return mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, 1.0f, 0, stream);
+}
+extern "C" int devias_mhsa_bwd_dropout(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                                       int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream) {
+    DEVIAS_REQUIRE(keep > 0.f && keep <= 1.f, "devias_mhsa_bwd_dropout: keep must be in (0, 1]");
+    return mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream);
 }

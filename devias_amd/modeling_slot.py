@@ -289,21 +289,33 @@ class EncoderBlockFn(Function):
     """x -> x + proj(MHSA(LN1 x)) -> + fc2(GELU(fc1(LN2 .)))   (Block.forward, modeling_slot.py:142-152; no LayerScale, drop_path 0)"""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qb, vb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, meta, ds1=None, ds2=None):
+    def forward(ctx, x, n1w, n1b, qkvw, qb, vb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, meta, ds1=None, ds2=None, drop=None):
+        """drop = (E1, E2, attn): training with drop_rate / attn_drop_rate > 0 (modeling_slot.py:110,114,66).  E1 / E2: fp32 [M, D] element masks of
+        proj_drop / Mlp.drop, each 0 or 1 / keep and already carrying the branch's per-sample drop_path factor (then ds1 / ds2 are None); attn =
+        (keep, seed) of the softmax-matrix dropout (ops.mhsa_fwd) or None."""
         B, N, H, eps, cdt = meta
         scale = 64 ** -0.5
+        E1, E2, adrop = drop if drop is not None else (None, None, None)
+        assert (E1 is None) == (E2 is None) and (E1 is None or (ds1 is None and ds2 is None))
         n1w_, n1b_, n2w_, n2b_ = _f32(n1w), _f32(n1b), _f32(n2w), _f32(n2b)
         Wqkv, Wp, W1, W2 = (_WCACHE.get(w, cdt) for w in (qkvw, pw, f1w, f2w))
         u, mean1, rstd1 = ops.layernorm_fwd(x, n1w_, n1b_, eps)
         qkv_bias = torch.cat((_f32(qb), torch.zeros_like(_f32(vb)), _f32(vb)))         # modeling_slot.py:97-99
         qkv = ops.gemm(u, Wqkv, bias=qkv_bias)                                          # [M, 3D] == [B,N,3,H,64]
-        o, lse = ops.mhsa_fwd(qkv, B, N, H, scale)
-        x1 = ops.gemm(o, Wp, bias=_f32(pb), res=x, row_scale=ds1, rows_per_scale=N)       # x + drop_path(proj(.))
+        o, lse = ops.mhsa_fwd(qkv, B, N, H, scale, drop=adrop)
+        if E1 is None:
+            x1 = ops.gemm(o, Wp, bias=_f32(pb), res=x, row_scale=ds1, rows_per_scale=N)   # x + drop_path(proj(.))
+        else:
+            x1 = ops.mul_mask(ops.gemm(o, Wp, bias=_f32(pb)), E1, x)                      # x + drop_path(proj_drop(proj(.)))
         u2, mean2, rstd2 = ops.layernorm_fwd(x1, n2w_, n2b_, eps)
         hpre = torch.empty((x.shape[0], W1.shape[0]), dtype=cdt, device=x.device)
         hact = ops.gemm(u2, W1, bias=_f32(f1b), act=ACT_GELU, aux_out=hpre)
-        x2 = ops.gemm(hact, W2, bias=_f32(f2b), res=x1, row_scale=ds2, rows_per_scale=N)   # x1 + drop_path(mlp(.))
+        if E2 is None:
+            x2 = ops.gemm(hact, W2, bias=_f32(f2b), res=x1, row_scale=ds2, rows_per_scale=N)   # x1 + drop_path(mlp(.))
+        else:
+            x2 = ops.mul_mask(ops.gemm(hact, W2, bias=_f32(f2b)), E2, x1)                 # x1 + drop_path(drop(fc2(.)))
         ctx.meta = meta
+        ctx.drop = (E1, E2, adrop)
         ctx.ds = (ds1, ds2)
         ctx.params = (n1w, n1b, qkvw, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, qb, vb)
         ctx.saved = (x, u, mean1, rstd1, qkv, o, lse, x1, u2, mean2, rstd2, hpre, hact, n1w_, n2w_, Wqkv, Wp, W1, W2)
@@ -319,12 +331,16 @@ class EncoderBlockFn(Function):
         D = x.shape[1]
         dev = x.device
         ds1, ds2 = ctx.ds
+        E1, E2, adrop = ctx.drop
         lane = _WgradLane(dev)
         (p_n1w, p_n1b, p_qkvw, p_pw, p_pb, p_n2w, p_n2b, p_f1w, p_f1b, p_f2w, p_f2b, p_qb, p_vb) = ctx.params
         f32 = lambda n: torch.empty((n,), dtype=torch.float32, device=dev)          # noqa: E731
         dst = lambda p_, n: _gout(p_) if _gout(p_) is not None else f32(n)          # noqa: E731  (gradient bucket view, or a fresh buffer)
         # ---- MLP branch (g2 = gradient of the branch output: dx2 scaled by the per-sample stochastic-depth factor, if any)
-        if ds2 is None:
+        if E2 is not None:
+            g2 = ops.mul_mask(dx2, E2)
+            db2 = ops.colsum(g2, out=_gout(p_f2b))
+        elif ds2 is None:
             g2, db2 = dx2, _take_colsum(dx2, out=_gout(p_f2b))                          # fc2 bias gradient
         else:
             g2 = ops.row_scale(dx2, ds2, N)
@@ -340,7 +356,10 @@ class EncoderBlockFn(Function):
         dx1, dn2w, dn2b = ops.layernorm_bwd(du2, x1, n2w_, mean2, rstd2, dres=dx2, dx_colsum=dbp,
                                             dgamma=_gout(p_n2w), dbeta=_gout(p_n2b))      # + residual gradient; dbp = colsum(dx1)
         # ---- attention branch
-        if ds1 is None:
+        if E1 is not None:
+            g1 = ops.mul_mask(dx1, E1)
+            dbp = ops.colsum(g1, out=dbp)
+        elif ds1 is None:
             g1 = dx1
         else:
             g1 = ops.row_scale(dx1, ds1, N)
@@ -348,7 +367,7 @@ class EncoderBlockFn(Function):
         with lane.after_main():
             dWp = ops.wgrad(g1, o, out=_gout(p_pw))
         d_o = ops.gemm(g1, Wp, trans_b=True)
-        dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale)
+        dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop)
         with lane.after_main():
             dWqkv = ops.wgrad(dqkv, u, out=_gout(p_qkvw))
             dbq = ops.colsum(dqkv, out=_gout(p_qb), cols=(0, D))              # q_bias | (k: no bias) | v_bias, each to its own destination
@@ -358,7 +377,37 @@ class EncoderBlockFn(Function):
         dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1, dx_colsum=dxs, dgamma=_gout(p_n1w), dbeta=_gout(p_n1b))
         _publish_colsum(dx, dxs)
         lane.join(dW2, dW1, dWp, dWqkv, dbq, dbv)
-        return (dx, dn1w, dn1b, dWqkv, dbq, dbv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None)
+        return (dx, dn1w, dn1b, dWqkv, dbq, dbv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2, None, None, None, None)
+
+
+class DropMaskFn(Function):
+    """y = x * mask with a caller-drawn fp32 mask of 0 / (1 / keep): nn.Dropout with its mask made explicit (pos_drop, modeling_slot.py:280,356)"""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.mask = mask
+        return ops.mul_mask(x, mask)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.mul_mask(dy.contiguous(), ctx.mask), None
+
+
+class DropoutSource:
+    """Where the training-time dropout masks of the encoder come from.  The default draws them from torch's generators, as nn.Dropout does
+    (element masks: the device generator, like the drop_path masks; the seed of the attention-matrix mask: the CPU generator, no device sync).
+    Tests and tests/golden/make_goldens.py replace it (VisionTransformer.dropout_source) to give the reference, the oracle and the kernels the SAME masks."""
+
+    def element_mask(self, kind: str, block: int, shape, keep: float, device) -> torch.Tensor:
+        """fp32 mask of 0 / (1 / keep); kind in {'pos', 'proj', 'mlp'}"""
+        return ((keep + torch.rand(shape, device=device, dtype=torch.float32)).floor() / keep).contiguous()
+
+    def path_scale(self, block: int, B: int, keep: float, device) -> torch.Tensor:
+        """fp32 [2, B]: timm 0.4.12 drop_path (modeling_slot.py:36-47) masks of the attention and the MLP branch, 0 / (1 / keep) per sample"""
+        return ((keep + torch.rand((2, B), device=device, dtype=torch.float32)).floor() / keep).contiguous()
+
+    def attn_seed(self, block: int) -> int:
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 _LAYER_KEYS = ("to_q", "to_k", "to_v", "to_out_w", "to_out_b", "norm_w", "norm_b", "ctx_w", "ctx_b",
@@ -1036,7 +1085,7 @@ class Block(nn.Module):
         else:
             self.gamma_1, self.gamma_2 = None, None
 
-    def run(self, x, B, N, cdt):
+    def run(self, x, B, N, cdt, index=0, source=None):
         a = self.attn
         if a.q_bias is None:
             raise NotImplementedError("qkv_bias=False is not used by any DEVIAS entrypoint")
@@ -1044,14 +1093,29 @@ class Block(nn.Module):
         if self.training and self.drop_path_rate > 0:
             # timm 0.4.12 drop_path (modeling_slot.py:36-47): per-sample Bernoulli(keep) mask scaled by 1/keep, drawn independently
             # for the attention and the MLP branch; applied inside the residual GEMM epilogues (row_scale)
-            keep = 1.0 - self.drop_path_rate
-            r = torch.rand((2, B), device=x.device, dtype=torch.float32)
-            ds = ((keep + r).floor() / keep).contiguous()
+            source = source or DropoutSource()
+            ds = source.path_scale(index, B, 1.0 - self.drop_path_rate, x.device)
             ds1, ds2 = ds[0], ds[1]
         meta = (B, N, a.num_heads, self.norm1.eps, cdt)
-        return (EncoderBlockRegionFn if _REGIONS else EncoderBlockFn).apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight,
-                                    a.proj.bias, self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
-                                    self.mlp.fc2.weight, self.mlp.fc2.bias, meta, ds1, ds2)
+        args = (x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias, a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias,
+                self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, meta)
+        p_drop, p_attn = float(a.proj_drop.p), float(a.attn_drop.p)          # Mlp.drop.p == proj_drop.p (Block.__init__: both `drop`)
+        if self.training and (p_drop > 0 or p_attn > 0):
+            # nn.Dropout inside the block (modeling_slot.py:110 attn_drop, :114 proj_drop, :66 Mlp.drop): the per-kernel sequence, not the fused region
+            # (no DEVIAS recipe sets these rates; the region's GEMM epilogues carry no element mask)
+            source = source or DropoutSource()
+            E1 = E2 = None
+            if p_drop > 0:
+                M, D = x.shape
+                E1 = source.element_mask("proj", index, (M, D), 1.0 - p_drop, x.device)
+                E2 = source.element_mask("mlp", index, (M, D), 1.0 - p_drop, x.device)
+                if ds1 is not None:                                           # drop_path(dropout(.)): one mask carries both factors
+                    E1 = (E1.view(B, N, D) * ds1.view(B, 1, 1)).view(M, D).contiguous()
+                    E2 = (E2.view(B, N, D) * ds2.view(B, 1, 1)).view(M, D).contiguous()
+                    ds1 = ds2 = None
+            adrop = (1.0 - p_attn, source.attn_seed(index)) if p_attn > 0 else None
+            return EncoderBlockFn.apply(*args, ds1, ds2, (E1, E2, adrop))
+        return (EncoderBlockRegionFn if _REGIONS else EncoderBlockFn).apply(*args, ds1, ds2)
 
 
 class PatchEmbed(nn.Module):
@@ -1165,11 +1229,10 @@ class VisionTransformer(nn.Module):
             raise ValueError("incorrent slot_matching_method")
         if head_type not in ('linear', 'mlp'):
             raise ValueError(f"head_type must be 'linear' or 'mlp' (modeling_slot.py:300-313), got {head_type!r}")
-        if drop_rate or attn_drop_rate:
-            raise NotImplementedError("drop_rate / attn_drop_rate > 0 (dropout inside the encoder blocks) is not implemented in the HIP path: no DEVIAS "
-                                      "recipe sets them (docs/TRAIN.md); fc_drop_rate (dropout before the head, UCF-101 / HMDB recipes) is supported")
-        if not 0.0 <= float(fc_drop_rate) < 1.0:
-            raise ValueError(f"fc_drop_rate must be in [0, 1), got {fc_drop_rate}")
+        for nm, v in (("fc_drop_rate", fc_drop_rate), ("drop_rate", drop_rate), ("attn_drop_rate", attn_drop_rate)):
+            if not 0.0 <= float(v) < 1.0:
+                raise ValueError(f"{nm} must be in [0, 1), got {v}")
+        self.dropout_source = None             # None: DropoutSource() (torch's generators); tests install one with given masks
         if use_learnable_pos_emb:
             raise NotImplementedError("learnable pos-emb is not used by DEVIAS (sinusoid table only)")
         self.num_slots = num_latents
@@ -1280,8 +1343,11 @@ class VisionTransformer(nn.Module):
         cdt = self.compute_dtype
         pe = self.patch_embed
         h = PatchEmbedFn.apply(x, pe.proj.weight, pe.proj.bias, self._pos(x.device, cdt), (pe.tubelet_size, pe.patch_size[0], cdt))
-        for blk in self.blocks:
-            h = blk.run(h, B, N, cdt)
+        src = self.dropout_source or DropoutSource()
+        if self.training and self.pos_drop.p > 0:                                 # pos_drop (modeling_slot.py:280,356)
+            h = DropMaskFn.apply(h, src.element_mask("pos", -1, tuple(h.shape), 1.0 - float(self.pos_drop.p), h.device))
+        for i, blk in enumerate(self.blocks):
+            h = blk.run(h, B, N, cdt, i, src)
         return h          # [B*N, D], BEFORE the final LayerNorm (it is fused into AggBlockFn)
 
     def forward(self, x, return_attn=False):

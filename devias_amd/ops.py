@@ -276,7 +276,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
     return dx, dgamma, dbeta
 
 
-def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, out: Optional[torch.Tensor] = None):
+def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, out: Optional[torch.Tensor] = None, drop=None):
+    """drop = (keep, seed): nn.Dropout(1 - keep) on the softmax matrix, mask = the library's hash of (seed, b, h, i, j) (include/devias_amd.h)"""
     _chk(qkv, "mhsa_fwd.qkv")
     assert qkv.numel() == B * N * 3 * H * 64, "mhsa: head dim must be 64"
     if out is None:
@@ -285,15 +286,24 @@ def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, out: Optio
         o = _chk(out, "mhsa_fwd.out", qkv.dtype)
         assert o.shape == (B * N, H * 64)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    if drop is not None and float(drop[0]) < 1.0:
+        _lib.check(_lib.load().devias_mhsa_fwd_dropout(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, scale, dt_code(qkv.dtype),
+                                                       float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, _stream()), "devias_mhsa_fwd_dropout")
+        return o, lse
     _lib.check(_lib.load().devias_mhsa_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), _stream()),
                "devias_mhsa_fwd")
     return o, lse
 
 
-def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float):
+def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None):
     _chk(qkv, "mhsa_bwd.qkv"); _chk(o, "mhsa_bwd.o", qkv.dtype); _chk(d_o, "mhsa_bwd.d_o", qkv.dtype)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    if drop is not None and float(drop[0]) < 1.0:
+        _lib.check(_lib.load().devias_mhsa_bwd_dropout(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(),
+                                                       B, N, H, scale, dt_code(qkv.dtype), float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, _stream()),
+                   "devias_mhsa_bwd_dropout")
+        return dqkv
     _lib.check(_lib.load().devias_mhsa_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
                                            dqkv.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), None, _stream()), "devias_mhsa_bwd")
     return dqkv

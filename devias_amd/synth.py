@@ -148,3 +148,17 @@ def scene_video(batch: int, frames: int, size: int, seed: int = 2000, first: int
                 v = np.minimum(v, 255).astype(np.float32) / np.float32(256.0)
                 out[b, c, t] = (v - np.float32(IMAGENET_MEAN[c])) / np.float32(IMAGENET_STD[c])
     return torch.from_numpy(out)
+
+
+def dropout_mask(kind: str, block: int, shape, keep: float, seed: int = 3000) -> torch.Tensor:
+    """fp32 mask of 0 / (1 / keep) for an nn.Dropout / drop_path call of the encoder, as a formula (kept where u < keep): what the golden generator
+    hands the reference's dropout modules and the tests hand the oracle and the HIP model.  kind: 'pos' | 'proj' | 'mlp' | 'path1' | 'path2'."""
+    n = int(np.prod(shape))
+    u = uniform24(seed, f"drop.{kind}.{block}", n)
+    inv = np.float32(1.0) / np.float32(keep)
+    return _t(np.where(u < keep, inv, np.float32(0)).astype(np.float32), tuple(shape))
+
+
+def attn_drop_seed(block: int, seed: int = 3000) -> int:
+    """64-bit seed of block `block`'s attention-matrix dropout mask (devias_mhsa_fwd_dropout)"""
+    return int(hash_u64(seed, f"drop.attn.{block}", 1)[0])

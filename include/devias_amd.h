@@ -212,6 +212,16 @@ int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, 
 int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                     int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* ws, void* stream);
 int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H);
+/* The same with nn.Dropout(attn_drop) on the softmax matrix (Attention.attn_drop, modeling_slot.py:90,110), ABI 161.  The matrix never exists, so neither
+ * does its mask: element (b, h, query i, key j) is KEPT when  mix(rowkey + j * 0xC2B2AE35) < floor(keep * 2^32)  with
+ *   rowkey = mix(mix(seed_lo ^ ((b * H + h) * 0x9E3779B1)) + seed_hi + i * 0x85EBCA6B),   mix(x): x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16
+ * (32-bit wrapping arithmetic; seed_lo / seed_hi = the halves of `seed`), and kept elements are scaled by 1 / keep.  Forward and backward of one call pair
+ * must be given the same (keep, seed); lse is of the un-dropped probabilities.  keep = 1 is devias_mhsa_fwd / _bwd.  (The reference draws its mask from
+ * torch's generator; this one is a function of the seed so that the backward can re-create it -- oracle/ref_cpu.py attn_drop_mask restates it in numpy.) */
+int devias_mhsa_fwd_dropout(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
+                            int32_t dtype, float keep, uint64_t seed, void* stream);
+int devias_mhsa_bwd_dropout(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                            int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Slot cross-attention core (agg_block/attention.py:128-140): heads h, head dim dh (4 x 512 in DEVIAS),

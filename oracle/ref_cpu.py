@@ -131,8 +131,39 @@ def patch_embed(P, cfg: SlotViTConfig, x: torch.Tensor) -> torch.Tensor:
     return a @ w.t() + P["patch_embed.proj.bias"]
 
 
-def encoder_block(P, cfg: SlotViTConfig, i: int, x: torch.Tensor) -> torch.Tensor:
-    """Block.forward model/modeling_slot.py:142-152 with Attention.forward :92-117 and Mlp :60-67."""
+def _mix32(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64)
+    M = np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & M
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & M
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def attn_drop_mask(keep: float, seed: int, B: int, H: int, N: int) -> torch.Tensor:
+    """The mask devias_mhsa_fwd_dropout / _bwd_dropout apply to the softmax matrix (include/devias_amd.h, csrc/attention.hip drop_rowkey / drop_scale),
+    restated in numpy: [B, H, N, N] fp32 of 0 or 1 / keep.  It stands in for nn.Dropout(attn_drop)'s mask (model/modeling_slot.py:90,110), which the
+    reference draws from torch's generator: tests/golden/make_goldens.py hands THIS mask to the reference's F.dropout call."""
+    M = np.uint64(0xFFFFFFFF)
+    keep32 = np.float32(keep)
+    t = np.floor(np.float64(keep32) * 4294967296.0)
+    thresh = np.uint64(4294967295 if t >= 4294967295.0 else int(t))
+    s0, s1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    bh = np.arange(B * H, dtype=np.uint64)
+    a = _mix32(s0 ^ ((bh * np.uint64(0x9E3779B1)) & M))                                        # [BH]
+    i = np.arange(N, dtype=np.uint64)
+    rowkey = _mix32((a[:, None] + s1 + ((i * np.uint64(0x85EBCA6B)) & M)[None, :]) & M)       # [BH, N]
+    u = _mix32((rowkey[:, :, None] + ((i * np.uint64(0xC2B2AE35)) & M)[None, None, :]) & M)    # [BH, N(query), N(key)]
+    inv = np.float32(1.0) / keep32
+    return torch.from_numpy(np.where(u < thresh, inv, np.float32(0)).astype(np.float32).reshape(B, H, N, N))
+
+
+def encoder_block(P, cfg: SlotViTConfig, i: int, x: torch.Tensor, drop: Optional[dict] = None) -> torch.Tensor:
+    """Block.forward model/modeling_slot.py:142-152 with Attention.forward :92-117 and Mlp :60-67.
+    `drop` (training with drop_rate / attn_drop_rate / drop_path > 0) makes the reference's random masks explicit, each already scaled by 1 / keep:
+    'attn' [B, H, N, N] (attn_drop :110), 'proj' [B, N, D] (proj_drop :114), 'mlp' [B, N, D] (Mlp.drop :66), 'path1' / 'path2' [B] (drop_path :150-151)."""
+    drop = drop or {}
+    bcast = lambda m: m.to(x.dtype).reshape(-1, 1, 1)   # noqa: E731
     p = f"blocks.{i}."
     B, N, D = x.shape
     H = cfg.num_heads
@@ -142,19 +173,34 @@ def encoder_block(P, cfg: SlotViTConfig, i: int, x: torch.Tensor) -> torch.Tenso
     qkv = F.linear(u, P[p + "attn.qkv.weight"], bias).reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * dh ** -0.5, qkv[1], qkv[2]
     attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    if drop.get("attn") is not None:
+        attn = attn * drop["attn"].to(attn.dtype)
     o = (attn @ v).transpose(1, 2).reshape(B, N, D)
-    x = x + F.linear(o, P[p + "attn.proj.weight"], P[p + "attn.proj.bias"])
+    y = F.linear(o, P[p + "attn.proj.weight"], P[p + "attn.proj.bias"])
+    if drop.get("proj") is not None:
+        y = y * drop["proj"].to(y.dtype)
+    if drop.get("path1") is not None:
+        y = y * bcast(drop["path1"])
+    x = x + y
     u2 = F.layer_norm(x, (D,), P[p + "norm2.weight"], P[p + "norm2.bias"], cfg.eps_encoder)
     h = F.gelu(F.linear(u2, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"]))
-    return x + F.linear(h, P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"])
+    y = F.linear(h, P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"])
+    if drop.get("mlp") is not None:
+        y = y * drop["mlp"].to(y.dtype)
+    if drop.get("path2") is not None:
+        y = y * bcast(drop["path2"])
+    return x + y
 
 
-def forward_features(P, cfg: SlotViTConfig, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-    """VisionTransformer.forward_features model/modeling_slot.py:350-377."""
+def forward_features(P, cfg: SlotViTConfig, x: torch.Tensor, taps: Optional[dict] = None, drops: Optional[dict] = None) -> torch.Tensor:
+    """VisionTransformer.forward_features model/modeling_slot.py:350-377.  `drops`: {'pos': [B, N, D] mask of pos_drop (:356), i: encoder_block's `drop` of block i}."""
+    drops = drops or {}
     x = patch_embed(P, cfg, x)
     x = x + sinusoid_table(cfg.num_patches, cfg.embed_dim).to(x.dtype)
+    if drops.get("pos") is not None:
+        x = x * drops["pos"].to(x.dtype)
     for i in range(cfg.depth):
-        x = encoder_block(P, cfg, i, x)
+        x = encoder_block(P, cfg, i, x, drops.get(i))
         if taps is not None:
             taps[f"block{i}"] = x
     D = cfg.embed_dim
@@ -197,9 +243,9 @@ def mask_predictor(P, cfg: SlotViTConfig, slots_flat: torch.Tensor) -> torch.Ten
     return torch.sigmoid(F.linear(m, P["mask_predictor.decoder.4.weight"], P["mask_predictor.decoder.4.bias"]))
 
 
-def student_forward(P, cfg: SlotViTConfig, x: torch.Tensor, taps: Optional[dict] = None):
-    """VisionTransformer.forward ('matching' branch) model/modeling_slot.py:379-410."""
-    feats = forward_features(P, cfg, x, taps)
+def student_forward(P, cfg: SlotViTConfig, x: torch.Tensor, taps: Optional[dict] = None, drops: Optional[dict] = None):
+    """VisionTransformer.forward ('matching' branch) model/modeling_slot.py:379-410.  `drops`: forward_features' masks (training with dropout)."""
+    feats = forward_features(P, cfg, x, taps, drops)
     slots, attn = agg_block(P, cfg, feats, taps)
     B, S, D = slots.shape
     slots_flat = slots.reshape(-1, D)
@@ -315,11 +361,11 @@ def teacher_forward(P, cfg: SlotViTConfig, x: torch.Tensor):
     return tok, F.linear(tok, P["head.weight"], P["head.bias"])
 
 
-def train_step(P, cfg: SlotViTConfig, x, target, teacher_scene_logit, fg_mask, **loss_kw):
+def train_step(P, cfg: SlotViTConfig, x, target, teacher_scene_logit, fg_mask, drops: Optional[dict] = None, **loss_kw):
     """train_class_batch engine/engine_for_slot.py:50-56 (teacher logits supplied) + backward.
-    Returns (total, logits, loss_dict, grads: name -> tensor, student_output)."""
+    Returns (total, logits, loss_dict, grads: name -> tensor, student_output).  `drops`: forward_features' dropout masks."""
     Pg = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
-    out = student_forward(Pg, cfg, x)
+    out = student_forward(Pg, cfg, x, None, drops)
     total, logits, ld, idx = train_loss(cfg, out, teacher_scene_logit, target, fg_mask, **loss_kw)
     total.backward()
     grads = {k: v.grad for k, v in Pg.items()}

@@ -34,6 +34,8 @@ REF = "/root/reference"
 
 from devias_amd import synth  # noqa: E402
 from oracle import ref_cpu  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_util import dropout_masks  # noqa: E402  (the masks a dropout golden is made with, shared with the tests that replay it)
 
 
 def install_reference():
@@ -77,14 +79,39 @@ CONFIGS = {
     "vits_t8": (dict(all_frames=8, embed_dim=384, num_heads=6), 2),
     "vitb_t8_s4_untied": (dict(all_frames=8, num_latents=4, agg_weights_tie=False, agg_depth=4), 2),
     "vitb_t8_mlphead": (dict(all_frames=8, head_type="mlp"), 2),          # MLPHead (modeling_slot.py:23-34, 307-313)
+    # nn.Dropout inside the encoder (pos_drop :280,356; attn_drop :90,110; proj_drop :92,114; Mlp.drop :58,66) + drop_path, training mode, with the
+    # masks of devias_amd.synth.dropout_mask / oracle attn_drop_mask handed to the reference's own modules
+    "vitb_t8_dropout": (dict(all_frames=8, _drop=dict(drop_rate=0.1, attn_drop_rate=0.1, drop_path_rate=0.1)), 2),
 }
 
 
-def build_reference_student(cfg: ref_cpu.SlotViTConfig, reg, ms, AggregationBlock):
+def install_masks(model, drops: dict):
+    """make the reference's dropout modules multiply by the GIVEN masks instead of drawing their own (instance-level forward overrides)"""
+    if "pos" in drops:
+        model.pos_drop.forward = lambda x, m=drops["pos"]: x * m.view_as(x)
+    for i, blk in enumerate(model.blocks):
+        d = drops[i]
+        if "attn" in d:
+            blk.attn.attn_drop.forward = lambda a, m=d["attn"]: a * m
+        if "proj" in d:
+            blk.attn.proj_drop.forward = lambda y, m=d["proj"]: y * m.view_as(y)
+            blk.mlp.drop.forward = lambda y, m=d["mlp"]: y * m.view_as(y)
+        if "path1" in d:
+            state = {"n": 0}
+
+            def dp(x, d=d, state=state):           # Block.forward calls self.drop_path twice: attention branch, then MLP branch (:150-151)
+                m = d["path1"] if state["n"] % 2 == 0 else d["path2"]
+                state["n"] += 1
+                return x * m.view(-1, 1, 1)
+            blk.drop_path.forward = dp
+
+
+def build_reference_student(cfg: ref_cpu.SlotViTConfig, reg, ms, AggregationBlock, rates=None):
     if cfg.embed_dim == 768:
+        rates = rates or dict(drop_rate=0., attn_drop_rate=0., drop_path_rate=0.)
         return reg["slot_vit_base_patch16_224"](
             num_classes=cfg.num_classes, all_frames=cfg.all_frames, tubelet_size=cfg.tubelet_size,
-            drop_path_rate=0., init_scale=1e-3, num_latents=cfg.num_latents, head_type=cfg.head_type,
+            drop_path_rate=rates["drop_path_rate"], drop_rate=rates["drop_rate"], attn_drop_rate=rates["attn_drop_rate"], init_scale=1e-3, num_latents=cfg.num_latents, head_type=cfg.head_type,
             slot_matching_method="matching", agg_weights_tie=cfg.agg_weights_tie, agg_depth=cfg.agg_depth,
             num_scene_classes=cfg.num_scene_classes)
 
@@ -149,10 +176,17 @@ def tap_summary(t: torch.Tensor) -> np.ndarray:
 def generate(name: str, ref):
     reg, ms, mf, AggregationBlock, TrainLoss = ref
     kw, B = CONFIGS[name]
+    kw = dict(kw)
+    rates = kw.pop("_drop", None)
     cfg = ref_cpu.SlotViTConfig(**kw)
     torch.manual_seed(0)
-    model = build_reference_student(cfg, reg, ms, AggregationBlock)
+    model = build_reference_student(cfg, reg, ms, AggregationBlock, rates)
     model.train()
+    drops = None
+    if rates is not None:
+        assert isinstance(model.pos_drop, nn.Dropout) and model.pos_drop.p == rates["drop_rate"] and model.blocks[0].attn.attn_drop.p == rates["attn_drop_rate"]
+        drops = dropout_masks(cfg, B, rates)
+        install_masks(model, drops)
     synth.fill_module_(model, seed=0)
     names = [n for n, _ in model.named_parameters()]
     shapes = ref_cpu.param_shapes(cfg)
@@ -187,7 +221,7 @@ def generate(name: str, ref):
     P = synth.fill_params(shapes, seed=0)
     otaps = {}
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    oout = ref_cpu.student_forward(Pg, cfg, x, otaps)
+    oout = ref_cpu.student_forward(Pg, cfg, x, otaps, drops)
     ototal, ologits, old, oidx = ref_cpu.train_loss(cfg, oout, tl, y, fg)
     ototal.backward()
     checks = {
@@ -217,7 +251,7 @@ def generate(name: str, ref):
     assert i_star == oidx[0].tolist()
 
     fx = {
-        "config": np.array(repr(kw)), "batch": np.array(B),
+        "config": np.array(repr(CONFIGS[name][0])), "batch": np.array(B),
         "slots_head": slots_head.detach().numpy(), "slots": slots.detach().numpy(),
         "mask_predictions": maskp.detach().numpy(), "attn": attn.detach().numpy(),
         "action_feat": af.detach().numpy(), "scene_feat": sf.detach().numpy(),

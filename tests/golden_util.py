@@ -10,13 +10,54 @@ from oracle import ref_cpu
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STUDENT_GOLDENS = ["vitb_t8", "vitb_t16", "vits_t8", "vitb_t8_s4_untied", "vitb_t8_mlphead"]
+DROPOUT_GOLDEN = "vitb_t8_dropout"          # training mode with drop_rate / attn_drop_rate / drop_path_rate = 0.1 and GIVEN masks (dropout_masks below)
 
 
 def load(name):
     fx = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
     kw = ast.literal_eval(str(fx["config"]))
+    rates = kw.pop("_drop", None)
     cfg = ref_cpu.SlotViTConfig(**kw)
+    if rates is not None:
+        fx["_rates"] = rates
     return fx, cfg, int(fx["batch"])
+
+
+def dropout_masks(cfg, B, rates):
+    """the `drops` argument of ref_cpu.student_forward for these rates: formula masks (devias_amd.synth.dropout_mask) for nn.Dropout's element masks and
+    drop_path's per-sample masks, and the attention kernels' mask hash (ref_cpu.attn_drop_mask) for attn_drop.  tests/golden/make_goldens.py installs the
+    same masks in the reference's own dropout modules."""
+    N, D, H = cfg.num_patches, cfg.embed_dim, cfg.num_heads
+    kd, ka = 1.0 - rates["drop_rate"], 1.0 - rates["attn_drop_rate"]
+    dpr = [x.item() for x in torch.linspace(0, rates["drop_path_rate"], cfg.depth)]
+    drops = {}
+    if rates["drop_rate"] > 0:
+        drops["pos"] = synth.dropout_mask("pos", -1, (B, N, D), kd)
+    for i in range(cfg.depth):
+        d = {}
+        if rates["drop_rate"] > 0:
+            d["proj"] = synth.dropout_mask("proj", i, (B, N, D), kd)
+            d["mlp"] = synth.dropout_mask("mlp", i, (B, N, D), kd)
+        if rates["attn_drop_rate"] > 0:
+            d["attn"] = ref_cpu.attn_drop_mask(ka, synth.attn_drop_seed(i), B, H, N)
+        if dpr[i] > 0:
+            d["path1"] = synth.dropout_mask("path1", i, (B,), 1.0 - dpr[i])
+            d["path2"] = synth.dropout_mask("path2", i, (B,), 1.0 - dpr[i])
+        drops[i] = d
+    return drops
+
+
+class FormulaDropoutSource:
+    """devias_amd.modeling_slot.DropoutSource with the formula masks of dropout_masks(): the HIP model then uses the masks the golden's reference run used"""
+
+    def element_mask(self, kind, block, shape, keep, device):
+        return synth.dropout_mask(kind, block, shape, keep).to(device).contiguous()
+
+    def path_scale(self, block, B, keep, device):
+        return torch.stack([synth.dropout_mask("path1", block, (B,), keep), synth.dropout_mask("path2", block, (B,), keep)]).to(device).contiguous()
+
+    def attn_seed(self, block):
+        return synth.attn_drop_seed(block)
 
 
 def inputs(cfg, B, seed=1000):

@@ -205,6 +205,43 @@ def test_mhsa_fwd_bwd(dtype, B, N, H):
         assert rel(mine[:, :, w], g[:, :, w]) < (2e-4 if dtype == torch.float32 else 3e-2), name
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,H,keep", [(2, 100, 3, 0.9), (1, 784, 2, 0.75), (1, 333, 1, 0.5), (2, 200, 6, 0.9)])
+def test_mhsa_dropout_matches_the_reference_with_the_same_mask(dtype, B, N, H, keep):
+    """nn.Dropout(attn_drop) on the softmax matrix (model/modeling_slot.py:90,110): the kernels' mask is a hash of (seed, b, h, i, j); the oracle's
+    numpy restatement of that hash gives plain PyTorch the SAME mask, forward and backward (ragged N: last key / query tiles partly empty).  Row sums
+    (lse) are of the un-dropped probabilities."""
+    from oracle import ref_cpu
+    o = ops()
+    scale = 64 ** -0.5
+    seed = 0x5DEECE66D1234567 + N
+    qkv = rnd(B * N, 3 * H * 64, dtype=dtype, seed=32)
+    out, lse = o.mhsa_fwd(qkv, B, N, H, scale, drop=(keep, seed))
+    mask = ref_cpu.attn_drop_mask(keep, seed, B, H, N).cuda()
+    assert abs(float((mask > 0).float().mean()) - keep) < 0.02
+    x = qkv.float().clone().requires_grad_(True)
+    q, k, v = x.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s_ = (q * scale) @ k.transpose(-1, -2)
+    ro = ((s_.softmax(-1) * mask) @ v).transpose(1, 2).reshape(B * N, H * 64)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel(out.float(), ro) < tol
+    assert rel(lse, torch.logsumexp(s_, -1)) < (1e-5 if dtype == torch.float32 else 1e-2)
+    plain, _ = o.mhsa_fwd(qkv, B, N, H, scale)
+    assert rel(out.float(), plain.float()) > 0.05                      # it is not the un-dropped product
+    d_o = rnd(B * N, H * 64, dtype=dtype, seed=33)
+    ro.backward(d_o.float())
+    dqkv = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale, drop=(keep, seed))
+    g = x.grad.reshape(B, N, 3, H, 64)
+    mine = dqkv.float().reshape(B, N, 3, H, 64)
+    for w, name in enumerate("qkv"):
+        assert rel(mine[:, :, w], g[:, :, w]) < (2e-4 if dtype == torch.float32 else 3e-2), name
+    # run-to-run: the mask is a function of the seed, nothing is drawn
+    out2, _ = o.mhsa_fwd(qkv, B, N, H, scale, drop=(keep, seed))
+    assert torch.equal(out, out2)
+    out3, _ = o.mhsa_fwd(qkv, B, N, H, scale, drop=(keep, seed + 1))
+    assert not torch.equal(out, out3)
+
+
 def test_mhsa_bf16_online_softmax_rescale():
     """force the running max to jump late in the key sequence (the rare rescale path of the online softmax)"""
     o = ops()

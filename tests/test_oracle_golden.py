@@ -8,6 +8,9 @@ from oracle import ref_cpu
 
 import golden_util as gu
 
+KNOWN_ATTN_MASK_SEED7 = [[0, 1, 0, 1, 0, 1, 1, 0], [1, 1, 0, 0, 1, 0, 0, 0], [0, 1, 0, 1, 0, 1, 1, 0], [1, 0, 1, 0, 0, 0, 1, 1],
+                         [0, 0, 0, 1, 0, 0, 0, 0], [0, 0, 1, 1, 1, 1, 0, 1], [1, 0, 1, 0, 0, 1, 0, 1], [0, 0, 1, 0, 1, 0, 0, 1]]      # keep 0.5, seed 7, B = H = 1, N = 8
+
 
 @pytest.mark.parametrize("name", gu.STUDENT_GOLDENS)
 def test_oracle_matches_reference_golden(name):
@@ -17,6 +20,34 @@ def test_oracle_matches_reference_golden(name):
     assert list(P.keys()) == [str(n) for n in fx["param_names"]]
     total, logits, ld, grads, out, idx = ref_cpu.train_step(P, cfg, x, y, tl, fg)
     gu.check_against_golden(fx, out, total, logits, ld, grads, tol_out=5e-5, tol_grad=1e-3, idx=idx)
+
+
+def test_oracle_matches_reference_golden_with_dropout():
+    """training mode with drop_rate = attn_drop_rate = drop_path_rate = 0.1: the fixture is the REAL reference run with its nn.Dropout / DropPath modules
+    multiplying by given masks (tests/golden/make_goldens.py install_masks); the oracle gets the same masks (golden_util.dropout_masks) -- including the
+    attention-matrix mask, which is the numpy restatement of the HIP kernels' hash (ref_cpu.attn_drop_mask)"""
+    fx, cfg, B = gu.load(gu.DROPOUT_GOLDEN)
+    x, y, tl, fg = gu.inputs(cfg, B)
+    P = synth.fill_params(ref_cpu.param_shapes(cfg), seed=0)
+    drops = gu.dropout_masks(cfg, B, fx["_rates"])
+    total, logits, ld, grads, out, idx = ref_cpu.train_step(P, cfg, x, y, tl, fg, drops=drops)
+    gu.check_against_golden(fx, out, total, logits, ld, grads, tol_out=5e-5, tol_grad=1e-3, idx=idx)
+    plain, _cfg, _ = gu.load("vitb_t8")
+    assert abs(float(fx["total_loss"]) - float(plain["total_loss"])) > 1e-3 * abs(float(plain["total_loss"]))      # it is not the un-dropped step
+
+
+def test_attn_drop_mask_statistics_and_known_values():
+    """the kernels' attention-mask hash, restated in numpy: keep fraction, independence across seeds / heads, and pinned values (a change of the hash
+    in csrc/attention.hip without the oracle -- or the reverse -- fails the GPU tests; a change of both fails here)"""
+    m = ref_cpu.attn_drop_mask(0.9, 0x0123456789ABCDEF, 2, 3, 128)
+    assert m.shape == (2, 3, 128, 128) and abs(float((m > 0).float().mean()) - 0.9) < 0.01
+    assert float(m.max()) == float(np.float32(1) / np.float32(0.9))
+    m2 = ref_cpu.attn_drop_mask(0.9, 0x0123456789ABCDEF + 1, 2, 3, 128)
+    agree = float(((m > 0) == (m2 > 0)).float().mean())
+    assert abs(agree - 0.82) < 0.02                                   # independent masks agree with probability 0.81 + 0.01
+    assert abs(float(((m[0, 0] > 0) == (m[1, 2] > 0)).float().mean()) - 0.82) < 0.03
+    k = (ref_cpu.attn_drop_mask(0.5, 7, 1, 1, 8)[0, 0] > 0).int().numpy()
+    assert k.tolist() == KNOWN_ATTN_MASK_SEED7, k.tolist()
 
 
 def test_oracle_teacher_matches_reference_golden():

@@ -15,10 +15,10 @@ pytestmark = pytest.mark.gpu
 TOL_FP32 = 1e-3          # north_star: per-slot logits and total loss within 1e-3 relative (fp32)
 
 
-def build(cfg, dtype):
+def build(cfg, dtype, rates=None):
     from devias_amd.modeling_slot import VisionTransformer
     from functools import partial
-    m = VisionTransformer(patch_size=16, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4,
+    m = VisionTransformer(patch_size=16, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4, **(rates or {}),
                           qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_classes=cfg.num_classes,
                           all_frames=cfg.all_frames, tubelet_size=cfg.tubelet_size, init_scale=1e-3,
                           num_latents=cfg.num_latents, head_type=cfg.head_type, slot_matching_method="matching",
@@ -51,6 +51,55 @@ def test_fp32_step_matches_reference_golden(name):
     errs, gerrs = gu.check_against_golden(fx, out, float(total), logits, ld, grads, tol_out=TOL_FP32, tol_grad=5e-3, idx=idx)
     print(name, "max output err", max(errs.values()), "max grad err", max(gerrs.values()))
     # intermediate taps are not exposed by the fused path; outputs + 186 gradient norms pin every parameter's path
+
+
+@pytest.mark.parametrize("dtype,tol_out,tol_grad", [("fp32", TOL_FP32, 5e-3), ("bf16", 5e-2, None)])
+def test_dropout_step_matches_reference_golden(dtype, tol_out, tol_grad):
+    """nn.Dropout inside the encoder (pos_drop, attn_drop, proj_drop, Mlp.drop: model/modeling_slot.py:280,356 / 90,110 / 92,114 / 58,66) + drop_path,
+    training mode, rates 0.1: the golden is the REAL reference run with its dropout modules multiplying by given masks; the HIP model draws the same masks
+    through its DropoutSource (element masks: devias_amd.synth formulae; attention-matrix mask: the kernels' hash of the same seeds).  fp32: the north_star
+    gate on outputs, loss and every gradient; bf16: bounded."""
+    fx, cfg, B = gu.load(gu.DROPOUT_GOLDEN)
+    model = build(cfg, dtype, fx["_rates"])
+    model.dropout_source = gu.FormulaDropoutSource()
+    from devias_amd import ops
+    ops.counters(reset=True)
+    out, total, logits, ld, grads, match = run_step(model, cfg, B)
+    cnt = ops.counters()
+    assert cnt["mhsa_fwd_" + ("f32" if dtype == "fp32" else "bf16")] == cfg.depth            # every block's attention ran in the library
+    if dtype == "fp32":
+        idx = (match[:, 0].cpu().tolist(), match[:, 1].cpu().tolist())
+        errs, gerrs = gu.check_against_golden(fx, out, float(total.detach()), logits, ld, grads, tol_out=tol_out, tol_grad=tol_grad, idx=idx)
+        print("dropout golden fp32: max output err", max(errs.values()), "max grad err", max(gerrs.values()))
+    else:
+        e_logit = gu.rel(out[2][0].detach().float().cpu(), fx["slots_head"])
+        e_total = abs(float(total) - float(fx["total_loss"])) / abs(float(fx["total_loss"]))
+        names = [str(n) for n in fx["param_names"]]
+        gn = np.array([float(grads[n].double().norm()) for n in names])
+        e_gn = np.abs(gn - fx["grad_norms"]) / np.maximum(fx["grad_norms"], 1e-6 * fx["grad_norms"].max())
+        print(f"dropout golden bf16: logits rel {e_logit:.3e}, total loss rel {e_total:.3e}, grad-norm rel median {np.median(e_gn):.3e}")
+        assert e_logit < tol_out and e_total < 2e-2 and np.median(e_gn) < 5e-2
+    # eval mode draws nothing and is the un-dropped model
+    model.eval()
+    x, _, _, _ = gu.inputs(cfg, B)
+    with torch.no_grad():
+        a = model(x.cuda())[2][0]
+        b = model(x.cuda())[2][0]
+    assert torch.equal(a, b)
+
+
+def test_dropout_default_source_draws_from_torch_generators():
+    """without an installed source the masks come from torch's generators (as nn.Dropout's do): reproducible under torch.manual_seed, different across
+    draws; rates reach the modules as in the reference (modeling_slot.py:280-289)"""
+    fx, cfg, B = gu.load("vits_t8")
+    model = build(cfg, "fp32", dict(drop_rate=0.2, attn_drop_rate=0.3))
+    assert model.pos_drop.p == 0.2 and model.blocks[0].attn.attn_drop.p == 0.3 and model.blocks[0].attn.proj_drop.p == 0.2 and model.blocks[0].mlp.drop.p == 0.2
+    x, _, _, _ = gu.inputs(cfg, B)
+    x = x.cuda()
+    torch.manual_seed(5); a = model(x)[2][0].detach().clone()
+    b = model(x)[2][0].detach().clone()
+    torch.manual_seed(5); c = model(x)[2][0].detach().clone()
+    assert torch.equal(a, c) and not torch.equal(a, b)
 
 
 def test_fp32_forward_is_deterministic():

@@ -66,8 +66,8 @@ def test_fc_dropout_module_switch():
     m.train(); torch.manual_seed(0); c = m(x); d = m(x)
     assert not torch.equal(c[2][0], d[2][0])                  # slots_head differs between two draws ...
     assert torch.equal(c[2][1], d[2][1]) and torch.equal(c[2][2], d[2][2])      # ... slots and mask predictions do not (un-dropped, :408)
-    with pytest.raises(NotImplementedError):
-        VisionTransformer(embed_dim=384, num_heads=6, depth=1, drop_rate=0.1)
+    with pytest.raises(ValueError):
+        VisionTransformer(embed_dim=384, num_heads=6, depth=1, drop_rate=1.0)
 
 
 @pytest.mark.parametrize("dtype,tol_out,tol_grad", [("fp32", 1e-3, 5e-3), ("bf16", 3e-2, None)])
