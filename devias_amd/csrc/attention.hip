@@ -34,6 +34,20 @@ __device__ __forceinline__ int img_tr_off(int row, int col) {
     return row * 128 + ((((col >> 4) ^ ((row >> 1) & 3))) << 5) + (col & 15) * 2;
 }
 
+// The 32x32x16 forward kernel reads V^T with 32 lanes on rows 4 hi .. + 4 of TWO adjacent windows (16 lanes each) per ds_read_b64_tr_b16 where the 16x16x32
+// kernels read rows 0..7 of ONE window: under img_tr_off's swizzle rows r and r + 2 then meet in the same banks (window w of row r + 2 sits where window
+// w ^ 1 of row r does) -- SQ_LDS_BANK_CONFLICT = half of the kernel's LDS cycles (profiles/r4_lds_conflicts.txt).  This swizzle moves rows r, r + 2 two
+// windows apart and r, r + 4 one: the eight (row, window) pairs of a 32-lane group cover all 64 banks.
+// ... and its K row image: a ds_read_b128 serves lanes i and i + 16 in the same cycle (the 16x16x32 kernels' fragments put the SAME row's next chunk there;
+// here lane i + 16 holds row i + 16 with the same chunk, i.e. the same banks under `chunk ^ (row & 7)`): rows 16..31 of a 32-key block take the odd
+// permutation.  Measured per launch at B = 32, N = 1568, H = 12: SQ_LDS_BANK_CONFLICT 3.01e7 -> 1.51e7 (V image) -> 0 (K image), SQ_LDS_IDX_ACTIVE 6.2e7 -> 3.2e7.
+__device__ __forceinline__ int row_swz2(int row) { return (row & 7) ^ ((row >> 4) & 1); }
+__device__ __forceinline__ int img_row_off2(int row, int chunk) { return row * 128 + ((chunk ^ row_swz2(row)) << 4); }
+__device__ __forceinline__ int tr_swz2(int row) { return (((row >> 1) & 1) << 1) | ((row >> 2) & 1); }
+__device__ __forceinline__ int img_tr_off2(int row, int col) {
+    return row * 128 + ((((col >> 4) ^ tr_swz2(row))) << 5) + (col & 15) * 2;
+}
+
 // fragment of the row image: lane holds tile[row = base + (lane&15)][32*ks + 8*(lane>>4) .. +8]
 __device__ __forceinline__ bf16x8 frag_rows(const char* img, int base, int ks, int lane) {
     int row = base + (lane & 15);
@@ -145,7 +159,9 @@ __device__ __forceinline__ void dma_tile(const bf16* __restrict__ base, int64_t 
 // vector arithmetic per tile (the per-lane 64-bit source pointers of dma_tile cost 12-15 vector instructions per wave-instruction, and these
 // kernels are bound by their vector instruction count: rocprofv3 PMC, profiles/r3_attn_pmc.txt).  Rows past `nrows` are not clamped: they belong
 // to the next batch entry (finite) or lie beyond the tensor (read as zero); every consumer zeroes their probabilities.
-template <int NW, bool TR>
+// TR: 0 = row image, 1 = transposed-read image, 2 = transposed-read image with the window swizzle of img_tr_off2 (forward kernel's V),
+// 3 = row image with the chunk swizzle of img_row_off2 (forward kernel's K)
+template <int NW, int TR>
 struct TileDma {
     __amdgpu_buffer_rsrc_t rs;
     uint32_t vo[8 / NW];
@@ -157,7 +173,8 @@ struct TileDma {
 #pragma unroll
         for (int i = 0; i < 8 / NW; ++i) {
             const int row = (wave * (8 / NW) + i) * 8 + (lane >> 3), slot = lane & 7;
-            const int chunk = TR ? ((((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1)) : (slot ^ (row & 7));
+            const int wswz = TR == 2 ? tr_swz2(row) : ((row >> 1) & 3);
+            const int chunk = TR == 0 ? (slot ^ (row & 7)) : TR == 3 ? (slot ^ row_swz2(row)) : ((((slot >> 1) ^ wswz) << 1) | (slot & 1));
             vo[i] = (uint32_t)((row * (int)row_stride + chunk * 8) * 2);
         }
     }
@@ -210,8 +227,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void mhsa_fwd_bf16_kernel(const bf16*
 
     const int nkv = (N + 63) / 64;
     TileRegs<NW * 64> rk, rv;
-    TileDma<NW, false> dK;
-    TileDma<NW, true> dV;
+    TileDma<NW, 0> dK;
+    TileDma<NW, 1> dV;
     if constexpr (DMA) {
         const int64_t left = ((int64_t)(xcd >> 16) - b) * N * RS - h * 64;      // elements from `base` to the end of qkv
         dK.init(base + D, RS, left - D, wave, lane);
@@ -401,16 +418,16 @@ __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16*
     // loop-invariant LDS byte offsets: K row fragments (per 16-deep step ks; second key block = + 4096), V^T fragments (per 32-d block, + 2048 per 16 keys)
     int ko[4], vo_[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) ko[ks] = img_row_off(r32, 2 * ks + hi);
+    for (int ks = 0; ks < 4; ++ks) ko[ks] = img_row_off2(r32, 2 * ks + hi);
     {
         const int dsub = (lane >> 4) & 1, c = lane & 15;
 #pragma unroll
-        for (int db = 0; db < 2; ++db) vo_[db] = img_tr_off(4 * hi + (c >> 2), 32 * db + 16 * dsub + 4 * (c & 3));
+        for (int db = 0; db < 2; ++db) vo_[db] = img_tr_off2(4 * hi + (c >> 2), 32 * db + 16 * dsub + 4 * (c & 3));
     }
 
     const int nkv = (N + 63) / 64;
-    TileDma<NW, false> dK;
-    TileDma<NW, true> dV;
+    TileDma<NW, 3> dK;
+    TileDma<NW, 2> dV;
     {
         const int64_t left = ((int64_t)(xcd >> 16) - b) * N * RS - h * 64;
         dK.init(base + D, RS, left - D, wave, lane);
@@ -591,8 +608,8 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 
     const int nkv = (N + 63) / 64;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    TileDma<NW, true> dK;
-    TileDma<NW, false> dV;
+    TileDma<NW, 1> dK;
+    TileDma<NW, 0> dV;
     {
         const int64_t left = ((int64_t)(xcd >> 16) - b) * N * RS - h * 64;      // elements from `base` to the end of qkv
         dK.init(base + D, RS, left - D, wv, lane);
@@ -731,7 +748,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
         return r0 + tid - 64 < N ? dl_bh[r0 + tid - 64] : 0.f;
     };
     float rstat = 0.f;
-    TileDma<4, true> dQ_, dO_;
+    TileDma<4, 1> dQ_, dO_;
     dQ_.init(base, RS, ((int64_t)(xcd >> 16) - b) * N * RS - h * 64, wv, lane);
     dO_.init(dobase, D, ((int64_t)(xcd >> 16) - b) * N * D - h * 64, wv, lane);
     dQ_.issue(0, smem, wv);
