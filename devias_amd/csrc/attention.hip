@@ -630,57 +630,62 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
             dV.issue((t + 1) * 64, nxt + 8192, wv);
         }
         if (q0 < N) {                         // (waves without a valid query only stage and synchronise: see the forward kernel)
-        f32x4 acc_s[4][QT], acc_dp[4][QT];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < QT; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                bf16x8 kf = frag_rows_tr(imgKt, 16 * kt, ks, lane);
-                bf16x8 vf = frag_rows(imgV, 16 * kt, ks, lane);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    acc_s[kt][qt] = mfma(kf, qf[qt][ks], acc_s[kt][qt]);
-                    acc_dp[kt][qt] = mfma(vf, dof[qt][ks], acc_dp[kt][qt]);
-                }
-            }
+        // The 64-key tile in two halves of 32 keys (16-key tiles kt = 2s, 2s + 1), each run to completion -- S^T and dP^T (8 QT MFMAs), the softmax arithmetic,
+        // dQ^T += K^T dS^T (4 QT MFMAs) -- so that only HALF a tile of scores and dP is ever live: 32 registers fewer than the whole-tile form, which is what
+        // takes the kernel from 194 to 162 registers = three waves per SIMD instead of two: -6.5 % on the kernel, -0.32 ms on the step.  Same MFMAs on the same operands in the same accumulation order:
+        // bitwise equal to the whole-tile form.
         const int k0 = t * 64;
-        if (k0 + 64 > N) {                    // ragged last tile only: p = exp2(-inf) = 0 for keys >= N
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (k0 + 16 * kt + 4 * g + r >= N) {
-#pragma unroll
-                        for (int qt = 0; qt < QT; ++qt) acc_s[kt][qt][r] = -INFINITY;
-                    }
-        }
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const f32x2 sl2v = {sl2, sl2}, nl = {-lse2[qt], -lse2[qt]}, dlv = {dl[qt], dl[qt]};   // packed fp32: two scores per VALU op
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const f32x2 e = f32x2{acc_s[kt][qt][r], acc_s[kt][qt][r + 1]} * sl2v + nl;
-                    const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
-                    f32x2 dp = {acc_dp[kt][qt][r], acc_dp[kt][qt][r + 1]};
-                    if constexpr (DROP) {                              // dP_ij = mask_ij (dO_i . V_j)
-                        const uint32_t key = (uint32_t)(k0 + 16 * kt + 4 * g + r);
-                        dp = dp * f32x2{drop_scale(drop, rowkey[qt], key), drop_scale(drop, rowkey[qt], key + 1)};
-                    }
-                    const f32x2 ds = p * (dp - dlv);                   // dS^T / scale (scale applied once at the end)
-                    acc_s[kt][qt][r] = ds[0]; acc_s[kt][qt][r + 1] = ds[1];
-                }
-        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            f32x4 acc_s[2][QT], acc_dp[2][QT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < QT; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int kt = 2 * s + h2;
+                    bf16x8 kf = frag_rows_tr(imgKt, 16 * kt, ks, lane);
+                    bf16x8 vf = frag_rows(imgV, 16 * kt, ks, lane);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        acc_s[h2][qt] = mfma(kf, qf[qt][ks], acc_s[h2][qt]);
+                        acc_dp[h2][qt] = mfma(vf, dof[qt][ks], acc_dp[h2][qt]);
+                    }
+                }
+            if (k0 + 64 > N) {                // ragged last tile only: p = exp2(-inf) = 0 for keys >= N
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + 16 * (2 * s + h2) + 4 * g + r >= N) {
+#pragma unroll
+                            for (int qt = 0; qt < QT; ++qt) acc_s[h2][qt][r] = -INFINITY;
+                        }
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const f32x2 sl2v = {sl2, sl2}, nl = {-lse2[qt], -lse2[qt]}, dlv = {dl[qt], dl[qt]};   // packed fp32: two scores per VALU op
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 e = f32x2{acc_s[h2][qt][r], acc_s[h2][qt][r + 1]} * sl2v + nl;
+                        const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
+                        f32x2 dp = {acc_dp[h2][qt][r], acc_dp[h2][qt][r + 1]};
+                        if constexpr (DROP) {                          // dP_ij = mask_ij (dO_i . V_j)
+                            const uint32_t key = (uint32_t)(k0 + 16 * (2 * s + h2) + 4 * g + r);
+                            dp = dp * f32x2{drop_scale(drop, rowkey[qt], key), drop_scale(drop, rowkey[qt], key + 1)};
+                        }
+                        const f32x2 ds = p * (dp - dlv);               // dS^T / scale (scale applied once at the end)
+                        acc_s[h2][qt][r] = ds[0]; acc_s[h2][qt][r + 1] = ds[1];
+                    }
+            }
             bf16x8 dsf[QT];
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) dsf[qt] = pack8(acc_s[2 * s][qt], acc_s[2 * s + 1][qt]);
+            for (int qt = 0; qt < QT; ++qt) dsf[qt] = pack8(acc_s[0][qt], acc_s[1][qt]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 bf16x8 kf = frag_tr(imgKt, 16 * dt, s, lane);
@@ -702,7 +707,10 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 }
 
 // ======================================= backward dK, dV (bf16) ==========================================
-template <bool DROP = false>
+// KT = 16-key tiles per wave.  2 = 32 keys per wave, 128 per workgroup, 252 registers, two waves per SIMD: the shipped form.  1 (16 / 64 keys: 114 registers, four
+// waves per SIMD) was measured and is not instantiated: the step is 0.38 ms SLOWER -- every wave still streams the whole Q / dO tile through LDS for half the
+// keys (profiles/r4_attn_occupancy.txt)
+template <bool DROP = false, int KT = 2>
 __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
                                                                  bf16* __restrict__ dqkv, int N, int H, float scale, int xcd, DropP drop = DropP{}) {
@@ -713,18 +721,18 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
     const float* s_lse = s_stat;
     const float* s_dl = s_stat + 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-    const HeadMap hm = head_map((N + 127) / 128, H, xcd >> 16, (xcd & 1) != 0);
+    const HeadMap hm = head_map((N + 64 * KT - 1) / (64 * KT), H, xcd >> 16, (xcd & 1) != 0);
     const int h = hm.h, b = hm.b;
     const int D = H * 64;
     const int64_t RS = 3 * (int64_t)D;
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
     const bf16* dobase = d_o + (int64_t)b * N * D + h * 64;
-    const int key0 = hm.blk * 128 + wave * 32;
+    const int key0 = hm.blk * (64 * KT) + wave * (16 * KT);
     const float sl2 = scale * LOG2E;
 
-    bf16x8 kreg[2][2], vreg[2][2];
+    bf16x8 kreg[KT][2], vreg[KT][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < KT; ++kt) {
         int key = min(key0 + 16 * kt + c, N - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -732,11 +740,11 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             vreg[kt][ks] = *reinterpret_cast<const bf16x8*>(base + 2 * D + (int64_t)key * RS + 32 * ks + 8 * g);
         }
     }
-    f32x4 acc_dk[4][2], acc_dv[4][2];
+    f32x4 acc_dk[4][KT], acc_dv[4][KT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { acc_dk[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < KT; ++j) { acc_dk[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const int nq = (N + 63) / 64;
     const float* lse_bh = lse + ((int64_t)b * H + h) * N;
@@ -777,11 +785,11 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
         }
         if (key0 < N) {                       // (waves without a valid key only stage and synchronise: see the forward kernel)
         // S and dP tiles: acc[qt][kt] holds queries 16qt + 4g + r (rows) x key c (col)
-        f32x4 acc_s[4][2], acc_dp[4][2];
+        f32x4 acc_s[4][KT], acc_dp[4][KT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int j = 0; j < KT; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
                 bf16x8 qfr = frag_rows_tr(imgQt, 16 * qt, ks, lane);
                 bf16x8 dofr = frag_rows_tr(imgOt, 16 * qt, ks, lane);
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
+                for (int kt = 0; kt < KT; ++kt) {
                     acc_s[qt][kt] = mfma(qfr, kreg[kt][ks], acc_s[qt][kt]);
                     acc_dp[qt][kt] = mfma(dofr, vreg[kt][ks], acc_dp[qt][kt]);
                 }
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_dl + 16 * qt + 4 * g);
             const f32x2 sl2v = {sl2, sl2};
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {                                    // packed fp32: two scores per VALU op
                     const f32x2 e = f32x2{acc_s[qt][kt][r], acc_s[qt][kt][r + 1]} * sl2v - f32x2{l4[r], l4[r + 1]};
@@ -819,9 +827,9 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 pf[2], dsf[2];
+            bf16x8 pf[KT], dsf[KT];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
+            for (int kt = 0; kt < KT; ++kt) {
                 pf[kt] = pack8(acc_s[2 * s][kt], acc_s[2 * s + 1][kt]);
                 dsf[kt] = pack8(acc_dp[2 * s][kt], acc_dp[2 * s + 1][kt]);
             }
@@ -830,7 +838,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
                 bf16x8 dot = frag_tr(imgOt, 16 * dt, s, lane);
                 bf16x8 qt_ = frag_tr(imgQt, 16 * dt, s, lane);
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
+                for (int kt = 0; kt < KT; ++kt) {
                     acc_dv[dt][kt] = mfma(dot, pf[kt], acc_dv[dt][kt]);
                     acc_dk[dt][kt] = mfma(qt_, dsf[kt], acc_dk[dt][kt]);
                 }
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
         }
     }
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < KT; ++kt) {
         const int key = key0 + 16 * kt + c;
         if (key < N) {
             bf16* row = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 4 * g;
