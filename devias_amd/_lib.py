@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DEVIAS_LIB_PATH") or os.path.join(_HERE, "libdevias_amd.so")     # (override: ablation builds of tools/)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 161                # devias_version() of the library these prototypes describe
+ABI_VERSION = 162                # devias_version() of the library these prototypes describe
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4, 5
 
 
@@ -123,6 +123,8 @@ PROTOTYPES = {
     "devias_mhsa_bwd_workspace_bytes": (c_int64, [_I, _I, _I]),
     "devias_mhsa_fwd_dropout": (c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _F, ctypes.c_uint64, _P]),
     "devias_mhsa_bwd_dropout": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, ctypes.c_uint64, _P]),
+    "devias_mhsa_bwd_bias": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, ctypes.c_uint64, _P, _P, _P, _P, _P]),
+    "devias_mhsa_bwd_bias_workspace_bytes": (c_int64, [_I, _I, _I]),
     "devias_slot_attn_fwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "devias_slot_attn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "devias_slot_attn_kv_grad": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),

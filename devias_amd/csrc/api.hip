@@ -12,7 +12,7 @@ int devias_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int devias_version(void) { return 161; }   // 161: devias_mhsa_fwd_dropout / _bwd_dropout (additive); 160: devias_loss_dims.scene_ce (struct grew); 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options, 140: stream-K GEMM (args struct grew), 150: fused regions, roctx ranges
+extern "C" int devias_version(void) { return 162; }   // 162: devias_mhsa_bwd_bias (additive); 161: devias_mhsa_fwd_dropout / _bwd_dropout (additive); 160: devias_loss_dims.scene_ce (struct grew); 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options, 140: stream-K GEMM (args struct grew), 150: fused regions, roctx ranges
 
 // ---- launch counters: which kernel family served a call (tests assert that the measured kernels are the ones under test) ----
 #include <atomic>

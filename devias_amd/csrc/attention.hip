@@ -558,12 +558,48 @@ __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16*
     }
 }
 
+// Column sums of a gradient tile for the bias gradient (q_bias / v_bias: the sum of dQ / dV over all rows), taken from the fp32 accumulators BEFORE they are
+// rounded and stored: lane (g, c) holds, per 16-wide d-tile dt, the 4 values d = 16 dt + 4 g + r of row c of each of its NT row tiles.  Sum over the valid row
+// tiles, over the 16 lanes c of a group (xor 1, 2, 4, 8), over the 4 waves through LDS in wave order: one [64] partial per workgroup, written to
+// part[(b * nblk + blk) * D + h * 64 + d] and reduced over (b, blk) in a fixed order by the caller's second stage (devias_colsum_finish): deterministic, no atomics.
+// Replaces two column-sum passes over the stored tensor per encoder block (77 MB read each at ViT-B).  `smem` is free: the caller has synchronised after its last tile.
+template <int NT>
+__device__ __forceinline__ void bias_partials(const f32x4 (&acc)[4][NT], const bool (&valid)[NT], float mul, char* smem, float* __restrict__ part, int64_t slot,
+                                              int tid, int lane, int wave) {
+    // every lane drops its 16 row-tile sums into LDS ([wave][d = 16 dt + 4 g + r][c], 16 KB), then thread d < 64 of the workgroup adds the 4 x 16 entries of its
+    // column in a fixed order (cross-lane shuffles cost this epilogue more than the 64 LDS reads do)
+    float* red = reinterpret_cast<float*>(smem);
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (valid[t]) v += acc[dt][t] * mul;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 64 + 16 * dt + 4 * g + r) * 17 + c] = v[r];      // (17: the 16 lanes of a group write 16 different banks, the 4 groups too)
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float t4[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* p = red + (w * 64 + tid) * 17;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a += p[i];
+            t4[w] = a;
+        }
+        part[slot + tid] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    }
+}
+
 // ======================================= backward dQ (bf16) ==============================================
 template <int QT, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                               int N, int H, float scale, int xcd, DropP drop = DropP{}) {
+                                                               int N, int H, float scale, int xcd, DropP drop = DropP{}, float* __restrict__ part_q = nullptr) {
     __shared__ __attribute__((aligned(16))) char smem[32768];     // two stages of (K image | V image), filled by LDS-DMA one tile ahead
     char* imgKt = smem;            // K, one image for both uses: row reads (S^T = K Q^T) and transposed reads (dQ^T = K^T dS^T)
     char* imgV = smem + 8192;      // V rows   (dP^T = V dO^T)
@@ -704,6 +740,22 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
             for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt, acc_dq[dt][qt] * scale);
         }
     }
+    if (part_q) {                                                 // (workgroup-uniform) q_bias gradient partials
+        __syncthreads();                                          // every wave is done with the last tile's LDS stage
+        // everything the epilogue needs is derived again from the (laundered) ids: nothing of it stays live across the key loop, whose register budget
+        // (three waves per SIMD) and schedule are then those of the kernel without the epilogue
+        int bid = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, t2 = threadIdx.x;
+        asm volatile("" : "+s"(bid), "+s"(by), "+s"(bz), "+v"(t2));
+        const int nblk = (N + NW * 16 * QT - 1) / (NW * 16 * QT);
+        int blk2, h2, b2;
+        if (xcd & 1) { const int x = bid & 7, slot = bid >> 3, hidx = (slot / nblk) * 8 + x; blk2 = slot - (slot / nblk) * nblk; h2 = hidx % H; b2 = hidx / H; }
+        else { blk2 = bid; h2 = by; b2 = bz; }
+        const int lane2 = t2 & 63, wave2 = t2 >> 6, q02 = blk2 * (NW * 16 * QT) + wave2 * (16 * QT);
+        bool valid[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) valid[qt] = q02 + 16 * qt + (lane2 & 15) < N;
+        bias_partials<QT>(acc_dq, valid, scale, smem, part_q, ((int64_t)b2 * nblk + blk2) * (H * 64) + h2 * 64, t2, lane2, wave2);
+    }
 }
 
 // ======================================= backward dK, dV (bf16) ==========================================
@@ -713,7 +765,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 template <bool DROP = false, int KT = 2>
 __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                 bf16* __restrict__ dqkv, int N, int H, float scale, int xcd, DropP drop = DropP{}) {
+                                                                 bf16* __restrict__ dqkv, int N, int H, float scale, int xcd, DropP drop = DropP{}, float* __restrict__ part_v = nullptr) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 2 * 512];   // two stages of (Q image | dO image) filled by LDS-DMA one tile ahead, + their row statistics
     char* imgQt = smem;             // Q, one image: row reads (S = Q K^T) and transposed reads (dK^T = Q^T dS)
     char* imgOt = smem + 8192;      // dO, one image: row reads (dP = dO V^T) and transposed reads (dV^T = dO^T P)
@@ -857,6 +909,20 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
                 store4(row + 2 * D + 16 * dt, acc_dv[dt][kt]);
             }
         }
+    }
+    if (part_v) {                                                 // (workgroup-uniform) v_bias gradient partials (ids derived again: see the dQ kernel)
+        __syncthreads();
+        int bid = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, t2 = threadIdx.x;
+        asm volatile("" : "+s"(bid), "+s"(by), "+s"(bz), "+v"(t2));
+        const int nblk = (N + 64 * KT - 1) / (64 * KT);
+        int blk2, h2, b2;
+        if (xcd & 1) { const int x = bid & 7, slot = bid >> 3, hidx = (slot / nblk) * 8 + x; blk2 = slot - (slot / nblk) * nblk; h2 = hidx % H; b2 = hidx / H; }
+        else { blk2 = bid; h2 = by; b2 = bz; }
+        const int lane2 = t2 & 63, wave2 = t2 >> 6, key02 = blk2 * (64 * KT) + wave2 * (16 * KT);
+        bool valid[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) valid[kt] = key02 + 16 * kt + (lane2 & 15) < N;
+        bias_partials<KT>(acc_dv, valid, 1.0f, smem, part_v, ((int64_t)b2 * nblk + blk2) * (H * 64) + h2 * 64, t2, lane2, wave2);
     }
 }
 
@@ -1042,12 +1108,13 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dkdv_f32_kernel(const float* __r
 
 // process-wide options, read from the environment once; devias_set_option("attn_cfg" | "attn_xcd", v) changes them at run time
 namespace {
-struct AttnKnobs { int cfg, xcd; };
+struct AttnKnobs { int cfg, xcd, bias_fused; };
 AttnKnobs& attn_knobs() {
     static AttnKnobs k = [] {
         AttnKnobs x;
         const char* e = getenv("DEVIAS_ATTN_CFG"); x.cfg = e ? atoi(e) : 0;
         e = getenv("DEVIAS_ATTN_XCD"); x.xcd = e ? atoi(e) : 1;
+        e = getenv("DEVIAS_ATTN_BIAS_FUSED"); x.bias_fused = e ? atoi(e) : 1;
         return x;
     }();
     return k;
@@ -1056,6 +1123,7 @@ AttnKnobs& attn_knobs() {
 int devias_attn_set_option(const char* name, int value) {
     if (!strcmp(name, "attn_cfg")) attn_knobs().cfg = value;
     else if (!strcmp(name, "attn_xcd")) attn_knobs().xcd = value;
+    else if (!strcmp(name, "attn_bias_fused")) attn_knobs().bias_fused = value;      // 0: devias_mhsa_bwd_bias takes the bias gradients by column-sum passes in bf16 too (A/B aid)
     else return 0;
     return 1;
 }
@@ -1119,7 +1187,8 @@ extern "C" int devias_mhsa_fwd_dropout(const void* qkv, void* o, float* lse, int
 extern "C" int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H) { (void)B; (void)N; (void)H; return 0; }
 
 static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
-                         int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream) {
+                         int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream,
+                         float* part_q = nullptr, float* part_v = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     DropP dp{};
     const bool drop = drop_params(keep, seed, dp);
@@ -1130,19 +1199,19 @@ static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
         const int cfg = attn_knobs().cfg;
         const int xcd = attn_xcd_flag(B, H);
         devias_count(DEVIAS_CNT_MHSA_BWD_BF16);
-#define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp
+#define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_q
 #define BWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
         if (drop) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 4, true>), BWD_GRID(128), dim3(256), 0, st, DQ_ARGS);
-        else if (cfg == 1) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 2>), BWD_GRID(128), dim3(128), 0, st, DQ_ARGS);
-        else if (cfg == 2) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 4>), BWD_GRID(256), dim3(256), 0, st, DQ_ARGS);
-        else if (cfg == 3) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 2>), BWD_GRID(64), dim3(128), 0, st, DQ_ARGS);
+        else if (cfg == 1 && !part_q) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 2>), BWD_GRID(128), dim3(128), 0, st, DQ_ARGS);
+        else if (cfg == 2 && !part_q) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 4>), BWD_GRID(256), dim3(256), 0, st, DQ_ARGS);
+        else if (cfg == 3 && !part_q) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 2>), BWD_GRID(64), dim3(128), 0, st, DQ_ARGS);
         else hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 4>), BWD_GRID(128), dim3(256), 0, st, DQ_ARGS);
 #undef DQ_ARGS
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");
         if (drop) hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<true>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
-                                     lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp);
+                                     lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_v);
         else hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<false>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
-                                lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp);
+                                lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_v);
 #undef BWD_GRID
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv)");
     } else if (dtype == DEVIAS_F32) {
@@ -1169,4 +1238,31 @@ extern "C" int devias_mhsa_bwd_dropout(const void* qkv, const void* o, const voi
                                        int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream) {
     DEVIAS_REQUIRE(keep > 0.f && keep <= 1.f, "devias_mhsa_bwd_dropout: keep must be in (0, 1]");
     return mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream);
+}
+
+// Backward + the q_bias / v_bias gradients (the column sums of the dQ and dV thirds of dqkv over all B * N rows; modeling_slot.py:97-99).  bf16: the two kernels
+// emit one [H * 64] partial per (batch entry, 128-row block) from their fp32 accumulators (bias_partials above) and the fixed-order second stage sums the
+// B * ceil(N / 128) partials -- no pass over the stored tensor.  fp32 (parity mode): the plain backward followed by two column-sum passes.  ws_q / ws_v: scratch of
+// devias_mhsa_bwd_bias_workspace_bytes() bytes each.  keep < 1: with the attention dropout of devias_mhsa_bwd_dropout.  (ABI 162)
+extern "C" int64_t devias_mhsa_bwd_bias_workspace_bytes(int32_t B, int32_t N, int32_t H) {
+    const int64_t a = (int64_t)B * cdiv(N, 128) * H * 64 * 4, c = devias_colsum_workspace_bytes(B * N, H * 64);
+    return a > c ? a : c;
+}
+extern "C" int devias_mhsa_bwd_bias(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
+                                    float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, void* stream) {
+    DEVIAS_REQUIRE(dbq && dbv && ws_q && ws_v, "devias_mhsa_bwd_bias: null bias-gradient / workspace pointer");
+    DEVIAS_REQUIRE(keep > 0.f && keep <= 1.f, "devias_mhsa_bwd_bias: keep must be in (0, 1]");
+    const int D = H * 64;
+    if (dtype == DEVIAS_BF16 && attn_knobs().bias_fused) {
+        const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream, ws_q, ws_v);
+        if (rc != DEVIAS_OK) return rc;
+        const int rows = B * cdiv(N, 128);
+        const int r1 = devias_colsum_finish(ws_q, rows, D, dbq, 0.f, (hipStream_t)stream);
+        return r1 != DEVIAS_OK ? r1 : devias_colsum_finish(ws_v, rows, D, dbv, 0.f, (hipStream_t)stream);
+    }
+    const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream);
+    if (rc != DEVIAS_OK) return rc;
+    const int64_t es = dtype == DEVIAS_BF16 ? 2 : 4;
+    const int r1 = devias_colsum(dqkv, dtype, B * N, D, 3 * D, dbq, 0.f, ws_q, stream);
+    return r1 != DEVIAS_OK ? r1 : devias_colsum(static_cast<const char*>(dqkv) + (int64_t)2 * D * es, dtype, B * N, D, 3 * D, dbv, 0.f, ws_v, stream);
 }

@@ -58,6 +58,7 @@ struct DeviasDeferList { enum { MAX = 16 }; DeviasReduceJob jobs[MAX]; int n; };
 DeviasDeferList*& devias_defer_slot();                            // api.hip: thread-local; non-null only while a region is collecting
 int& devias_defer_enabled();                                      // api.hip: option "regions_defer" / DEVIAS_REGIONS_DEFER (1, default; 0 = every second stage its own launch)
 int devias_flush_deferred(DeviasDeferList* l, hipStream_t st);    // elementwise.hip
+int devias_colsum_finish(const float* part, int nparts, int N, float* out, float beta, hipStream_t st);   // elementwise.hip: second stage of a column sum (deferred when a region collects)
 // true = the `count` second stages described by `j` were taken over by the collecting region (the caller must NOT launch them)
 static inline bool devias_defer(const DeviasReduceJob* j, int count) {
     DeviasDeferList* l = devias_defer_slot();

@@ -359,6 +359,15 @@ int devias_flush_deferred(DeviasDeferList* l, hipStream_t st) {
 
 extern "C" int64_t devias_colsum_workspace_bytes(int32_t M, int32_t N) { return (int64_t)cdiv(M, CS_ROWS) * N * 4; }
 
+// second stage of a column sum whose [nparts, N] fp32 partials some kernel has written: out = beta * out + sum over the parts in index order.  Taken over by the
+// collecting region when there is one (common.h: deferred final reductions), else its own launch.
+int devias_colsum_finish(const float* part, int nparts, int N, float* out, float beta, hipStream_t st) {
+    { const DeviasReduceJob j = {part, nparts, N, N, out, beta}; if (devias_defer(&j, 1)) return DEVIAS_OK; }
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64, 16), 0, st, part, nparts, N, out, beta);
+    DEVIAS_CHECK_LAUNCH("devias_colsum(final)");
+    return DEVIAS_OK;
+}
+
 extern "C" int devias_colsum(const void* x, int32_t dtype, int32_t M, int32_t N, int32_t ldx, float* out, float beta,
                              float* ws, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -371,10 +380,7 @@ extern "C" int devias_colsum(const void* x, int32_t dtype, int32_t M, int32_t N,
     else hipLaunchKernelGGL((colsum_partial_kernel<float>), g, b, 0, st, (const float*)x, M, N, ldx, ws, vec, direct, beta);
     DEVIAS_CHECK_LAUNCH("devias_colsum(partial)");
     if (direct) return DEVIAS_OK;
-    { const DeviasReduceJob j = {ws, nparts, N, N, out, beta}; if (devias_defer(&j, 1)) return DEVIAS_OK; }
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64, 16), 0, st, ws, nparts, N, out, beta);
-    DEVIAS_CHECK_LAUNCH("devias_colsum(final)");
-    return DEVIAS_OK;
+    return devias_colsum_finish(ws, nparts, N, out, beta, st);
 }
 
 extern "C" int devias_rows_reduce_mod(const void* x, int32_t dtype, int32_t M, int32_t N, int32_t mod, float* out, void* stream) {

@@ -139,7 +139,9 @@ struct BlockScratch {
         const int64_t lnw = devias_layernorm_bwd_workspace_bytes((int)M, D), csw = devias_colsum_workspace_bytes((int)M, 3 * D);
         p_ln2 = (float*)take(lnw); p_ln1 = (float*)take(lnw);
         p_db1 = (float*)take(max64((int64_t)cdiv(M, 128) * hid * 4, devias_colsum_workspace_bytes((int)M, hid)));
-        p_b2 = (float*)take(csw); p_bp = (float*)take(csw); p_q = (float*)take(csw); p_v = (float*)take(csw);
+        p_b2 = (float*)take(csw); p_bp = (float*)take(csw);
+        const int64_t abw = max64(csw, devias_mhsa_bwd_bias_workspace_bytes(B, N, H));
+        p_q = (float*)take(abw); p_v = (float*)take(abw);
         bytes = off;
     }
 };
@@ -231,11 +233,12 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
     }
     RUN(wgrad(c, g1, s.o, g->dWp, M, D, D));
     { Epi e; RUN(gemm(c, g1, a->Wp, t.small, M, D, D, D, D, 0, 1, e)); }                                                                        // d_o
-    RUN(devias_mhsa_bwd(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, nullptr, stream));                              // dqkv
+    if (g->dbq && g->dbv)                                                   // dqkv + the q_bias / v_bias gradients (each to its own destination) from the same two kernels
+        RUN(devias_mhsa_bwd_bias(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, 1.0f, 0, g->dbq, g->dbv, t.p_q, t.p_v, stream));
+    else
+        RUN(devias_mhsa_bwd(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, nullptr, stream));                          // dqkv
     RUN(wgrad(c, t.big, s.u, g->dWqkv, M, 3 * D, D));
-    if (g->dbq && g->dbv) {                                                 // q_bias | (k: no bias) | v_bias: the two thirds that exist, each to its own destination
-        RUN(devias_colsum(t.big, c.dtype, M, D, 3 * D, g->dbq, 0.f, t.p_q, c.st));
-        RUN(devias_colsum(t.big + (int64_t)2 * D * esize(c.dtype), c.dtype, M, D, 3 * D, g->dbv, 0.f, t.p_v, c.st));
+    if (g->dbq && g->dbv) {
     } else {
         RUN(colsum(with_ws(t.p_q), t.big, M, 3 * D, g->dbqkv));
     }

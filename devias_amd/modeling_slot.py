@@ -367,11 +367,10 @@ class EncoderBlockFn(Function):
         with lane.after_main():
             dWp = ops.wgrad(g1, o, out=_gout(p_pw))
         d_o = ops.gemm(g1, Wp, trans_b=True)
-        dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop)
+        dbq, dbv = dst(p_qb, D), dst(p_vb, D)                                  # q_bias | (k: no bias) | v_bias, each to its own destination
+        dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop, bias_out=(dbq, dbv))
         with lane.after_main():
             dWqkv = ops.wgrad(dqkv, u, out=_gout(p_qkvw))
-            dbq = ops.colsum(dqkv, out=_gout(p_qb), cols=(0, D))              # q_bias | (k: no bias) | v_bias, each to its own destination
-            dbv = ops.colsum(dqkv, out=_gout(p_vb), cols=(2 * D, D))
         du = ops.gemm(dqkv, Wqkv, trans_b=True)
         dxs = f32(D)
         dx, dn1w, dn1b = ops.layernorm_bwd(du, x, n1w_, mean1, rstd1, dres=dx1, dx_colsum=dxs, dgamma=_gout(p_n1w), dbeta=_gout(p_n1b))

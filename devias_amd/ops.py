@@ -295,10 +295,22 @@ def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, out: Optio
     return o, lse
 
 
-def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None):
+def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None, bias_out=None):
+    """bias_out = (dbq, dbv): fp32 [H * 64] destinations of the q_bias / v_bias gradients (column sums of dQ / dV over all rows), produced by the same call
+    (devias_mhsa_bwd_bias: from the kernels' accumulators in bf16, by two column-sum passes in fp32)"""
     _chk(qkv, "mhsa_bwd.qkv"); _chk(o, "mhsa_bwd.o", qkv.dtype); _chk(d_o, "mhsa_bwd.d_o", qkv.dtype)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    if bias_out is not None:
+        dbq, dbv = (_chk(t, "mhsa_bwd.bias_out", torch.float32) for t in bias_out)
+        assert dbq.numel() == H * 64 and dbv.numel() == H * 64
+        wsb = int(_lib.load().devias_mhsa_bwd_bias_workspace_bytes(B, N, H))
+        ws = torch.empty((2, (wsb + 3) // 4), dtype=torch.float32, device=qkv.device)
+        keep, seed = (float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF) if drop is not None else (1.0, 0)
+        _lib.check(_lib.load().devias_mhsa_bwd_bias(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N, H, scale,
+                                                    dt_code(qkv.dtype), keep, seed, dbq.data_ptr(), dbv.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), _stream()),
+                   "devias_mhsa_bwd_bias")
+        return dqkv
     if drop is not None and float(drop[0]) < 1.0:
         _lib.check(_lib.load().devias_mhsa_bwd_dropout(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(),
                                                        B, N, H, scale, dt_code(qkv.dtype), float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, _stream()),

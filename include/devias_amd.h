@@ -77,7 +77,8 @@ void devias_counters_reset(void);
  * the persistent kernel pull their tiles from per-XCD queues at run time instead of walking static lists -- a CU held or slowed by a concurrent kernel, e.g. RCCL's during
  * backward, just takes fewer tiles; 0: static lists; -1, default: queues exactly when "gemm_concurrent" is set; same bits either way), "gemm_concurrent" (the host
  * announces that other kernels run beside the step's: devias_amd.parallel.GradSync sets it for N > 1), "gemm_reserve_cus" (CUs the big-tile grids and the weight-gradient split-K sizing leave free for such a kernel),
- * "attn_cfg", "attn_xcd", "regions_defer" (1, default: an encoder block's backward runs the second stages of its partial reductions -- LayerNorm parameter
+ * "attn_cfg", "attn_xcd", "attn_bias_fused" (1, default: devias_mhsa_bwd_bias takes the q_bias / v_bias gradients from the backward kernels' accumulators; 0: by two
+ * column-sum passes over dqkv, as before ABI 162 -- A/B aid), "regions_defer" (1, default: an encoder block's backward runs the second stages of its partial reductions -- LayerNorm parameter
  * gradients, bias-gradient column sums -- as ONE launch at its end instead of 5-7).  Every choice computes the same bits EXCEPT gemm_smallm (different K summation order) and gemm_reserve_cus (like the device's CU count it
  * sets the split-K factor of the weight-gradient GEMMs, hence their fp32 summation order: runs with different reserves -- or N = 1 against N > 1 runs that set one --
  * agree to rounding, not bitwise).  0 = ok, DEVIAS_EINVAL = unknown name. */
@@ -222,6 +223,13 @@ int devias_mhsa_fwd_dropout(const void* qkv, void* o, float* lse, int32_t B, int
                             int32_t dtype, float keep, uint64_t seed, void* stream);
 int devias_mhsa_bwd_dropout(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                             int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream);
+/* Backward + the q_bias / v_bias gradients dbq, dbv: fp32 [H*64] each = the column sums of the dQ and dV thirds of dqkv over all B*N rows (the bias enters the QKV
+ * projection, modeling_slot.py:97-101), ABI 162.  bf16: the two kernels emit one partial per (batch entry, 128-row block) from their fp32 accumulators and a
+ * fixed-order second stage sums them -- no pass over the stored tensor (it replaces two devias_colsum calls per block: 2 x 77 MB read at ViT-B); fp32: the plain
+ * backward followed by the two column sums.  keep = 1: no attention dropout (seed ignored).  ws_q, ws_v: devias_mhsa_bwd_bias_workspace_bytes() bytes each. */
+int devias_mhsa_bwd_bias(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
+                         float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, void* stream);
+int64_t devias_mhsa_bwd_bias_workspace_bytes(int32_t B, int32_t N, int32_t H);
 
 /* ---------------------------------------------------------------------------------------------------
  * Slot cross-attention core (agg_block/attention.py:128-140): heads h, head dim dh (4 x 512 in DEVIAS),

@@ -242,6 +242,33 @@ def test_mhsa_dropout_matches_the_reference_with_the_same_mask(dtype, B, N, H, k
     assert not torch.equal(out, out3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,H", [(2, 100, 3), (1, 784, 2), (3, 333, 1), (2, 1568, 2)])
+@pytest.mark.parametrize("keep", [1.0, 0.8])
+def test_mhsa_bwd_emits_the_bias_gradients(dtype, B, N, H, keep):
+    """devias_mhsa_bwd_bias: dqkv is bitwise that of the plain backward, and dbq / dbv are the column sums of its dQ / dV thirds over all rows -- in bf16 taken
+    from the kernels' fp32 accumulators (one partial per batch entry and 128-row block, fixed-order second stage), so they agree with the sums of the
+    bf16-ROUNDED stored values to rounding noise and are closer to the fp32 reference than those; ragged N (partly empty blocks) and attention dropout included"""
+    o = ops()
+    scale = 64 ** -0.5
+    D = H * 64
+    drop = None if keep == 1.0 else (keep, 1234567 + N)
+    qkv = rnd(B * N, 3 * D, dtype=dtype, seed=40)
+    d_o = rnd(B * N, D, dtype=dtype, seed=41)
+    out, lse = o.mhsa_fwd(qkv, B, N, H, scale, drop=drop)
+    plain = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale, drop=drop)
+    dbq = torch.full((D,), 7.0, device="cuda"); dbv = torch.full((D,), -3.0, device="cuda")        # (overwritten, not accumulated)
+    dqkv = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale, drop=drop, bias_out=(dbq, dbv))
+    assert torch.equal(dqkv, plain)
+    g = plain.float().reshape(B * N, 3, D)
+    rq, rv = g[:, 0].sum(0), g[:, 2].sum(0)
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
+    assert rel(dbq, rq) < tol and rel(dbv, rv) < tol
+    dbq2 = torch.empty_like(dbq); dbv2 = torch.empty_like(dbv)
+    o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale, drop=drop, bias_out=(dbq2, dbv2))
+    assert torch.equal(dbq, dbq2) and torch.equal(dbv, dbv2)            # run to run
+
+
 def test_mhsa_bf16_online_softmax_rescale():
     """force the running max to jump late in the key sequence (the rare rescale path of the online softmax)"""
     o = ops()
