@@ -79,7 +79,7 @@ void devias_counters_reset(void);
  * announces that other kernels run beside the step's: devias_amd.parallel.GradSync sets it for N > 1), "gemm_reserve_cus" (CUs the big-tile grids and the weight-gradient split-K sizing leave free for such a kernel),
  * "attn_cfg", "attn_xcd", "attn_bias_fused" (1, default: devias_mhsa_bwd_bias takes the q_bias / v_bias gradients from the backward kernels' accumulators; 0: by two
  * column-sum passes over dqkv, as before ABI 162 -- A/B aid), "regions_defer" (1, default: an encoder block's backward runs the second stages of its partial reductions -- LayerNorm parameter
- * gradients, bias-gradient column sums -- as ONE launch at its end instead of 5-7).  Every choice computes the same bits EXCEPT gemm_smallm (different K summation order) and gemm_reserve_cus (like the device's CU count it
+ * gradients, bias-gradient column sums -- as ONE launch at its end instead of 5-7).  Every choice computes the same bits EXCEPT gemm_smallm (different K summation order), attn_bias_fused (the two bias gradients are sums of the kernels' fp32 accumulators instead of the bf16-rounded tensor) and gemm_reserve_cus (like the device's CU count it
  * sets the split-K factor of the weight-gradient GEMMs, hence their fp32 summation order: runs with different reserves -- or N = 1 against N > 1 runs that set one --
  * agree to rounding, not bitwise).  0 = ok, DEVIAS_EINVAL = unknown name. */
 int devias_set_option(const char* name, int32_t value);
