@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--img-size", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--drop-path", type=float, default=0.0, help="stochastic depth rate (BASELINE.md quotes the metric at 0; the reference's training default is 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary full-step number (teacher fwd + AdamW)")
@@ -58,7 +59,7 @@ def build_model(args, device):
     from devias_amd import create_model, synth
     name = {"vit_base": "slot_vit_base_patch16_224", "vit_small": "slot_vit_small_patch16_224",
             "vit_large": "slot_vit_large_patch16_224"}[args.model]
-    model = create_model(name, img_size=args.img_size, num_classes=400, all_frames=args.frames, tubelet_size=2, drop_path_rate=0.0, init_scale=0.001,
+    model = create_model(name, img_size=args.img_size, num_classes=400, all_frames=args.frames, tubelet_size=2, drop_path_rate=args.drop_path, init_scale=0.001,
                          num_latents=2, head_type="linear", slot_matching="matching", agg_weights_tie=True, agg_depth=8,
                          num_scene_classes=365, compute_dtype=args.dtype)
     synth.fill_module_(model, seed=0)        # formula weights: identical on every rank, no broadcast needed
@@ -346,6 +347,7 @@ def main():
                                f"B={B} clips/GPU, student fwd + matching loss + bwd" + (f" + RCCL grad all-reduce ({args.comm_dtype} wire format, 64 MiB fp32 buckets, side stream)" if world > 1 else "") +
                                (" + gradient-bucket path with the collective replaced by a device copy (--force-gradsync)" if args.force_gradsync and world == 1 else "") +
                                (f" + gradient-bucket path over a ONE-rank RCCL group ({args.comm_dtype} wire format, --rccl-world1)" if args.rccl_world1 and world == 1 else "") +
+                               (f" + stochastic depth {args.drop_path} (--drop-path; NOT the BASELINE configuration)" if args.drop_path else "") +
                                (f" + {args.cu_hog} CUs held on a side stream during backward (--cu-hog)" if args.cu_hog else "") +
                                (f" + persistent GEMM grids sized for {args.reserve_cus} fewer CUs (--reserve-cus)" if args.reserve_cus else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",

@@ -59,6 +59,7 @@ DeviasDeferList*& devias_defer_slot();                            // api.hip: th
 int& devias_defer_enabled();                                      // api.hip: option "regions_defer" / DEVIAS_REGIONS_DEFER (1, default; 0 = every second stage its own launch)
 int devias_flush_deferred(DeviasDeferList* l, hipStream_t st);    // elementwise.hip
 int devias_colsum_finish(const float* part, int nparts, int N, float* out, float beta, hipStream_t st);   // elementwise.hip: second stage of a column sum (deferred when a region collects)
+int devias_row_scale_colsum(const void* x, const float* scale, int rps, void* y, int dtype, int M, int N, float* out, float beta, float* ws, hipStream_t st);   // elementwise.hip: y = x * scale[row / rps] and its column sums in one pass
 // true = the `count` second stages described by `j` were taken over by the collecting region (the caller must NOT launch them)
 static inline bool devias_defer(const DeviasReduceJob* j, int count) {
     DeviasDeferList* l = devias_defer_slot();

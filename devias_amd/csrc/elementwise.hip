@@ -67,9 +67,14 @@ __global__ void im2col_kernel(const S* __restrict__ x, D* __restrict__ out, int 
 // fp32 loads per row), so a wave reads 2 rows x 512 contiguous bytes per instruction.  CS_ROWS rows per workgroup ->
 // partial[rb][n]; stage 2: out[n] = beta*out[n] + sum_rb partial (fixed order).
 enum { CS_ROWS = 256, CS_COLS = 256 };
-template <typename T>
+// SCALE: y = x * scale[row / rps] is written as well (devias_row_scale's arithmetic) and the sums are those of the STORED (rounded) y: one pass instead of the
+// row-scale pass followed by a column-sum pass over its output, bitwise the same results (vector path only: the host falls back to the two kernels otherwise)
+__device__ __forceinline__ f32x4 stored4(f32x4 v, const float*) { return v; }
+__device__ __forceinline__ f32x4 stored4(f32x4 v, const bf16*) { return f32x4{(float)(bf16)v[0], (float)(bf16)v[1], (float)(bf16)v[2], (float)(bf16)v[3]}; }
+template <typename T, bool SCALE = false>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int M, int N, int ldx, float* __restrict__ part, int vec,
-                                                             float* __restrict__ out, float beta) {
+                                                             float* __restrict__ out, float beta, const float* __restrict__ scale = nullptr, int rps = 1,
+                                                             T* __restrict__ y = nullptr) {
     __shared__ float sm[8][CS_COLS + 8];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n0 = blockIdx.x * CS_COLS + tx * 8;
@@ -81,6 +86,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     if (vec && n0 + 7 < N) {
         for (int r = r0 + ty; r < r1; r += 8) {
             f32x4 a = load4(x + (int64_t)r * ldx + n0), b = load4(x + (int64_t)r * ldx + n0 + 4);
+            if constexpr (SCALE) {
+                const float sc = scale[r / rps];
+                a = a * sc; b = b * sc;
+                store4(y + (int64_t)r * ldx + n0, a); store4(y + (int64_t)r * ldx + n0 + 4, b);
+                a = stored4(a, x); b = stored4(b, x);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s[j] += a[j]; s[4 + j] += b[j]; }
         }
@@ -413,6 +424,23 @@ extern "C" int devias_row_scale(const void* x, const float* scale, int32_t rps, 
     else return devias_set_error(DEVIAS_EINVAL, "devias_row_scale: bad dtype %d", dtype);
     DEVIAS_CHECK_LAUNCH("devias_row_scale");
     return DEVIAS_OK;
+}
+
+// y = x * scale[row / rps] AND out = beta * out + column sums of y, in one pass over x (the stochastic-depth backward of an encoder block: the rescaled branch
+// gradient and its bias gradient).  Bitwise devias_row_scale followed by devias_colsum of its output.  ws: devias_colsum_workspace_bytes(M, N).
+int devias_row_scale_colsum(const void* x, const float* scale, int rps, void* y, int dtype, int M, int N, float* out, float beta, float* ws, hipStream_t st) {
+    DEVIAS_REQUIRE(x && scale && y && out && ws && rps > 0 && M > 0 && N > 0, "devias_row_scale_colsum: bad args");
+    if (N % 8 != 0 || !aligned16(x) || !aligned16(y) || M <= CS_ROWS) {                    // (no vector path / single row block: the two kernels)
+        int rc = devias_row_scale(x, scale, rps, y, dtype, M, N, st);
+        return rc ? rc : devias_colsum(y, dtype, M, N, N, out, beta, ws, st);
+    }
+    const int nparts = cdiv(M, CS_ROWS);
+    dim3 g(cdiv(N, CS_COLS), nparts), b(256);
+    if (dtype == DEVIAS_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16, true>), g, b, 0, st, (const bf16*)x, M, N, N, ws, 1, (float*)nullptr, beta, scale, rps, (bf16*)y);
+    else if (dtype == DEVIAS_F32) hipLaunchKernelGGL((colsum_partial_kernel<float, true>), g, b, 0, st, (const float*)x, M, N, N, ws, 1, (float*)nullptr, beta, scale, rps, (float*)y);
+    else return devias_set_error(DEVIAS_EINVAL, "devias_row_scale_colsum: bad dtype %d", dtype);
+    DEVIAS_CHECK_LAUNCH("devias_row_scale_colsum");
+    return devias_colsum_finish(ws, nparts, N, out, beta, st);
 }
 
 extern "C" int devias_add(const void* a, const void* b_, void* y, int32_t dtype, int64_t n, void* stream) {

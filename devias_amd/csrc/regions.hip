@@ -211,9 +211,8 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
     // ---- MLP branch (g2 = gradient of the branch output: dx2 scaled by the per-sample stochastic-depth factor, if any)
     const void* g2 = dx2;
     if (a->ds2) {
-        RUN(devias_row_scale(dx2, a->ds2, N, t.g, a->dtype, M, D, stream));
+        RUN(devias_row_scale_colsum(dx2, a->ds2, N, t.g, a->dtype, M, D, g->db2, 0.f, t.p_b2, (hipStream_t)stream));      // the rescaled copy and its column sums in one pass
         g2 = t.g;
-        RUN(colsum(with_ws(t.p_b2), g2, M, D, g->db2));
     } else if (!g->db2_done) {
         RUN(colsum(with_ws(t.p_b2), dx2, M, D, g->db2));                       // fc2 bias gradient (the caller had no ready-made column sums of dx2)
     }
@@ -227,9 +226,8 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
     // ---- attention branch
     const void* g1 = t.dx1;
     if (a->ds1) {
-        RUN(devias_row_scale(t.dx1, a->ds1, N, t.g, a->dtype, M, D, stream));
+        RUN(devias_row_scale_colsum(t.dx1, a->ds1, N, t.g, a->dtype, M, D, g->dbp, 0.f, t.p_bp, (hipStream_t)stream));
         g1 = t.g;
-        RUN(colsum(with_ws(t.p_bp), g1, M, D, g->dbp));
     }
     RUN(wgrad(c, g1, s.o, g->dWp, M, D, D));
     { Epi e; RUN(gemm(c, g1, a->Wp, t.small, M, D, D, D, D, 0, 1, e)); }                                                                        // d_o
