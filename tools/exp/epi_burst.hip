@@ -11,7 +11,7 @@
 typedef __attribute__((ext_vector_type(4))) unsigned int u4;
 
 __global__ __launch_bounds__(512) void k(char* __restrict__ out, int rounds, int busy, int mode, int active, int nout, long long out_stride,
-                                          long long* __restrict__ stamps) {
+                                          long long* __restrict__ stamps, int shape) {
     if ((int)blockIdx.x >= 256) return;
     // active < 256: keep workgroups spread over the XCDs (blockIdx % 8 = XCD)
     if (active < 256 && (int)(blockIdx.x >> 3) >= active / 8) return;
@@ -31,8 +31,13 @@ __global__ __launch_bounds__(512) void k(char* __restrict__ out, int rounds, int
         for (int o = 0; o < nout; ++o) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int r16 = (wave >> 2) * 128 + (i >> 1) * 16 + (lane & 15);
-                char* dst = out + o * out_stride + ((size_t)(t / 9) * 256 + r16) * 4608 + (t % 9) * 512 + (wave & 3) * 128 + (i & 1) * 64 + (lane >> 4) * 16;
+                // shape 0: the GEMM epilogue's 16 rows x 64 B per wave-instruction (two instructions per 128-byte line); shape 1: 8 rows x 128 B (whole lines);
+                // shape 2: 4 rows x 256 B
+                const int r16 = shape == 0 ? (wave >> 2) * 128 + (i >> 1) * 16 + (lane & 15) : shape == 1 ? (wave >> 2) * 128 + i * 8 + (lane >> 3)
+                                                                                                         : (wave >> 2) * 128 + (i >> 1) * 8 + (i & 1) * 4 + (lane >> 4) + 0 * 0;
+                char* dst = shape == 0 ? out + o * out_stride + ((size_t)(t / 9) * 256 + r16) * 4608 + (t % 9) * 512 + (wave & 3) * 128 + (i & 1) * 64 + (lane >> 4) * 16
+                          : shape == 1 ? out + o * out_stride + ((size_t)(t / 9) * 256 + r16) * 4608 + (t % 9) * 512 + (wave & 3) * 128 + (lane & 7) * 16
+                                       : out + o * out_stride + ((size_t)(t / 9) * 256 + (wave >> 1) * 64 + i * 4 + (lane >> 4)) * 4608 + (t % 9) * 512 + (wave & 1) * 256 + (lane & 15) * 16;
                 *reinterpret_cast<u4*>(dst) = v;
                 v.x += 1;
             }
@@ -52,7 +57,9 @@ __global__ __launch_bounds__(512) void k(char* __restrict__ out, int rounds, int
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const int shape = argc > 1 ? atoi(argv[1]) : 0;
+    printf("store shape %d\n", shape);
     const int rounds = 9;
     const long long out_stride = (long long)(rounds * 256 / 9 + 1) * 256 * 4608;
     char* out; long long* st;
@@ -71,7 +78,7 @@ int main() {
                 for (int rep = 0; rep < 3; ++rep) {
                     (void)hipMemset(st, 0, 256 * 4 * sizeof(long long));
                     (void)hipEventRecord(e0);
-                    for (int l = 0; l < 4; ++l) hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, out, rounds, busy, mode, active, nout, out_stride, st);
+                    for (int l = 0; l < 4; ++l) hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, out, rounds, busy, mode, active, nout, out_stride, st, shape);
                     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
                     (void)hipEventElapsedTime(&ms, e0, e1);
                 }
