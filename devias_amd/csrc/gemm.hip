@@ -833,11 +833,23 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int t = xcd_remap(blockIdx.x, ntiles);
+    int t, z;
+    if (gridDim.y == 1 && p.split_k > 1) {
+        // Split-K launched as ONE list of (slab z, tile) pairs in XCD-major order: XCD x (block ids congruent to x mod 8) takes the x-th eighth of the list, i.e. ~32
+        // consecutive tiles of ONE slab.  Workgroups of a slab read the same K range (rows of both operands, for the weight gradient) and differ only in the column blocks:
+        // 32 tiles of one slab are ~11 x 3 column blocks, 14 operand blocks for 32 workgroups, held by the XCD's L2 while the workgroups stream through K together.
+        // The (tile, slab) grid put ~4.5 tiles of EVERY slab on each XCD: seven K ranges per L2, 2.7 x the operand bytes from the fabric (profiles/r4_wgrad_xcd.txt).
+        const int total = ntiles * p.split_k, per = (total + 7) >> 3;
+        const int j = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        if (j >= total || (int)(blockIdx.x >> 3) >= per) return;
+        z = j / ntiles; t = j - z * ntiles;
+    } else {
+        t = xcd_remap(blockIdx.x, ntiles);
+        z = blockIdx.y;
+    }
     int tm, tn;
     tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     const int m0 = tm * T2, n0 = tn * T2;
-    const int z = blockIdx.y;
     const int kbeg = z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     int nk = (kend - kbeg) / 64;
@@ -1974,6 +1986,7 @@ struct GemmKnobs {
                        //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
     int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
                        //                                        15 = all four; -1, default: all four where K >= 1024 and N >= 1024)
+    int splitk_xcd;    // "gemm_splitk_xcd" DEVIAS_GEMM_SPLITK_XCD 1 (default): split-K launches of the 256 x 256 kernel (the weight gradients) order their (slab, tile) pairs XCD-major; 0: (tile, slab) grid
     int dynamic;       // "gemm_dynamic"    DEVIAS_GEMM_DYNAMIC  1: the persistent kernel's workgroups pull their tiles from per-XCD queues at run time (robust to CUs
                        //                                        held or slowed by a concurrent kernel: -2.5 ms per step with 16 CUs held during backward, profiles/
                        //                                        r4_cu_hog.txt); 0: the static per-workgroup tile lists (0.3 ms per step faster when the GPU is the
@@ -1997,6 +2010,7 @@ GemmKnobs& knobs() {
         x.persistent = env_int("DEVIAS_GEMM_PERSIST", 1);
         x.debug = env_int("DEVIAS_GEMM_DEBUG", 0);
         x.reserve = env_int("DEVIAS_GEMM_RESERVE_CUS", 0);
+        x.splitk_xcd = env_int("DEVIAS_GEMM_SPLITK_XCD", 1);
         x.dynamic = env_int("DEVIAS_GEMM_DYNAMIC", -1);
         x.concurrent = env_int("DEVIAS_GEMM_CONCURRENT", 0);
         x.w4 = env_int("DEVIAS_GEMM_W4", -1);
@@ -2043,6 +2057,7 @@ int devias_gemm_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_tail_split")) k.tail_split = value;
     else if (!strcmp(name, "gemm_smallm")) k.smallm = value;
     else if (!strcmp(name, "gemm_reserve_cus")) k.reserve = value < 0 ? 0 : value;
+    else if (!strcmp(name, "gemm_splitk_xcd")) k.splitk_xcd = value;
     else if (!strcmp(name, "gemm_dynamic")) k.dynamic = value;
     else if (!strcmp(name, "gemm_concurrent")) k.concurrent = value;
     else return 0;
@@ -2228,6 +2243,7 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
             devias_count(DEVIAS_CNT_GEMM256P);
         } else {
             dim3 grid(nt, p.split_k), block(NT2);
+            if (p.split_k > 1 && kn.splitk_xcd) grid = dim3(8 * ((nt * p.split_k + 7) / 8));      // (slab, tile) pairs in XCD-major order (gemm256_kernel)
             if (!ta && !tb) hipLaunchKernelGGL((gemm256_kernel<false, false, 1>), grid, block, 0, st, p);
             else if (!ta && tb) hipLaunchKernelGGL((gemm256_kernel<false, true>), grid, block, 0, st, p);
             else if (ta && tb) hipLaunchKernelGGL((gemm256_kernel<true, true>), grid, block, 0, st, p);

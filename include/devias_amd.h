@@ -77,6 +77,8 @@ void devias_counters_reset(void);
  * the persistent kernel pull their tiles from per-XCD queues at run time instead of walking static lists -- a CU held or slowed by a concurrent kernel, e.g. RCCL's during
  * backward, just takes fewer tiles; 0: static lists; -1, default: queues exactly when "gemm_concurrent" is set; same bits either way), "gemm_concurrent" (the host
  * announces that other kernels run beside the step's: devias_amd.parallel.GradSync sets it for N > 1), "gemm_reserve_cus" (CUs the big-tile grids and the weight-gradient split-K sizing leave free for such a kernel),
+ * "gemm_splitk_xcd" (1, default: a split-K launch of the 256 x 256 kernel -- the weight gradients -- orders its (slab, tile) pairs XCD-major, ~32 tiles of ONE slab per
+ * XCD, so that an L2 holds one K range instead of seven: 2.3 x fewer operand bytes from the fabric; 0: the (tile, slab) grid; same bits),
  * "attn_cfg", "attn_xcd", "attn_bias_fused" (1, default: devias_mhsa_bwd_bias takes the q_bias / v_bias gradients from the backward kernels' accumulators; 0: by two
  * column-sum passes over dqkv, as before ABI 162 -- A/B aid), "regions_defer" (1, default: an encoder block's backward runs the second stages of its partial reductions -- LayerNorm parameter
  * gradients, bias-gradient column sums -- as ONE launch at its end instead of 5-7).  Every choice computes the same bits EXCEPT gemm_smallm (different K summation order), attn_bias_fused (the two bias gradients are sums of the kernels' fp32 accumulators instead of the bf16-rounded tensor) and gemm_reserve_cus (like the device's CU count it
