@@ -23,8 +23,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=f
          "-mllvm", "-amdgpu-mfma-vgpr-form"]   # keep MFMA accumulators in VGPRs: no v_accvgpr_* shuffles around the VALU epilogues
 
 
+# per-file additions.  attention.hip: no SLP vectorisation -- the compiler packs adjacent scalar fp32 adds / multiplies of the softmax arithmetic into v_pk_* instructions,
+# and a packed fp32 instruction beside MFMAs costs more issue time than the two it replaces (MI355X_MICROARCH.md, per-instruction constants): forward attention -4 %
+# (profiles/r4_packed_fp32.txt)
+FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+
+
 def _flags(src: str):
-    return FLAGS
+    return FLAGS + FILE_FLAGS.get(src, [])
 
 
 def source_hash() -> str:
@@ -36,6 +42,7 @@ def source_hash() -> str:
         h.update(name.encode()); h.update(open(os.path.join(CSRC, name), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "devias_amd.h"), "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()[:16]
 
 
