@@ -465,7 +465,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16*
 #pragma unroll
         for (int r = 3; r < 15; r += 2) mx2 = fmaxf(fmaxf(mx2, st[1][r]), st[1][r + 1]);
         mx = fmaxf(mx, fmaxf(mx2, st[1][15]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        {   // the other half's maximum by v_permlane32_swap (one vector instruction) instead of a ds_bpermute round trip through the LDS crossbar on every tile's critical path
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));      // (forward kernel 316.6 -> 309.7 us)
+        }
         if (first || __any(mx > THR)) {
             const float shift = first ? mx : fmaxf(mx, 0.f);
             const float alpha = first ? 0.f : fast_exp2(-shift);
