@@ -93,15 +93,26 @@ __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
 }
 
 // ---- wave reductions (all 64 lanes participate) ---------------------------------------------------
+// the 64-lane sum without the LDS crossbar: four DPP adds inside each row of 16 lanes (quad_perm, quad_perm, row_ror:4, row_ror:8), then the four row sums by v_permlane32_swap and
+// v_permlane16_swap; every lane ends with the total.  Six `__shfl_xor` (ds_bpermute round trips) per sum were what held the LayerNorm kernels below the copy rate: forward 31.2 -> 26.6 us
+// at [50176, 768] (5.8 TB/s), backward 61.2 -> 58.5 (profiles/r4_packed_fp32.txt).  The association differs from the xor butterfly's: sums change in their last bits, deterministically.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define DEVIAS_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+    DEVIAS_DPP_ADD(0xB1); DEVIAS_DPP_ADD(0x4E); DEVIAS_DPP_ADD(0x124); DEVIAS_DPP_ADD(0x128);
+#undef DEVIAS_DPP_ADD
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+#define DEVIAS_DPP_MAX(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false)))
+    DEVIAS_DPP_MAX(0xB1); DEVIAS_DPP_MAX(0x4E); DEVIAS_DPP_MAX(0x124); DEVIAS_DPP_MAX(0x128);
+#undef DEVIAS_DPP_MAX
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // bf16 kernels: GELU and its derivative from two odd degree-17 polynomials in t = clamp(x, -4, 4) / 4 (least-squares fits at
