@@ -627,6 +627,11 @@ __device__ __forceinline__ bf16x8 sm_frag_tr(const char* img, int cbase, int lan
 __device__ __forceinline__ f32x4 sm_mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 // NB = 64-column blocks per wave (D = 256 * NB): 3 for ViT-B (768), 4 for ViT-L (1024), 2 for D = 512
+// xor-1 / xor-2 lane exchange inside a quad by DPP quad_perm (no LDS crossbar round trip); o is 1 or 2
+__device__ __forceinline__ float quad_xor(float x, int o) {
+    return o == 1 ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false))
+                  : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));
+}
 template <int NB, bool BWD>
 __global__ __launch_bounds__(256) void slotm_kernel(const bf16* __restrict__ rowsrc,   // forward: q' [B*S, h*D]; backward: dz [B*S, h*D]
                                                     const bf16* __restrict__ ctx, float* __restrict__ attn,      // forward: written; backward: read
@@ -733,16 +738,16 @@ __global__ __launch_bounds__(256) void slotm_kernel(const bf16* __restrict__ row
                 if constexpr (!BWD) {
                     float sv = rvalid ? acc[sub][r] * scale : -INFINITY;
                     float mx = sv;
-                    for (int o = 1; o < S; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));          // S is 1, 2 or 4: lanes of one head are aligned
+                    _Pragma("unroll") for (int o = 1; o < S; o <<= 1) mx = fmaxf(mx, quad_xor(mx, o));          // S is 1, 2 or 4: lanes of one head are aligned
                     float ev = rvalid ? expf(sv - mx) : 0.f;
                     float den = ev;
-                    for (int o = 1; o < S; o <<= 1) den += __shfl_xor(den, o, 64);
+                    _Pragma("unroll") for (int o = 1; o < S; o <<= 1) den += quad_xor(den, o);
                     v = (rvalid && tok + r < j1) ? ev / den : 0.f;
                     rs += v;
                 } else {
                     const float dA = (acc[sub][r] - dl) * rinv + e4[r];
                     float tsum = a4[r] * dA;
-                    for (int o = 1; o < S; o <<= 1) tsum += __shfl_xor(tsum, o, 64);
+                    _Pragma("unroll") for (int o = 1; o < S; o <<= 1) tsum += quad_xor(tsum, o);
                     v = (rvalid && tok + r < j1) ? a4[r] * (dA - tsum) : 0.f;
                 }
                 vals[4 * sub + r] = v;
