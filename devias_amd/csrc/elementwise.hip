@@ -346,8 +346,19 @@ __global__ void reduce_jobs_kernel(ReduceJobs jobs) {
     const int n = blockIdx.x * 64 + threadIdx.x;
     if (blockIdx.x * 64 >= jb.n) return;                   // (whole block past this job's width)
     float s = 0.f;
-    if (n < jb.n)
-        for (int i = threadIdx.y; i < jb.nparts; i += 16) s += jb.part[(int64_t)i * jb.stride + n];
+    if (n < jb.n) {
+        // eight loads in flight, added in index order (the same sums as the one-at-a-time loop: this is a latency chain of nparts / 16 dependent loads otherwise --
+        // 26 of them for the 416 partials of the attention backward's bias gradients)
+        int i = threadIdx.y;
+        for (; i + 7 * 16 < jb.nparts; i += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = jb.part[(int64_t)(i + 16 * u) * jb.stride + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < jb.nparts; i += 16) s += jb.part[(int64_t)i * jb.stride + n];
+    }
     sm[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0 && n < jb.n) {
