@@ -455,18 +455,31 @@ __global__ __launch_bounds__(256) void slotf_fwd_kernel(const T* __restrict__ qp
     }
 }
 
+// sum of n values `stride` floats apart, added in index order with eight loads in flight (a chain of n dependent load latencies otherwise: these finish kernels are all latency)
+__device__ __forceinline__ float sum_strided8(const float* __restrict__ p, int n, int64_t stride) {
+    float s = 0.f;
+    int c = 0;
+    for (; c + 7 < n; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(c + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < n; ++c) s += p[(int64_t)c * stride];
+    return s;
+}
+
 // finish: rsum[bh,i] = sum_chunks ws_r + 1e-7 ; z[b,i,hh*D+d] = sum_chunks ws_z / rsum
 template <typename T>
 __global__ void slotf_fwd_finish_kernel(const float* __restrict__ ws_r, const float* __restrict__ ws_z, float* __restrict__ rsum,
                                         T* __restrict__ z, int S, int h, int D, int nchunks) {
     const int bh = blockIdx.x / S, i = blockIdx.x % S, b = bh / h, hh = bh % h;
-    float r = 0.f;
-    for (int c = 0; c < nchunks; ++c) r += ws_r[((int64_t)bh * nchunks + c) * S + i];
+    float r = sum_strided8(ws_r + (int64_t)bh * nchunks * S + i, nchunks, S);
     r += 1e-7f;
     if (threadIdx.x == 0) rsum[(int64_t)bh * S + i] = r;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float s = 0.f;
-        for (int c = 0; c < nchunks; ++c) s += ws_z[(((int64_t)bh * nchunks + c) * S + i) * D + d];
+        const float s = sum_strided8(ws_z + ((int64_t)bh * nchunks * S + i) * D + d, nchunks, (int64_t)S * D);
         z[((int64_t)b * S + i) * h * D + hh * D + d] = from_f32<T>(s / r);
     }
 }
@@ -558,8 +571,7 @@ template <typename T>
 __global__ void slotf_bwd_finish_kernel(const float* __restrict__ ws_q, T* __restrict__ dqp, int S, int h, int D, int nchunks) {
     const int bh = blockIdx.x / S, i = blockIdx.x % S, b = bh / h, hh = bh % h;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float s = 0.f;
-        for (int c = 0; c < nchunks; ++c) s += ws_q[(((int64_t)bh * nchunks + c) * S + i) * D + d];
+        const float s = sum_strided8(ws_q + ((int64_t)bh * nchunks * S + i) * D + d, nchunks, (int64_t)S * D);
         dqp[((int64_t)b * S + i) * h * D + hh * D + d] = from_f32<T>(s);
     }
 }
