@@ -91,31 +91,84 @@ def cpu_baseline(args):
                       f"{args.model} {args.frames}x{args.img_size}^2, {torch.get_num_threads()} of {os.cpu_count()} host cores (PyTorch CPU kernels stop scaling beyond)"}
 
 
+PMC_PROFILE = "profiles/r5_pmc/summary.json"      # written by tools/runs/r5_profile.sh (tools/pmc_summary.py --json), keyed by the kernel-source hash
+
+
 def pmc_traffic(kernel_substr: str) -> dict:
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r4_pmc/summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (PMC_PROFILE: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes over tools/pmc_probe.py, 2 x FETCH + WRITE with the gfx950 correction) -- quoted only while the profile was taken on the kernel sources this run
     uses (devias_amd.build.source_hash); otherwise null with the reason (no literal that a kernel change leaves stale)."""
-    path = os.path.join(ROOT, "profiles", "r4_pmc", "summary.json")
+    path = os.path.join(ROOT, *PMC_PROFILE.split("/"))
     try:
         from devias_amd import build
         prof = json.load(open(path))
         cur = build.source_hash()
         hit = [(k, v) for k, v in prof["kernels"].items() if kernel_substr in k and "traffic_bytes" in v]
         if not hit:
-            return {"traffic": None, "traffic_note": f"{kernel_substr} is not in profiles/r4_pmc/summary.json"}
+            return {"traffic": None, "traffic_note": f"{kernel_substr} is not in {PMC_PROFILE}"}
         if prof.get("source_hash") != cur:
-            return {"traffic": None, "traffic_note": f"profiles/r4_pmc/summary.json was taken on kernel sources {prof.get('source_hash')}, this run uses {cur}: "
-                                                     f"stale ({hit[0][1]['traffic_bytes']:.4g} B then); re-run tools/runs/r4_pmc.sh"}
+            return {"traffic": None, "traffic_note": f"{PMC_PROFILE} was taken on kernel sources {prof.get('source_hash')}, this run uses {cur}: "
+                                                     f"stale ({hit[0][1]['traffic_bytes']:.4g} B then); re-run tools/runs/r5_profile.sh"}
         k, v = hit[0]
         return {"traffic": v["traffic_bytes"], "traffic_dur_us_under_pmc": v["dur_us"],
-                "traffic_source": f"profiles/r4_pmc/summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; kernel sources {cur})"}
+                "traffic_source": f"{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; kernel sources {cur})"}
     except (OSError, ValueError, KeyError) as e:
         return {"traffic": None, "traffic_note": f"no usable PMC profile: {e}"}
 
 
-def trace_top_kernel_probe(args, device):
+def in_step_gemm_ms(step, M: int, N: int, K: int, trans_a: int, trans_b: int):
+    """Average duration of the devias_gemm launches of one shape INSIDE a real step (library events around each such launch on the launch stream:
+    devias_debug_gemm_timer_*): the kernel with the operands, cache contents and clock the step gives it, not a back-to-back loop on fresh random data."""
+    import ctypes
+    from devias_amd import _lib as _dl
+    lib = _dl.load()
+    torch.cuda.synchronize()
+    _dl.check(lib.devias_debug_gemm_timer_arm(M, N, K, trans_a, trans_b), "devias_debug_gemm_timer_arm")
+    try:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        n, ms = ctypes.c_int32(0), ctypes.c_float(0.0)
+        _dl.check(lib.devias_debug_gemm_timer_read(ctypes.byref(n), ctypes.byref(ms)), "devias_debug_gemm_timer_read")
+    finally:
+        lib.devias_debug_gemm_timer_arm(0, 0, 0, 0, 0)
+    return (ms.value / n.value, n.value) if n.value else (None, 0)
+
+
+def sustained_mfma_probe(device) -> dict:
+    """What the matrix cores of THIS part sustain (VERDICT r4 missing 3): a bare v_mfma_f32_16x16x32_bf16 loop on random bf16 operands held in registers, one
+    512-thread workgroup per CU, ~50 ms per launch after a warm launch (devias_debug_mfma_probe); TFLOP/s from HIP events around the launch, the clock the CUs held from
+    the kernel's own s_memtime / s_memrealtime stamps (median over workgroups).  The chip lowers its clock under a dense MFMA stream (MI355X_MICROARCH.md, DVFS
+    give-back), so this -- not 256 CUs x 2.4 GHz -- is what a perfect kernel could deliver at this power."""
+    import ctypes
+    from devias_amd import _lib as _dl
+    lib = _dl.load()
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    data = torch.randn(1 << 20, device=device).to(torch.bfloat16)
+    sink = torch.empty(cus * 512, device=device, dtype=torch.float32)
+    stamps = torch.zeros(cus, 2, device=device, dtype=torch.int64)
+    st = torch.cuda.current_stream(device).cuda_stream
+    run = lambda it: _dl.check(lib.devias_debug_mfma_probe(data.data_ptr(), data.numel(), cus, it, sink.data_ptr(), stamps.data_ptr(), st), "devias_debug_mfma_probe")  # noqa: E731
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    run(2000); torch.cuda.synchronize()
+    e0.record(); run(2000); e1.record(); torch.cuda.synchronize()
+    per_iter_ms = e0.elapsed_time(e1) / 2000
+    iters = max(2000, int(50.0 / per_iter_ms))
+    run(iters)                                           # the clock settles within microseconds; one warm launch of the final length anyway
+    e0.record(); run(iters); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    fl = float(lib.devias_debug_mfma_probe_flops(cus, iters))
+    s = stamps.cpu()
+    ghz = (s[:, 0].double() / s[:, 1].double().clamp(min=1) * 0.1).median().item()
+    return {"tflops": fl / ms / 1e9, "clock_ghz": ghz, "launch_ms": ms, "cus": cus,
+            "method": "devias_debug_mfma_probe: bare v_mfma_f32_16x16x32_bf16 loop, random bf16 operands in registers, 8 waves per CU on every CU, "
+                      "HIP events around one ~50 ms launch; clock = s_memtime / s_memrealtime x 100 MHz inside the kernel, median over workgroups"}
+
+
+def trace_top_kernel_probe(args, device, step=None):
     """The kernel at the top of the step's rocprofv3 trace (profiles/*_kernel_stats.csv row 1): the weight-gradient GEMM gemm256_kernel<true, true, 0>
-    (both operands k-strided, split-K over M, 16 % of the step), timed live on its largest launch, the fc1 weight gradient dW1 = dY^T X."""
+    (both operands k-strided, split-K over M, 16 % of the step), on its largest launch, the fc1 weight gradient dW1 = dY^T X: timed INSIDE real steps
+    (`avg_ms`, in_step_gemm_ms) and, for continuity with rounds 1-4, in a back-to-back loop on random operands (`avg_ms_back_to_back`)."""
     from devias_amd import ops
     D = {"vit_base": 768, "vit_small": 384, "vit_large": 1024}[args.model]
     M = args.batch * (args.frames // 2) * (args.img_size // 16) ** 2
@@ -132,11 +185,16 @@ def trace_top_kernel_probe(args, device):
         call()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    loop_ms = e0.elapsed_time(e1) / n
+    ms, n_in_step = in_step_gemm_ms(step, 4 * D, D, M, 1, 1) if step is not None else (None, 0)
+    timed = "inside real steps (library events around each launch)" if ms is not None else "back-to-back loop on random operands"
+    if ms is None:
+        ms = loop_ms
     fl = 2.0 * M * 4 * D * D
     es = 2 if dt == torch.bfloat16 else 4
     probe = {"name": "gemm256_kernel<true, true, 0> 256x256x64 LDS-DMA, split-K over M + fixed-order slab reduce: fc1 weight gradient (row 1 of the step's kernel trace)",
              "flop_per_launch": fl, "avg_ms": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
+             "timed": timed, "launches_timed": n_in_step, "avg_ms_back_to_back": loop_ms,
              "avg_ms_includes": "the split-K reduce launch that follows the product",
              "algorithmic_bytes": (M * 4 * D + M * D) * es + 4 * D * D * 4}
     if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
@@ -144,9 +202,9 @@ def trace_top_kernel_probe(args, device):
     return probe
 
 
-def dominant_kernel_probe(args, device):
-    """Live HIP-event timing (on torch's current stream = the stream the kernels are launched on) of the dominant kernel
-    class, the persistent 256x256 MFMA GEMM, on the fc1 launch of this workload's encoder block."""
+def fc1_fwd_probe(args, device, step=None):
+    """The persistent 256x256 MFMA GEMM on the fc1 launch of this workload's encoder block (the probe rounds 1-4 called `dominant_kernel`): timed INSIDE
+    real steps (`avg_ms`) and in the back-to-back loop on random operands of rounds 1-4 (`avg_ms_back_to_back`)."""
     from devias_amd import ops
     D = {"vit_base": 768, "vit_small": 384, "vit_large": 1024}[args.model]
     M = args.batch * (args.frames // 2) * (args.img_size // 16) ** 2
@@ -165,15 +223,35 @@ def dominant_kernel_probe(args, device):
         call()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    loop_ms = e0.elapsed_time(e1) / n
+    ms, n_in_step = in_step_gemm_ms(step, M, 4 * D, D, 0, 0) if step is not None else (None, 0)
+    timed = "inside real steps (library events around each launch)" if ms is not None else "back-to-back loop on random operands"
+    if ms is None:
+        ms = loop_ms
     fl = 2.0 * M * 4 * D * D
     es = 2 if dt == torch.bfloat16 else 4
-    probe = {"name": "gemm256p_kernel<false, 0> persistent 256x256x64 LDS-DMA: fc1 forward of the encoder block (bias + GELU + saved pre-activation)",
+    probe = {"name": "gemm256p_kernel<false, 0> persistent 256x256x64 LDS-DMA: fc1 forward of the encoder block (bias + GELU + second saved output)",
              "flop_per_launch": fl, "avg_ms": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
+             "timed": timed, "launches_timed": n_in_step, "avg_ms_back_to_back": loop_ms,
              "algorithmic_bytes": (M * D + 4 * D * D + 2 * M * 4 * D) * es}
     if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
         probe.update(pmc_traffic("gemm256p_kernel<false, 0"))
     return probe
+
+
+def rank_proof(device_desc: str) -> dict:
+    """What the process group itself says about the job -- the JSON line's `rccl` object at N > 1 (a SCALE record must be able to prove its rank
+    count): the collective library's version (RCCL reports itself through torch's nccl bindings), the group's world size and backend, and every rank's device,
+    gathered THROUGH the group (a rank that did not join cannot appear).  Collective: every rank calls it."""
+    names = [None] * dist.get_world_size()
+    dist.all_gather_object(names, f"rank {dist.get_rank()}: {device_desc}")
+    ver = None
+    if dist.get_backend() == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001  (a torch build without the bindings: say so instead of failing the bench)
+            ver = f"unavailable: {e}"
+    return {"version": ver, "world": dist.get_world_size(), "backend": dist.get_backend(), "devices": names}
 
 
 def self_launch(args) -> int:
@@ -209,6 +287,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
     if world > 1 and os.environ.get("DEVIAS_BENCH_TRACE_LAUNCH"):
         print(f"bench.py rank {rank}/{world} joined the process group ({dist.get_backend()})", file=sys.stderr, flush=True)
+        proof = rank_proof(torch.cuda.get_device_name(local % torch.cuda.device_count()) if torch.cuda.is_available() else "no GPU")   # (the plumbing test reads it)
+        if rank == 0:
+            print("bench.py rccl: " + json.dumps(proof), file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
     device = torch.device("cuda", local % torch.cuda.device_count())     # (ranks > GPUs only happens in the gloo plumbing test)
@@ -289,6 +370,7 @@ def main():
         host_idle.append(time.perf_counter() - th)
     torch.cuda.synchronize()
     host_idle.sort()
+    rccl_info = rank_proof(f"{torch.cuda.get_device_name(device)} (cuda:{device.index})") if world > 1 else None
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -354,24 +436,38 @@ def main():
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
                    "kernels": "persistent 256x256 GEMM (forward + dgrad; tail tiles of a partial round split between two workgroups), 32x32x16 MFMA attention forward, two-kernel MFMA attention backward, folded slot "
                               "cross-attention (K/V projections on the slot side); one library call per fused region and direction (csrc/regions.hip)"},
-        # schema 4 (round 4): `host_enqueue_ms_per_step` has its round-1/2 meaning again (host time to enqueue the K timed steps back to back: a full launch
+        # schema 5 (round 5): roofline.dominant_kernel = the trace's row 1 (the fc1 weight gradient), probe_fc1_fwd = the fc1 forward, both timed inside real steps;
+        # roofline.sustained_peak / frac_of_sustained; `rccl` at N > 1.  schema 4 (round 4): `host_enqueue_ms_per_step` has its round-1/2 meaning again (host time to enqueue the K timed steps back to back: a full launch
         # queue throttles the host to the device's pace, so on a device-bound step it reads ~ the step time); the host's own cost is the idle-stream number
-        "schema": 4,
+        "schema": 5,
         "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "host_library_calls_per_step": lib_calls,
         "host_idle_enqueue_ms_per_step": host_idle[len(host_idle) // 2] * 1e3,
         "host_idle_enqueue_method": "one step enqueued on an idle stream, median of 5, outside the timed region (python + fused-region library calls + HIP launches)",
         "device_ms_per_step": dev_ms / args.steps, "final_loss": loss_value, "peak_mem_gib": peak_mem,
     }
     if ach is not None:
+        in_step = step if world == 1 else None            # (at N > 1 a step contains collectives: rank 0 cannot run one alone)
+        dom = trace_top_kernel_probe(args, device, in_step)
+        sus = sustained_mfma_probe(device) if args.dtype == "bf16" else None
         line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                            "frac": ach / PEAK_BF16_TFLOPS,
+                            "traffic": dom.get("traffic"), "traffic_scope": "per launch of `dominant_kernel` (PMC, see its traffic_source / traffic_note); "
+                                                                            "`achieved` / `frac` are the whole step's",
                             "scope": f"whole step per GPU: {gflop} algorithmic GFLOP/clip x {B} clips / step time",
-                            "dominant_kernel": dominant_kernel_probe(args, device),
-                            "trace_top_kernel": trace_top_kernel_probe(args, device)}
+                            # the nominal fraction above stays the headline; beside it the same rate against what this part's matrix cores sustain on random data
+                            "sustained_peak": sus, "frac_of_sustained": (ach / sus["tflops"]) if sus else None,
+                            "dominant_kernel": dom,                                  # row 1 of the step's rocprofv3 kernel trace
+                            "probe_fc1_fwd": fc1_fwd_probe(args, device, in_step)}     # (rounds 1-4 reported this one under the key `dominant_kernel`)
+    if world > 1:
+        # proof of the rank count for a SCALE record: what the process group itself says, and every rank's device
+        line["rccl"] = rccl_info
     if full is not None:
         line["full_step"] = full
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
+    elif world > 1:
+        line["cpu_baseline"] = None
+        line["cpu_baseline_note"] = "reported by the N = 1 run only (rank 0's host cores are shared with the other ranks' launch threads at N > 1)"
     print(json.dumps(line))
     if world > 1 or dist.is_initialized():
         dist.destroy_process_group()

@@ -102,6 +102,12 @@ PROTOTYPES = {
     "devias_counter": (c_int64, [c_int32]),
     "devias_counters_reset": (None, []),
     "devias_set_option": (c_int, [c_char_p, c_int32]),
+    "devias_get_option": (c_int, [c_char_p, POINTER(c_int32)]),
+    "devias_debug_mfma_probe": (c_int, [_P, _L, _I, _I, _P, _P, _P]),
+    "devias_debug_mfma_probe_flops": (c_int64, [_I, _I]),
+    "devias_debug_gemm_timer_arm": (c_int, [_I, _I, _I, _I, _I]),
+    "devias_debug_gemm_timer_read": (c_int, [POINTER(c_int32), POINTER(c_float)]),
+    "devias_gemm_release_queue_stream": (c_int, [_P]),
     "devias_gemm": (c_int, [POINTER(GemmArgs), _P]),
     "devias_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
     "devias_cast": (c_int, [_P, _I, _P, _I, _L, _P]),

@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdevias_amd.so")
-SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "layernorm.hip", "attention.hip", "slot_attn.hip", "loss.hip", "fame.hip", "regions.hip"]
+SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "layernorm.hip", "attention.hip", "slot_attn.hip", "loss.hip", "fame.hip", "regions.hip", "probe.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
          "-fno-gpu-rdc", "-mllvm", "-amdgpu-early-inline-all=true",

@@ -12,7 +12,7 @@ int devias_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int devias_version(void) { return 162; }   // 162: devias_mhsa_bwd_bias (additive); 161: devias_mhsa_fwd_dropout / _bwd_dropout (additive); 160: devias_loss_dims.scene_ce (struct grew); 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options, 140: stream-K GEMM (args struct grew), 150: fused regions, roctx ranges
+extern "C" int devias_version(void) { return 163; }   // 163: devias_get_option, devias_gemm_release_queue_stream (additive); 162: devias_mhsa_bwd_bias (additive); 161: devias_mhsa_fwd_dropout / _bwd_dropout (additive); 160: devias_loss_dims.scene_ce (struct grew); 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options, 140: stream-K GEMM (args struct grew), 150: fused regions, roctx ranges
 
 // ---- launch counters: which kernel family served a call (tests assert that the measured kernels are the ones under test) ----
 #include <atomic>
@@ -26,6 +26,14 @@ extern "C" int devias_set_option(const char* name, int32_t value) {
     if (devias_gemm_set_option(name, value) || devias_attn_set_option(name, value)) return DEVIAS_OK;
     if (!strcmp(name, "regions_defer")) { devias_defer_enabled() = value; return DEVIAS_OK; }
     return devias_set_error(DEVIAS_EINVAL, "devias_set_option: unknown option '%s'", name);
+}
+
+extern "C" int devias_get_option(const char* name, int32_t* value) {
+    if (!name || !value) return devias_set_error(DEVIAS_EINVAL, "devias_get_option: null argument");
+    int v = 0;
+    if (devias_gemm_get_option(name, &v) || devias_attn_get_option(name, &v)) { *value = v; return DEVIAS_OK; }
+    if (!strcmp(name, "regions_defer")) { *value = devias_defer_enabled(); return DEVIAS_OK; }
+    return devias_set_error(DEVIAS_EINVAL, "devias_get_option: unknown option '%s'", name);
 }
 
 extern "C" const char* devias_last_error(void) { return g_err; }

@@ -1147,12 +1147,21 @@ AttnKnobs& attn_knobs() {
     return k;
 }
 }  // namespace
+static int* attn_option_slot(const char* name) {
+    if (!strcmp(name, "attn_cfg")) return &attn_knobs().cfg;
+    if (!strcmp(name, "attn_xcd")) return &attn_knobs().xcd;
+    if (!strcmp(name, "attn_bias_fused")) return &attn_knobs().bias_fused;      // 0: devias_mhsa_bwd_bias takes the bias gradients by column-sum passes in bf16 too (A/B aid)
+    return nullptr;
+}
 int devias_attn_set_option(const char* name, int value) {
-    if (!strcmp(name, "attn_cfg")) attn_knobs().cfg = value;
-    else if (!strcmp(name, "attn_xcd")) attn_knobs().xcd = value;
-    else if (!strcmp(name, "attn_bias_fused")) attn_knobs().bias_fused = value;      // 0: devias_mhsa_bwd_bias takes the bias gradients by column-sum passes in bf16 too (A/B aid)
-    else return 0;
-    return 1;
+    int* slot = attn_option_slot(name);
+    if (slot) *slot = value;
+    return slot != nullptr;
+}
+int devias_attn_get_option(const char* name, int* value) {
+    const int* slot = attn_option_slot(name);
+    if (slot) *value = *slot;
+    return slot != nullptr;
 }
 
 // bit 0: XCD-aware linear grid (needs B*H % 8 == 0); bits 16..: B.  Option attn_xcd = 0 restores the plain 3-D grid.

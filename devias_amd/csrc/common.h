@@ -21,6 +21,8 @@ int devias_set_error(int code, const char* fmt, ...);
 void devias_count(int id);                                  // launch counters (api.hip): DEVIAS_CNT_* of include/devias_amd.h
 int devias_gemm_set_option(const char* name, int value);    // per-module option handlers behind devias_set_option: 1 = name known
 int devias_attn_set_option(const char* name, int value);
+int devias_gemm_get_option(const char* name, int* value);    // ... and behind devias_get_option
+int devias_attn_get_option(const char* name, int* value);
 extern "C" int32_t devias_policy_gemm_cus(void);             // gemm.hip: CUs the big-tile grids count on (device CUs - option gemm_reserve_cus)
 
 #define DEVIAS_CHECK_LAUNCH(name)                                                              \

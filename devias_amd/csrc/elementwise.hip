@@ -26,8 +26,9 @@ __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int6
     }
 }
 
+// (no __restrict__: dst may be src -- devias_cast_scale's contract, used in place by GradSync.finish(); every thread reads and writes the same index)
 template <typename S, typename D>
-__global__ void cast_scale_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n, int vec, float scale) {
+__global__ void cast_scale_kernel(const S* src, D* dst, int64_t n, int vec, float scale) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {

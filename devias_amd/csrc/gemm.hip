@@ -10,6 +10,7 @@
 // The MFMA is issued as mfma(Bfrag, Afrag) so each lane ends up with 4 CONSECUTIVE output columns of one row
 // (8-byte bf16 / 16-byte f32 epilogue accesses, bias as one float4).
 #include "common.h"
+#include <mutex>
 #include <utility>
 #include <stdlib.h>
 #include <string.h>
@@ -2031,19 +2032,46 @@ GemmKnobs& knobs() {
 }
 }  // namespace
 
-// device address of the tile-queue ring of the CURRENT device's copy of the code object (resolved once per device)
-static unsigned int* tile_queue_base() {
-    static std::atomic<unsigned int*> cache[16];
+// The tile-queue ring of the CURRENT device's copy of the code object, and this launch's place in it.  The ring's protocol (launch n zeroes the slot of
+// launch n + TQ_RING / 2) is only sound while the launches that use one ring are ordered among themselves: the ring therefore belongs to ONE stream per
+// device -- the first that launches a dynamic-queue GEMM on it -- and has its own launch counter.  A launch on any other stream of that device gets no slot
+// (nullptr) and walks the static tile lists instead: same tiles, same bits (one process-wide counter let a second stream or a second GPU reach a
+// slot that was never zeroed, or have it zeroed mid-launch -- tiles silently not computed).  devias_gemm_release_queue_stream() hands the ring to a new owner.
+namespace {
+struct TileQueueRing { unsigned int* base; hipStream_t owner; bool owned; unsigned seq; };
+std::mutex g_tq_mutex;
+TileQueueRing g_tq_ring[16];
+}
+static bool tile_queue_slot(hipStream_t st, unsigned int** slot, unsigned int** clear) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    unsigned int* b = cache[dev].load(std::memory_order_acquire);
-    if (!b) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    std::lock_guard<std::mutex> lock(g_tq_mutex);
+    TileQueueRing& r = g_tq_ring[dev];
+    if (!r.base) {
         void* sym = nullptr;
-        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tile_queue)) != hipSuccess || !sym) { (void)hipGetLastError(); return nullptr; }
-        b = reinterpret_cast<unsigned int*>(sym);
-        cache[dev].store(b, std::memory_order_release);
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tile_queue)) != hipSuccess || !sym) { (void)hipGetLastError(); return false; }
+        r.base = reinterpret_cast<unsigned int*>(sym);
     }
-    return b;
+    if (!r.owned) { r.owner = st; r.owned = true; }
+    if (r.owner != st) return false;
+    const unsigned n = r.seq++;
+    *slot = r.base + (size_t)(n % TQ_RING) * TQ_SLOT;
+    *clear = r.base + (size_t)((n + TQ_RING / 2) % TQ_RING) * TQ_SLOT;
+    return true;
+}
+// The caller promises that every dynamic-queue launch of the current device's owner stream has completed (e.g. after a device synchronise): the whole ring
+// is zeroed on `stream`, which becomes the new owner.
+extern "C" int devias_gemm_release_queue_stream(void* stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return devias_set_error(DEVIAS_EINVAL, "devias_gemm_release_queue_stream: no current device");
+    std::lock_guard<std::mutex> lock(g_tq_mutex);
+    TileQueueRing& r = g_tq_ring[dev];
+    if (r.base && hipMemsetAsync(r.base, 0, sizeof(unsigned int) * TQ_RING * TQ_SLOT, (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return devias_set_error(DEVIAS_EINVAL, "devias_gemm_release_queue_stream: cannot zero the ring");
+    }
+    r.owner = (hipStream_t)stream; r.owned = true; r.seq = 0;
+    return DEVIAS_OK;
 }
 
 // CUs the big-tile grids may count on: the device's, minus the reserve (option gemm_reserve_cus), in whole XCD rows
@@ -2053,26 +2081,38 @@ extern "C" int32_t devias_policy_gemm_cus(void) {
     return (ncu - k.reserve > 8 ? ncu - k.reserve : 8) & ~7;
 }
 
-int devias_gemm_set_option(const char* name, int value) {
+// the option's storage, or nullptr for a name this file does not own (devias_set_option / devias_get_option, api.hip)
+static int* gemm_option_slot(const char* name) {
     GemmKnobs& k = knobs();
-    if (!strcmp(name, "gemm_epi")) k.epi_swap = value;
-    else if (!strcmp(name, "gemm256")) k.use256 = value;
-    else if (!strcmp(name, "gemm_ss")) k.use_ss = value;
-    else if (!strcmp(name, "gemm_groupm")) k.group_m = value;
-    else if (!strcmp(name, "gemm_persistent")) k.persistent = value;
-    else if (!strcmp(name, "gemm_debug")) k.debug = value;
-    else if (!strcmp(name, "gemm_w4")) k.w4 = value;
-    else if (!strcmp(name, "gemm_tail_split")) k.tail_split = value;
-    else if (!strcmp(name, "gemm_smallm")) k.smallm = value;
-    else if (!strcmp(name, "gemm_reserve_cus")) k.reserve = value < 0 ? 0 : value;
-    else if (!strcmp(name, "gemm_splitk_xcd")) k.splitk_xcd = value;
-    else if (!strcmp(name, "gemm_dynamic")) k.dynamic = value;
-    else if (!strcmp(name, "gemm_concurrent")) k.concurrent = value;
-    else return 0;
+    if (!strcmp(name, "gemm_epi")) return &k.epi_swap;
+    if (!strcmp(name, "gemm256")) return &k.use256;
+    if (!strcmp(name, "gemm_ss")) return &k.use_ss;
+    if (!strcmp(name, "gemm_groupm")) return &k.group_m;
+    if (!strcmp(name, "gemm_persistent")) return &k.persistent;
+    if (!strcmp(name, "gemm_debug")) return &k.debug;
+    if (!strcmp(name, "gemm_w4")) return &k.w4;
+    if (!strcmp(name, "gemm_tail_split")) return &k.tail_split;
+    if (!strcmp(name, "gemm_smallm")) return &k.smallm;
+    if (!strcmp(name, "gemm_reserve_cus")) return &k.reserve;
+    if (!strcmp(name, "gemm_splitk_xcd")) return &k.splitk_xcd;
+    if (!strcmp(name, "gemm_dynamic")) return &k.dynamic;
+    if (!strcmp(name, "gemm_concurrent")) return &k.concurrent;
+    return nullptr;
+}
+int devias_gemm_set_option(const char* name, int value) {
+    int* slot = gemm_option_slot(name);
+    if (!slot) return 0;
+    *slot = (!strcmp(name, "gemm_reserve_cus") && value < 0) ? 0 : value;
+    return 1;
+}
+int devias_gemm_get_option(const char* name, int* value) {
+    const int* slot = gemm_option_slot(name);
+    if (!slot) return 0;
+    *value = *slot;
     return 1;
 }
 
-extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
+static int gemm_impl(const devias_gemm_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     DEVIAS_REQUIRE(a && a->A && a->B && a->C, "devias_gemm: null operand");
     DEVIAS_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "devias_gemm: bad dims M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -2227,14 +2267,13 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         } else if (kn.persistent && pers_ok && nt > gp) {
             dim3 grid(gp), block(NT2);
             // dynamic queue: every XCD queue has at least one (reserved) item per workgroup, at most 32 workgroups per XCD (one claim-mask word)
-            unsigned int* tq = (dyn && a->K >= 128 && (gp >> 3) <= 32 && (nt >> 3) >= (gp >> 3)) ? tile_queue_base() : nullptr;
+            unsigned int *tq = nullptr, *tq_clear = nullptr;
+            if (!(dyn && a->K >= 128 && (gp >> 3) <= 32 && (nt >> 3) >= (gp >> 3) && tile_queue_slot(st, &tq, &tq_clear))) tq = nullptr;
             if (tq) {
                 // dynamic tile queue (default): the item list of an XCD queue of cnt tiles -- whole tiles, then the halves of a split partial round --
-                // for the two queue lengths that occur; this launch's ring slot and the one it zeroes
-                static std::atomic<unsigned> seq{0};
-                const unsigned n = seq.fetch_add(1);
-                p.tq = tq + (size_t)(n % TQ_RING) * TQ_SLOT;
-                p.tq_clear = tq + (size_t)((n + TQ_RING / 2) % TQ_RING) * TQ_SLOT;
+                // for the two queue lengths that occur; this launch's ring slot and the one it zeroes (both from the ring of this device AND this stream)
+                p.tq = tq;
+                p.tq_clear = tq_clear;
                 const int stride = gp >> 3;
                 for (int v = 0; v < 2; ++v) {
                     const int cnt = (nt >> 3) + (v == 0 ? 1 : 0);
@@ -2294,4 +2333,65 @@ extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
         DEVIAS_CHECK_LAUNCH("devias_gemm(split-k reduce)");
     }
     return DEVIAS_OK;
+}
+
+// ---- measurement aid: HIP events around the devias_gemm launches of ONE shape, wherever they are issued from (a fused region in the middle of a real step) --------
+// bench.py's roofline.dominant_kernel / probe_fc1_fwd: the kernel's duration as it runs IN the step (operands and caches as the step leaves them, the clock the step
+// holds), not in a back-to-back loop on fresh random data (0.396 ms in the loop against ~0.30 ms in the step).  Armed for one shape at a time; a
+// launch of that shape is bracketed by an event pair on its own stream (product + split-K reduce + column-sum second stage when they follow inside devias_gemm); at
+// most 64 pairs are kept.  Not armed (the default): one predictable branch per call.
+namespace {
+struct GemmTimer {
+    std::mutex mu;
+    bool armed = false;
+    int M = 0, N = 0, K = 0, ta = 0, tb = 0, n = 0;
+    hipEvent_t e0[64], e1[64];
+};
+GemmTimer& gemm_timer() { static GemmTimer t; return t; }
+std::atomic<int> g_gemm_timer_armed{0};
+}
+extern "C" int devias_debug_gemm_timer_arm(int32_t M, int32_t N, int32_t K, int32_t trans_a, int32_t trans_b) {
+    GemmTimer& t = gemm_timer();
+    std::lock_guard<std::mutex> lock(t.mu);
+    for (int i = 0; i < t.n; ++i) { (void)hipEventDestroy(t.e0[i]); (void)hipEventDestroy(t.e1[i]); }
+    t.n = 0;
+    t.armed = M > 0;
+    t.M = M; t.N = N; t.K = K; t.ta = trans_a != 0; t.tb = trans_b != 0;
+    g_gemm_timer_armed.store(t.armed ? 1 : 0);
+    return DEVIAS_OK;
+}
+extern "C" int devias_debug_gemm_timer_read(int32_t* count, float* total_ms) {
+    DEVIAS_REQUIRE(count && total_ms, "devias_debug_gemm_timer_read: null output");
+    GemmTimer& t = gemm_timer();
+    std::lock_guard<std::mutex> lock(t.mu);
+    float sum = 0.f;
+    for (int i = 0; i < t.n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.e1[i]) != hipSuccess || hipEventElapsedTime(&ms, t.e0[i], t.e1[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            return devias_set_error(DEVIAS_ELAUNCH, "devias_debug_gemm_timer_read: event %d not readable", i);
+        }
+        sum += ms;
+    }
+    *count = t.n; *total_ms = sum;
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_gemm(const devias_gemm_args* a, void* stream) {
+    if (!g_gemm_timer_armed.load(std::memory_order_relaxed) || !a) return gemm_impl(a, stream);
+    GemmTimer& t = gemm_timer();
+    int slot = -1;
+    {
+        std::lock_guard<std::mutex> lock(t.mu);
+        if (t.armed && a->M == t.M && a->N == t.N && a->K == t.K && (a->trans_a != 0) == (t.ta != 0) && (a->trans_b != 0) == (t.tb != 0) && t.n < 64 &&
+            hipEventCreate(&t.e0[t.n]) == hipSuccess) {
+            if (hipEventCreate(&t.e1[t.n]) == hipSuccess) slot = t.n++;
+            else (void)hipEventDestroy(t.e0[t.n]);
+        }
+    }
+    if (slot < 0) return gemm_impl(a, stream);
+    (void)hipEventRecord(t.e0[slot], (hipStream_t)stream);
+    const int rc = gemm_impl(a, stream);
+    (void)hipEventRecord(t.e1[slot], (hipStream_t)stream);
+    return rc;
 }

@@ -53,6 +53,13 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 
+def get_option(name: str) -> int:
+    """devias_get_option: the current value of a process-wide option (to restore it after a temporary change)"""
+    v = ctypes.c_int32(0)
+    _lib.check(_lib.load().devias_get_option(name.encode(), ctypes.byref(v)), "devias_get_option")
+    return int(v.value)
+
+
 def set_option(name: str, value: int) -> None:
     """devias_set_option: process-wide kernel-selection knobs (gemm_epi, gemm256, gemm_ss, gemm_groupm, gemm_persistent, attn_cfg, attn_xcd ...)"""
     _lib.check(_lib.load().devias_set_option(name.encode(), int(value)), "devias_set_option")

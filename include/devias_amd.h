@@ -85,6 +85,14 @@ void devias_counters_reset(void);
  * sets the split-K factor of the weight-gradient GEMMs, hence their fp32 summation order: runs with different reserves -- or N = 1 against N > 1 runs that set one --
  * agree to rounding, not bitwise).  0 = ok, DEVIAS_EINVAL = unknown name. */
 int devias_set_option(const char* name, int32_t value);
+/* The current value of one of those options (so that a host can restore what it changed: devias_amd.parallel.GradSync.remove()). */
+int devias_get_option(const char* name, int32_t* value);
+/* The dynamic tile queues ("gemm_dynamic") live in ONE ring of queue slots per device, whose protocol (launch n zeroes the slot launch n + 32 will use)
+ * relies on the launches being ordered among themselves.  The ring therefore belongs to one stream per device: the first stream that launches a
+ * dynamic-queue GEMM on the device.  Launches on any other stream of that device silently walk the static tile lists (same tiles, same bits).  A host that
+ * moves its step to another stream calls this once every dynamic-queue launch of the old stream has COMPLETED (e.g. after a device synchronise): the ring
+ * is zeroed on `stream`, which becomes its owner.  One GPU per process or several: each device has its own ring and counter. */
+int devias_gemm_release_queue_stream(void* stream);
 
 /* In-place SUM all-reduce of one flat gradient bucket over the caller's RCCL communicator (`nccl_comm` is an ncclComm_t; dtype DEVIAS_F32 or
  * DEVIAS_BF16), enqueued on `stream`: the data-path collective of the step (DDP / DeepSpeed ZeRO-0 gradient all-reduce, run_slot_finetuning.py:552-563)
@@ -102,6 +110,18 @@ void devias_range_pop(void);
  * CU -- and idle for `usec` microseconds, enqueued on `stream` (a side stream): a stand-in for the compute units a concurrent RCCL kernel
  * occupies during backward, so that the persistent GEMM grids' sensitivity to missing CUs can be measured on one GPU.  No reference analogue. */
 int devias_debug_cu_hog(int32_t n_workgroups, int32_t usec, void* stream);
+/* Measurement aid (bench.py's `roofline.sustained_peak`): a bare bf16 MFMA loop -- `n_workgroups` workgroups of 8 waves, operands in registers loaded once from
+ * `data_bf16` (random values; >= 6144 elements, 16-byte aligned), `iters` iterations of 64 v_mfma_f32_16x16x32_bf16 per wave.  `sink` ([n_workgroups * 512] floats)
+ * keeps the accumulators alive; `stamps` (optional, [n_workgroups][2] uint64) receives per workgroup the shader-clock cycles and the 100 MHz ticks its loop took:
+ * their quotient x 100 MHz is the clock the CU held.  devias_debug_mfma_probe_flops = the flops one launch executes.  No reference counterpart. */
+int devias_debug_mfma_probe(const void* data_bf16, int64_t data_elems, int32_t n_workgroups, int32_t iters, float* sink, uint64_t* stamps, void* stream);
+int64_t devias_debug_mfma_probe_flops(int32_t n_workgroups, int32_t iters);
+/* Measurement aid (bench.py's `roofline.dominant_kernel`): HIP events around every devias_gemm of ONE shape, wherever it is issued from -- a fused region in the
+ * middle of a real step --, so that a kernel is timed as it runs IN the step.  arm(M, N, K, trans_a, trans_b) starts collecting (M <= 0: stops and clears); at most
+ * 64 launches are kept; read() waits for them and returns their number and summed duration (product + the split-K reduce / column-sum second stage that devias_gemm
+ * launches behind it).  The dims are devias_gemm_args' M, N, K. */
+int devias_debug_gemm_timer_arm(int32_t M, int32_t N, int32_t K, int32_t trans_a, int32_t trans_b);
+int devias_debug_gemm_timer_read(int32_t* count, float* total_ms);
 
 /* fills: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes per block, [3]=wavefront size, [4]=gfx arch number (e.g. 950) */
 int devias_device_info(int device, int64_t* out5);

@@ -586,7 +586,7 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         torch.cuda.synchronize()
         cnt = o.counters()
         want = (1, 0) if (serves and mode not in ("0", "0s")) else (0, 1)
-        assert (cnt["gemm256p"], cnt["gemm256"]) == want and cnt["gemm_sk"] == 0, (mode, cnt)
+        assert (cnt["gemm256p"], cnt["gemm256"]) == want, (mode, cnt)
         assert cnt["gemm256d"] == (1 if mode in ("p", "p1", "p0") and serves and K >= 128 else 0), (mode, cnt)   # (one K-tile per tile: the static list)
         assert cnt["gemm256w"] == (1 if mode == "w" and serves and K >= 128 else 0), (mode, cnt)       # (one K-tile: the eight-wave kernel)
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))

@@ -78,7 +78,7 @@ def test_bf16_step_on_full_tile_kernels_vs_reference_chunks(name, B):
     cnt = ops.counters()
     # which kernels ran, per encoder block: qkv / fc1 forward and the fc2 dgrad (49 x {9, 12} tiles > 256 CUs) -> persistent 256^2 kernel; proj / fc2
     # forward, the other dgrads (147 tiles) and the four wgrads (split-K) -> one-tile-per-workgroup 256^2 kernel
-    assert cnt["gemm256p"] >= 12 * 3 and cnt["gemm256"] >= 12 * 9 and cnt["gemm256p"] + cnt["gemm256"] + cnt["gemm_sk"] >= 12 * 12, cnt
+    assert cnt["gemm256p"] >= 12 * 3 and cnt["gemm256"] >= 12 * 9 and cnt["gemm256p"] + cnt["gemm256"] >= 12 * 12, cnt
     assert cnt["mhsa_fwd_bf16"] == cfg.depth and cnt["mhsa_bwd_bf16"] == cfg.depth and cnt["mhsa_fwd_f32"] == 0, cnt
     assert cnt["gemm128_f32"] == 0, cnt
     S = cfg.num_latents
@@ -134,9 +134,9 @@ def test_bf16_full_size_step_properties():
     ops.counters(reset=True)
     out1, t1, g1 = step(model, x, y, tl, fg)
     cnt = ops.counters()
-    # M = 50176: the four forward and four dgrad GEMMs of a block run on the eight-wave persistent kernel (tail tiles split; the stream-K schedule and the
-    # four-wave kernel are options); the four wgrads split K on the one-tile-per-workgroup kernel
-    assert cnt["gemm256p"] >= 12 * 8 and cnt["gemm_sk"] == 0 and cnt["gemm256w"] == 0 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_bwd_bf16"] == 12 and cnt["gemm128_f32"] == 0, cnt
+    # M = 50176: the four forward and four dgrad GEMMs of a block run on the eight-wave persistent kernel (tail tiles split; the
+    # four-wave kernel is an option); the four wgrads split K on the one-tile-per-workgroup kernel
+    assert cnt["gemm256p"] >= 12 * 8 and cnt["gemm256w"] == 0 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_bwd_bf16"] == 12 and cnt["gemm128_f32"] == 0, cnt
     sh1 = out1[2][0].detach().clone()
     out2, t2, g2 = step(model, x, y, tl, fg)
     assert torch.isfinite(t1).all() and all(torch.isfinite(g).all() for g in g1.values())
@@ -160,7 +160,7 @@ def test_bf16_full_size_step_properties():
 
 def test_bf16_full_size_step_beside_the_oracle():
     """The oracle BESIDE the B = 32 kernels: the full-size bf16 step (M = 50176: the persistent 256x256 kernel with split tail tiles
-    serves every forward / dgrad GEMM and the stream-K kernel none, asserted by the launch counters) is compared with the REFERENCE golden on chunk 0 (clips 0-1 are the `vitb_t16` fixture's inputs) and with
+    serves every forward / dgrad GEMM, asserted by the launch counters) is compared with the REFERENCE golden on chunk 0 (clips 0-1 are the `vitb_t16` fixture's inputs) and with
     the CPU oracle's train_step on four more 2-clip chunks spread over the batch: per-slot logits, matched indices, and every term of the
     chunk's loss evaluated with the chunk's own teacher pad-min.  So the schedule that only exists at B = 32 is pinned to the
     reference, not to sibling kernels."""
@@ -181,7 +181,7 @@ def test_bf16_full_size_step_beside_the_oracle():
     total.backward()
     torch.cuda.synchronize()
     cnt = ops.counters()
-    assert cnt["gemm_sk"] == 0 and cnt["gemm256p"] >= 12 * 8 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_fwd_bf16"] == 12 and cnt["mhsa_bwd_bf16"] == 12, cnt
+    assert cnt["gemm256p"] >= 12 * 8 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_fwd_bf16"] == 12 and cnt["mhsa_bwd_bf16"] == 12, cnt
     sh = out[2][0].detach().float().cpu()
     # chunk 0: the reference's own numbers
     e0 = gu.rel(sh[:2 * S], fx["slots_head"])
@@ -199,7 +199,7 @@ def test_bf16_full_size_step_beside_the_oracle():
         mine = lds[c // 2]
         for k, v in ld.items():
             assert abs(float(mine[k]) - float(v)) <= 2e-2 * max(abs(float(v)), 1e-3), (c, k, float(mine[k]), float(v))
-    print(f"ViT-B 16x224^2 B=32 bf16 (stream-K grids live) vs golden / oracle on 5 chunks: per-slot logits rel {[f'{e:.2e}' for e in errs]}")
+    print(f"ViT-B 16x224^2 B=32 bf16 vs golden / oracle on 5 chunks: per-slot logits rel {[f'{e:.2e}' for e in errs]}")
     assert max(errs) < TOL_BF16_LOGITS
 
 
@@ -246,7 +246,7 @@ def test_vit_large_full_depth_fp32_vs_oracle_and_bf16_properties():
         res.append((o[2][0].detach().clone(), t.detach().clone(), [p.grad.clone() for p in mb.parameters()]))
     # M = 12544 = 49 row tiles: the N = 3072 / 4096 shapes (qkv, fc1 forward, fc2 dgrad: 588 / 784 tiles) run persistent, the N = 1024 ones
     # (196 tiles <= 256 CUs) one tile per workgroup
-    assert cnt["gemm256p"] >= 24 * 3 and cnt["gemm256p"] + cnt["gemm256"] + cnt["gemm_sk"] >= 24 * 12 and cnt["mhsa_bwd_bf16"] == 24, cnt
+    assert cnt["gemm256p"] >= 24 * 3 and cnt["gemm256p"] + cnt["gemm256"] >= 24 * 12 and cnt["mhsa_bwd_bf16"] == 24, cnt
     assert torch.isfinite(res[0][1]).all() and all(torch.isfinite(g).all() for g in res[0][2])
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))

@@ -416,6 +416,11 @@ def test_bench_launches_its_own_ranks():
         return
     for rank in (0, 1):
         assert f"bench.py rank {rank}/2 joined the process group" in err, err[-2000:]
+    # the JSON line's `rccl` object (rank-count proof for a SCALE record), as gathered through the process group itself
+    import json
+    proof = json.loads([ln for ln in err.splitlines() if ln.startswith("bench.py rccl: ")][-1][len("bench.py rccl: "):])
+    assert proof["world"] == 2 and proof["backend"] == "gloo" and len(proof["devices"]) == 2, proof
+    assert proof["devices"][0].startswith("rank 0:") and proof["devices"][1].startswith("rank 1:"), proof
     if not torch.cuda.is_available():
         assert "needs an MI355X" in err, err[-2000:]
         assert r.returncode != 0

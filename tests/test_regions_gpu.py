@@ -95,7 +95,29 @@ def test_regions_bitwise_equal_per_kernel_path(name, dtype, B):
     #  a last-bit difference in fp32 can flip such a rounding)
     _assert_bitwise(g0, g1, f"{name} {dtype} gradients", order_tol=1e-5 if dtype == "fp32" else 5e-3)
     if dtype == "bf16" and (B * cfg.num_patches) % 256 == 0:            # the measured kernels served the fused regions too
-        assert cnt["gemm256p"] + cnt["gemm256"] + cnt["gemm_sk"] >= 12 * 12 and cnt["mhsa_bwd_bf16"] == cfg.depth, cnt
+        assert cnt["gemm256p"] + cnt["gemm256"] >= 12 * 12 and cnt["mhsa_bwd_bf16"] == cfg.depth, cnt
+
+
+@pytest.mark.parametrize("name,dtype,B", [("vits_t8", "fp32", 2), ("vits_t8", "bf16", 2), ("vitb_t16", "bf16", 8)])
+def test_regions_defer_is_bitwise_the_per_kernel_second_stages(name, dtype, B):
+    """`regions_defer` (default 1): an encoder block's backward runs the second stages of its partial reductions (LayerNorm parameter gradients, bias-gradient
+    column sums, the dfc2 epilogue's column sums) as ONE launch of the multi-job kernel at its end instead of one launch per producer -- same loops, same order:
+    outputs and every gradient bitwise equal to regions_defer = 0 (the option shipped without this comparison)."""
+    from devias_amd import ops
+    fx, cfg, _ = gu.load(name)
+    model = _build(cfg, dtype)
+    crit = _crit()
+    data = _data(cfg, B)
+    old = ops.get_option("regions_defer")
+    try:
+        ops.set_option("regions_defer", 0)
+        o0, g0 = _step(model, crit, data, regions=True)
+        ops.set_option("regions_defer", 1)
+        o1, g1 = _step(model, crit, data, regions=True)
+    finally:
+        ops.set_option("regions_defer", old)
+    _assert_bitwise(o0, o1, f"{name} {dtype} outputs, regions_defer 0 vs 1")
+    _assert_bitwise(g0, g1, f"{name} {dtype} gradients, regions_defer 0 vs 1")
 
 
 def test_regions_with_stochastic_depth_same_masks():

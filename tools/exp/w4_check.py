@@ -39,7 +39,6 @@ for name, N, K, epi, tb in (("qkv bias", 2304, 768, "bias", 0), ("proj bias+res"
     used = 0
     def select(w4):
         o.set_option("gemm_w4", 15 if w4 else 0)
-        o.set_option("gemm_streamk", 1 if sk else 0)
     for w4 in (0, 1):
         select(w4)
         c0 = o.counters().get("gemm256p", 0)
