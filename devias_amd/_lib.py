@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DEVIAS_LIB_PATH") or os.path.join(_HERE, "libdevias_amd.so")     # (override: ablation builds of tools/)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 162                # devias_version() of the library these prototypes describe
+ABI_VERSION = 164                # devias_version() of the library these prototypes describe
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4, 5
 
 
@@ -106,6 +106,7 @@ PROTOTYPES = {
     "devias_debug_mfma_probe": (c_int, [_P, _L, _I, _I, _P, _P, _P]),
     "devias_debug_mfma_probe_flops": (c_int64, [_I, _I]),
     "devias_debug_gemm_timer_arm": (c_int, [_I, _I, _I, _I, _I]),
+    "devias_debug_dkdv_stamps": (c_int, [_P, _I]),
     "devias_debug_gemm_timer_read": (c_int, [POINTER(c_int32), POINTER(c_float)]),
     "devias_gemm_release_queue_stream": (c_int, [_P]),
     "devias_gemm": (c_int, [POINTER(GemmArgs), _P]),
@@ -127,6 +128,7 @@ PROTOTYPES = {
     "devias_mhsa_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "devias_mhsa_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P]),
     "devias_mhsa_bwd_workspace_bytes": (c_int64, [_I, _I, _I]),
+    "devias_mhsa_bwd_bias_dv_from_do": (c_int32, [_I, _F]),
     "devias_mhsa_fwd_dropout": (c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _F, ctypes.c_uint64, _P]),
     "devias_mhsa_bwd_dropout": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, ctypes.c_uint64, _P]),
     "devias_mhsa_bwd_bias": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, ctypes.c_uint64, _P, _P, _P, _P, _P]),

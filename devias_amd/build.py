@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdevias_amd.so")
-SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "layernorm.hip", "attention.hip", "slot_attn.hip", "loss.hip", "fame.hip", "regions.hip", "probe.hip"]
+SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "layernorm.hip", "attention.hip", "slot_attn.hip", "loss.hip", "fame.hip", "regions.hip", "probe.hip", "attn_bwd1w.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
          "-fno-gpu-rdc", "-mllvm", "-amdgpu-early-inline-all=true",
@@ -26,7 +26,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=f
 # per-file additions.  attention.hip: no SLP vectorisation -- the compiler packs adjacent scalar fp32 adds / multiplies of the softmax arithmetic into v_pk_* instructions,
 # and a packed fp32 instruction beside MFMAs costs more issue time than the two it replaces (MI355X_MICROARCH.md, per-instruction constants): forward attention -4 %
 # (profiles/r4_packed_fp32.txt)
-FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"attention.hip": ["-fno-slp-vectorize"], "attn_bwd1w.hip": ["-fno-slp-vectorize"]}
 
 
 def _flags(src: str):

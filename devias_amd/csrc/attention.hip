@@ -602,7 +602,8 @@ template <int QT, int NW, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                                float* __restrict__ delta, bf16* __restrict__ dqkv,
-                                                               int N, int H, float scale, int xcd, DropP drop = DropP{}, float* __restrict__ part_q = nullptr) {
+                                                               int N, int H, float scale, int xcd, DropP drop = DropP{}, float* __restrict__ part_q = nullptr,
+                                                               float* __restrict__ stat = nullptr, int Npad = 0) {
     __shared__ __attribute__((aligned(16))) char smem[32768];     // two stages of (K image | V image), filled by LDS-DMA one tile ahead
     char* imgKt = smem;            // K, one image for both uses: row reads (S^T = K Q^T) and transposed reads (dQ^T = K^T dS^T)
     char* imgV = smem + 8192;      // V rows   (dP^T = V dO^T)
@@ -638,6 +639,15 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
         dl[qt] = part;
         lse2[qt] = lse[((int64_t)b * H + h) * N + q] * LOG2E;
         if (g == 0 && q0 + 16 * qt + c < N) delta[((int64_t)b * H + h) * N + q] = part;
+        // the row statistics in the form the one-wave-per-SIMD dK / dV kernel (attn_bwd1w.hip) streams them by LDS-DMA: [B, H, Npad / 32, 2, 32], per 32-query
+        // slice -lse * log2 e | -delta, the padding rows N .. Npad - 1 as -inf | 0 (their probabilities are then exactly zero without masking code)
+        if (stat && g == 0 && q0 + 16 * qt + c < Npad) {
+            const int qq = q0 + 16 * qt + c;
+            const bool in = qq < N;
+            float* sp = stat + ((int64_t)b * H + h) * 2 * Npad + (qq >> 5) * 64 + (qq & 31);
+            sp[0] = in ? -lse2[qt] : -INFINITY;
+            sp[32] = in ? -part : 0.f;
+        }
     }
     f32x4 acc_dq[4][QT];
 #pragma unroll
@@ -1135,13 +1145,14 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dkdv_f32_kernel(const float* __r
 
 // process-wide options, read from the environment once; devias_set_option("attn_cfg" | "attn_xcd", v) changes them at run time
 namespace {
-struct AttnKnobs { int cfg, xcd, bias_fused; };
+struct AttnKnobs { int cfg, xcd, bias_fused, dkdv; };
 AttnKnobs& attn_knobs() {
     static AttnKnobs k = [] {
         AttnKnobs x;
         const char* e = getenv("DEVIAS_ATTN_CFG"); x.cfg = e ? atoi(e) : 0;
         e = getenv("DEVIAS_ATTN_XCD"); x.xcd = e ? atoi(e) : 1;
         e = getenv("DEVIAS_ATTN_BIAS_FUSED"); x.bias_fused = e ? atoi(e) : 1;
+        e = getenv("DEVIAS_ATTN_DKDV"); x.dkdv = e ? atoi(e) : 1;
         return x;
     }();
     return k;
@@ -1150,6 +1161,7 @@ AttnKnobs& attn_knobs() {
 static int* attn_option_slot(const char* name) {
     if (!strcmp(name, "attn_cfg")) return &attn_knobs().cfg;
     if (!strcmp(name, "attn_xcd")) return &attn_knobs().xcd;
+    if (!strcmp(name, "attn_dkdv")) return &attn_knobs().dkdv;              // 1 (default): dK / dV by the one-wave-per-SIMD kernel (attn_bwd1w.hip); 0: the two-waves-per-SIMD kernel
     if (!strcmp(name, "attn_bias_fused")) return &attn_knobs().bias_fused;      // 0: devias_mhsa_bwd_bias takes the bias gradients by column-sum passes in bf16 too (A/B aid)
     return nullptr;
 }
@@ -1220,11 +1232,19 @@ extern "C" int devias_mhsa_fwd_dropout(const void* qkv, void* o, float* lse, int
 
 // (ABI 140 had a single-pass backward that needed a workspace; it was removed in ABI 150 -- see DESIGN.md -- and the query stays for hosts
 // written against the older header: nothing is needed any more)
-extern "C" int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H) { (void)B; (void)N; (void)H; return 0; }
+// Row statistics for the one-wave-per-SIMD dK / dV kernel (attn_bwd1w.hip): [B, H, Npad / 32, 2, 32] fp32 (per 32-query slice -lse * log2 e | -delta), Npad = N
+// rounded up to a slice; written by the dQ kernel, streamed by LDS-DMA by the dK / dV kernel.
+static inline int attn_npad(int N) { return (N + 31) & ~31; }
+static inline int64_t attn_stat_bytes(int B, int N, int H) { return (((int64_t)B * H * 2 * attn_npad(N) * 4) + 255) & ~(int64_t)255; }
+extern "C" int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H) { return attn_stat_bytes(B, N, H); }
+int devias_attn_dkdv1w_launch(const void* qkv, const void* d_o, const float* stat, void* dqkv, int B, int N, int Npad, int H, float scale, int xcd_flag,
+                              hipStream_t st);      // attn_bwd1w.hip
+// true = devias_mhsa_bwd* runs the one-wave-per-SIMD dK / dV kernel for this call (bf16, no attention dropout, option attn_dkdv != 0, room for the statistics)
+static inline bool attn_use_dkdv1w(int dtype, float keep) { return dtype == DEVIAS_BF16 && !(keep < 1.0f) && attn_knobs().dkdv != 0; }
 
 static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                          int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream,
-                         float* part_q = nullptr, float* part_v = nullptr) {
+                         float* part_q = nullptr, float* part_v = nullptr, float* stat = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     DropP dp{};
     const bool drop = drop_params(keep, seed, dp);
@@ -1235,7 +1255,13 @@ static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
         const int cfg = attn_knobs().cfg;
         const int xcd = attn_xcd_flag(B, H);
         devias_count(DEVIAS_CNT_MHSA_BWD_BF16);
-#define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_q
+        // dK / dV by the one-wave-per-SIMD kernel when the caller gave room for the row statistics it streams (option attn_dkdv = 0: the two-waves-per-SIMD
+        // kernel, which also serves attention dropout)
+        const bool w1 = stat && attn_use_dkdv1w(dtype, keep);
+        DEVIAS_REQUIRE(!(w1 && part_v), "devias_mhsa_bwd: the one-wave-per-SIMD dK / dV kernel emits no v_bias partials (internal)");
+        float* const stat_w = w1 ? stat : nullptr;
+        const int npad = attn_npad(N);
+#define DQ_ARGS (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_q, stat_w, npad
 #define BWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
         if (drop) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 4, true>), BWD_GRID(128), dim3(256), 0, st, DQ_ARGS);
         else if (cfg == 1 && !part_q) hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<4, 2>), BWD_GRID(128), dim3(128), 0, st, DQ_ARGS);
@@ -1244,7 +1270,10 @@ static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
         else hipLaunchKernelGGL((mhsa_bwd_dq_bf16_kernel<2, 4>), BWD_GRID(128), dim3(256), 0, st, DQ_ARGS);
 #undef DQ_ARGS
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");
-        if (drop) hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<true>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
+        if (w1) {
+            const int rc = devias_attn_dkdv1w_launch(qkv, d_o, stat, dqkv, B, N, npad, H, scale, xcd, st);
+            if (rc != DEVIAS_OK) return rc;
+        } else if (drop) hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<true>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
                                      lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_v);
         else hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<false>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
                                 lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_v);
@@ -1267,8 +1296,8 @@ static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
 }
 extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                                int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* ws, void* stream) {
-    (void)ws;
-    return mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, 1.0f, 0, stream);
+    DEVIAS_REQUIRE(!ws || aligned16(ws), "devias_mhsa_bwd: unaligned workspace");
+    return mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, 1.0f, 0, stream, nullptr, nullptr, (float*)ws);
 }
 extern "C" int devias_mhsa_bwd_dropout(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                                        int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream) {
@@ -1280,15 +1309,30 @@ extern "C" int devias_mhsa_bwd_dropout(const void* qkv, const void* o, const voi
 // emit one [H * 64] partial per (batch entry, 128-row block) from their fp32 accumulators (bias_partials above) and the fixed-order second stage sums the
 // B * ceil(N / 128) partials -- no pass over the stored tensor.  fp32 (parity mode): the plain backward followed by two column-sum passes.  ws_q / ws_v: scratch of
 // devias_mhsa_bwd_bias_workspace_bytes() bytes each.  keep < 1: with the attention dropout of devias_mhsa_bwd_dropout.  (ABI 162)
+static inline int64_t attn_bias_part_bytes(int B, int N, int H) { return (((int64_t)B * cdiv(N, 128) * H * 64 * 4) + 255) & ~(int64_t)255; }
 extern "C" int64_t devias_mhsa_bwd_bias_workspace_bytes(int32_t B, int32_t N, int32_t H) {
-    const int64_t a = (int64_t)B * cdiv(N, 128) * H * 64 * 4, c = devias_colsum_workspace_bytes(B * N, H * 64);
+    const int64_t a = attn_bias_part_bytes(B, N, H) + attn_stat_bytes(B, N, H), c = devias_colsum_workspace_bytes(B * N, H * 64);
     return a > c ? a : c;
 }
+extern "C" int32_t devias_mhsa_bwd_bias_dv_from_do(int32_t dtype, float keep) { return attn_use_dkdv1w(dtype, keep) ? 1 : 0; }
 extern "C" int devias_mhsa_bwd_bias(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
                                     float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, void* stream) {
-    DEVIAS_REQUIRE(dbq && dbv && ws_q && ws_v, "devias_mhsa_bwd_bias: null bias-gradient / workspace pointer");
+    DEVIAS_REQUIRE(dbq && ws_q && ws_v, "devias_mhsa_bwd_bias: null bias-gradient / workspace pointer");
     DEVIAS_REQUIRE(keep > 0.f && keep <= 1.f, "devias_mhsa_bwd_bias: keep must be in (0, 1]");
     const int D = H * 64;
+    const int64_t es = dtype == DEVIAS_BF16 ? 2 : 4;
+    if (attn_use_dkdv1w(dtype, keep)) {
+        // One-wave-per-SIMD dK / dV kernel.  Its row statistics live behind the q partials in ws_q.  It emits no v partials: without dropout every softmax row sums
+        // to one, so sum_keys dV = sum_keys sum_queries P dO = sum_queries dO -- the v_bias gradient IS the column sum of d_o.  A caller that has those column sums
+        // from the producer of d_o (the projection's dgrad GEMM: devias_gemm's colsum epilogue, csrc/regions.hip) passes dbv = NULL; otherwise one pass over d_o here.
+        float* stat = reinterpret_cast<float*>(reinterpret_cast<char*>(ws_q) + attn_bias_part_bytes(B, N, H));
+        const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream, ws_q, nullptr, stat);
+        if (rc != DEVIAS_OK) return rc;
+        const int r1 = devias_colsum_finish(ws_q, B * cdiv(N, 128), D, dbq, 0.f, (hipStream_t)stream);
+        if (r1 != DEVIAS_OK || !dbv) return r1;
+        return devias_colsum(d_o, dtype, B * N, D, D, dbv, 0.f, ws_v, stream);
+    }
+    DEVIAS_REQUIRE(dbv, "devias_mhsa_bwd_bias: dbv may be NULL only where devias_mhsa_bwd_bias_dv_from_do() says so");
     if (dtype == DEVIAS_BF16 && attn_knobs().bias_fused) {
         const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream, ws_q, ws_v);
         if (rc != DEVIAS_OK) return rc;
@@ -1298,7 +1342,6 @@ extern "C" int devias_mhsa_bwd_bias(const void* qkv, const void* o, const void* 
     }
     const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream);
     if (rc != DEVIAS_OK) return rc;
-    const int64_t es = dtype == DEVIAS_BF16 ? 2 : 4;
     const int r1 = devias_colsum(dqkv, dtype, B * N, D, 3 * D, dbq, 0.f, ws_q, stream);
     return r1 != DEVIAS_OK ? r1 : devias_colsum(static_cast<const char*>(dqkv) + (int64_t)2 * D * es, dtype, B * N, D, 3 * D, dbv, 0.f, ws_v, stream);
 }

@@ -1,0 +1,606 @@
+// Attention backward, dK / dV kernel in its one-wave-per-SIMD form (bf16, head dim 64, non-causal; model/modeling_slot.py:105-112 backward).
+//
+// Why: the two-waves-per-SIMD kernel (attention.hip: mhsa_bwd_dkdv_bf16_kernel) ran 13-44 % ABOVE the back-to-back sum of its own MFMA and VALU
+// issue -- 44 % of its wave cycles parked on waits -- because nothing in a wave overlaps its matrix phase with its softmax phase and two phase-locked waves per
+// SIMD do not either.  Here ONE wave owns a SIMD and the whole 512-register file, and the overlap is built into its instruction stream:
+//
+//   * a wave keeps dK^T and dV^T of its 64 keys in 128 accumulator registers (AGPRs named literally in inline asm, the technique of gemm256w_kernel) and its K / V
+//     fragments in 64 more: the arch VGPRs carry only what flows -- S / dP tiles, Q / dO fragments, packed P / dS.  Workgroup = NW waves = NW x 64 keys of one
+//     (batch, head): NW = 4 for the whole 256-key blocks, and the ragged rest of a head (N mod 256 keys) goes to a second, small launch of one- or two-wave workgroups
+//     (four / two of them share a CU) instead of a 256-key workgroup with idle waves (at N = 1568: 6.125 blocks -- a seventh workgroup with one busy wave would cost 14 %);
+//   * Q / dO arrive in slices of 32 queries (one 4 KiB image each, read by rows for S / dP and transposed for dK^T / dV^T: a swizzle that is conflict-free for both
+//     kinds of read at the 32x32x16 lane shapes -- SQ_LDS_BANK_CONFLICT = 0) by LDS-DMA into a ring of NST stages, counted vmcnt, one barrier per slice; the row
+//     statistics of four slices ride in one more 1 KiB piece;
+//   * v_mfma_f32_32x32x16_bf16 throughout: it holds the vector issue port for 8 of its 32 cycles, so ~5 single-issue instructions hide in every gap
+//     (MI355X_MICROARCH.md, per-instruction constants).  Per slice 32 MFMAs in four groups of 8:
+//         1  S / dP of (slice i, keys 32..63)     beside  softmax arithmetic of (slice i, keys 0..31); the LDS-DMA; row fragments + row constants of slice i + 1
+//         2  dK^T / dV^T of (slice i - 1, 32..63) beside  the same arithmetic; the transposed fragments of slice i (each re-read behind the MFMA that consumed it)
+//         3  S / dP of (slice i + 1, keys 0..31)  beside  softmax arithmetic of (slice i, keys 32..63)
+//         4  dK^T / dV^T of (slice i, 0..31)      beside  the same
+//     i.e. a unit's score tile is produced in one group, exponentiated over the next two and consumed by the group after: two score tiles (64 registers) in flight.
+//   * per score one v_exp_f32, one v_mul_f32 and half a v_cvt_pk_bf16_f32 pair: the row constants ride in the MFMA's C operand (S accumulators start from
+//     -lse * log2 e, dP accumulators from -delta) and K is pre-multiplied by scale * log2 e once per workgroup, so the MFMAs deliver S' = s - lse2 and dP - delta:
+//     p = exp2(S'), p * (dP - delta) = dS / scale; dK is scaled by `scale` once at the end.
+//   * epilogue: the tile goes through LDS so that every store instruction writes eight whole 128-byte rows (row-per-lane stores touch 64 lines each).
+//
+// The row statistics come pre-scaled and padded from the dQ kernel, which reads lse and computes delta anyway: stat [B, H, Npad / 32, 2, 32] fp32 (per 32-query
+// slice -lse * log2 e | -delta; Npad = N rounded up to 32; -inf | 0 in the padding, so padded queries have p = 0 with no masking code).  Keys beyond N are computed on
+// clamped rows and never stored.  No v_bias-gradient partials here: softmax rows sum to one, so sum_keys dV = sum_queries dO -- the caller takes that gradient from the
+// column sums of dO (devias_mhsa_bwd_bias).  Deterministic (no atomics), bitwise run-to-run.
+#include "common.h"
+#include <utility>
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef __attribute__((address_space(3))) const char* lds_cptr;
+
+enum { IMG_BYTES = 4096, STAGE_BYTES = 2 * IMG_BYTES, NSTATG = 4 /* statistics ring: groups of four slices, 1 KiB each */ };
+
+// ---- the slice image: [32 rows][128 B], 16-byte chunk c of row r at r * 128 + ((c ^ swz(r)) << 4) -------------------------------------------------------------
+// Row reads (ds_read_b128, lane = row, chunk 2 ks + hi): the instruction's 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32) need 16 distinct
+// (row & 1, chunk ^ swz) pairs -> swz must be distinct over the four rows of a group with equal (row & 1, (row >> 1) & 1): (row >> 2) & 3 is.
+// Transposed reads (ds_read_b64_tr_b16, 32 lanes = rows r0 .. r0 + 3 (r0 % 4 == 0) x four consecutive chunks x two halves): rows r0 and r0 + 2 share a bank half and
+// must take disjoint chunk sets -> bit 2 of swz = (row >> 1) & 1.  Both kinds of read are conflict-free (measured: SQ_LDS_BANK_CONFLICT = 0).
+__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int img_off(int row, int c) { return row * 128 + ((c ^ swz(row)) << 4); }
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const bf16x2 t = {(bf16)a, (bf16)b};
+    return *reinterpret_cast<const unsigned*>(&t);
+}
+
+// ---- MFMAs on literal accumulator registers -------------------------------------------------------------------------------------------------------------------
+// AGPR map (asm-owned: claimed once, never touched by the compiler -- audited in tests/test_build_cpu.py):
+//   a[  0.. 63]  dV^T[db][kb]  (16 registers each, index db * 2 + kb)        a[128..159]  K fragments [kb][ks] (4 registers each), pre-multiplied by scale log2 e
+//   a[ 64..127]  dK^T[db][kb]                                                a[160..191]  V fragments [kb][ks]
+enum { A_DV = 0, A_DK = 64, A_K = 128, A_V = 160, A_END = 192 };
+// S / dP: D (VGPRs) = A (VGPRs: a Q / dO row fragment) x B (AGPRs: a K / V fragment) + C (VGPRs: the row constants)
+#ifndef DKDV_ABL
+#define DKDV_ABL 0
+#endif
+template <int BREG> __device__ __forceinline__ void mfma_init(f32x16& d, const bf16x8& a, const f32x16& c) {
+    if constexpr (DKDV_ABL & 256) { asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" :: "v"(a), "i"(192 + (BREG >= 160 ? 16 : 0)), "i"(207 + (BREG >= 160 ? 16 : 0)), "i"(BREG), "i"(BREG + 3) : "a192", "a223"); asm volatile("" : "+v"(d) : "v"(c)); }
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c3:%c4], %2" : "=&v"(d) : "v"(a), "v"(c), "i"(BREG), "i"(BREG + 3));
+}
+template <int BREG> __device__ __forceinline__ void mfma_more(f32x16& d, const bf16x8& a) {
+    if constexpr (DKDV_ABL & 256) { asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" :: "v"(a), "i"(192 + (BREG >= 160 ? 16 : 0)), "i"(207 + (BREG >= 160 ? 16 : 0)), "i"(BREG), "i"(BREG + 3)); asm volatile("" : "+v"(d)); }
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(BREG), "i"(BREG + 3));
+}
+// dV^T / dK^T: D (AGPRs) += A (VGPRs: a transposed dO / Q fragment) x B (VGPRs: packed P / dS)
+template <int DREG> __device__ __forceinline__ void mfma_agpr(const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "i"(DREG), "i"(DREG + 15));
+}
+#define DEVIAS_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+__device__ __forceinline__ void agpr_claim() {       // (the clobber list is what makes the kernel descriptor allocate a0 .. a191)
+    asm volatile("" ::: DEVIAS_A10(), DEVIAS_A10(1), DEVIAS_A10(2), DEVIAS_A10(3), DEVIAS_A10(4), DEVIAS_A10(5), DEVIAS_A10(6), DEVIAS_A10(7), DEVIAS_A10(8), DEVIAS_A10(9),
+                 DEVIAS_A10(10), DEVIAS_A10(11), DEVIAS_A10(12), DEVIAS_A10(13), DEVIAS_A10(14), DEVIAS_A10(15), DEVIAS_A10(16), DEVIAS_A10(17), DEVIAS_A10(18),
+                 "a190", "a191");
+}
+template <int I> __device__ __forceinline__ void agpr_zero1() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(I)); }
+template <int I> __device__ __forceinline__ void agpr_write1(unsigned v) { asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "i"(I)); }
+template <int I> __device__ __forceinline__ float agpr_read1() { float x; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(I)); return x; }
+template <typename F, int... N> __device__ __forceinline__ void sfor_seq(F&& f, std::integer_sequence<int, N...>) { (f(std::integral_constant<int, N>{}), ...); }
+template <int COUNT, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_seq(f, std::make_integer_sequence<int, COUNT>{}); }
+
+template <int OFF> __device__ __forceinline__ u32x2 lds_tr_off(unsigned addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(r) : "v"(addr), "i"(OFF) : "memory");
+    return r;
+}
+
+#define SB __builtin_amdgcn_sched_barrier(0);
+// -DDKDV_STAMP builds: wave 0 of the first 4096 workgroups of the 256-key launch records the shader clock at kernel entry, loop entry, loop exit and kernel exit
+// (devias_debug_dkdv_stamps reads them; each stamp drains the wave's LDS / scalar-memory counter, which is harmless at those four points)
+__device__ unsigned long long g_dkdv_stamp[4096][4];
+#ifdef DKDV_STAMP
+#define STAMP(k) { if (NW == 4 && wave == 0 && blockIdx.x < 4096) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) g_dkdv_stamp[blockIdx.x][k] = t_; } }
+#else
+#define STAMP(k)
+#endif
+// Diagnostic builds only (tools/build_variant_file.sh <tag> attn_bwd1w -DDKDV_ABL=<mask>; results are then WRONG, the timing is what is read): leave out of the
+// slice loop  1 = the LDS-DMA, 2 = the barrier, 4 = the softmax arithmetic, 8 = the row-fragment / row-constant reads, 16 = the transposed reads, 32 = the counted vmcnt;
+// 64 = a v_mul in place of every v_exp, 128 = a v_perm in place of every v_cvt_pk, 256 = the S / dP MFMAs write (dummy) AGPRs instead of VGPRs
+#ifndef DKDV_ABL
+#define DKDV_ABL 0
+#endif
+
+// =================================================================================================================================================================
+// NW waves of 64 keys; the workgroup's first key is key_first + 64 NW * (its index within the head): the main launch covers the whole 256-key blocks (key_first = 0),
+// the rest launch the ragged end (key_first = 256 * (N / 256), one workgroup per head).  NST = stages of the Q / dO ring.
+template <int NW, int NST>
+__global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o, const float* __restrict__ stat,
+                                                                  bf16* __restrict__ dqkv, int N, int Npad, int H, int B, float scale, int xcd, int key_first, int nblk) {
+    enum { PPW = 4 / NW /* 1 KiB pieces of each image per wave and slice */, DPS = 2 * PPW /* counted DMA instructions per wave and slice */,
+           RING = NST * STAGE_BYTES, EPI = NW * 16384, LDS_BYTES = (RING + NSTATG * 1024) > EPI ? (RING + NSTATG * 1024) : EPI };
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];      // | Q / dO ring | statistics ring |   (epilogue: one 16 KiB tile per wave)
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, r32 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    STAMP(0)
+    int blk, h, b;
+    if (xcd & 1) {                                     // all workgroups of one (batch, head) on one XCD (attention.hip head_map): its Q / dO rows stay in that L2
+        const int bid = blockIdx.x, x = bid & 7, slot = bid >> 3, hidx = (slot / nblk) * 8 + x;
+        blk = slot - (slot / nblk) * nblk; h = hidx % H; b = hidx / H;
+    } else { blk = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
+    const int D = H * 64;
+    const int64_t RS = 3 * (int64_t)D;
+    const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
+    const bf16* dobase = d_o + (int64_t)b * N * D + h * 64;
+    const float* stbase = stat + ((int64_t)b * H + h) * 2 * Npad;
+    const int key0 = key_first + blk * (64 * NW) + wave * 64;
+    const bool active = key0 < N;                       // (a wave without a valid key only stages and synchronises)
+    const int nsl = Npad >> 5;                          // query slices
+
+    // ---- LDS-DMA: per wave and slice PPW 1 KiB pieces of the Q image (piece p = rows 8 p .. + 8), PPW of the dO image; with every fourth slice the 1 KiB of row
+    // statistics of four slices (every wave writes the same bytes: the duplicate costs less than a wave-dependent vmcnt count) ----------------------------------------
+    __amdgpu_buffer_rsrc_t rs_q, rs_o, rs_s;
+    uint32_t vo_q[PPW], vo_o[PPW];
+    {
+        const int64_t left_q = ((int64_t)B - b) * N * RS - h * 64, left_o = ((int64_t)B - b) * N * D - h * 64;
+        const int64_t bq = left_q * 2, bo = left_o * 2;
+        rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base), 0, (int)(bq < 0x7fffffff ? bq : 0x7fffffff), 0x00020000);
+        rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(dobase), 0, (int)(bo < 0x7fffffff ? bo : 0x7fffffff), 0x00020000);
+        rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stbase), 0, 2 * Npad * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int row = (wave + NW * k) * 8 + (lane >> 3), c = (lane & 7) ^ swz(row);
+            vo_q[k] = (uint32_t)((row * (int)RS + c * 8) * 2);
+            vo_o[k] = (uint32_t)((row * D + c * 8) * 2);
+        }
+    }
+    const uint32_t vo_s = (uint32_t)(lane * 16);
+    const int qstride = (int)RS * 64, ostride = D * 64;      // bytes per slice of 32 rows
+    // slice -> stage `stage_off` (a byte offset into the ring, kept in scalar registers by the callers: slice mod NST never becomes a division)
+    auto dma_q = [&](int slice, int stage_off, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int sl = min(slice, nsl - 1);                  // (past the end: harmless re-reads keep the per-iteration DMA count, which the counted vmcnt relies on, constant)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_ptr)(smem + stage_off + (wave + NW * k) * 1024), 16, vo_q[k], sl * qstride, 0, 0);
+#else
+        (void)slice; (void)stage_off; (void)k;
+#endif
+    };
+    auto dma_o = [&](int slice, int stage_off, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int sl = min(slice, nsl - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_o, (lds_void_ptr)(smem + stage_off + IMG_BYTES + (wave + NW * k) * 1024), 16, vo_o[k], sl * ostride, 0, 0);
+#else
+        (void)slice; (void)stage_off; (void)k;
+#endif
+    };
+    // the statistics of slices 4 g .. 4 g + 3 (1 KiB, contiguous in `stat`), issued in front of slice 4 g's pieces; beyond Npad the buffer reads zero
+    auto dma_s = [&](int slice) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((slice & 3) == 0) {
+            const int g = slice >> 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lds_void_ptr)(smem + RING + (g & (NSTATG - 1)) * 1024), 16, vo_s, g * 1024, 0, 0);
+        }
+#else
+        (void)slice;
+#endif
+    };
+    // ---- K / V fragments: requested FIRST -- vmcnt completes in issue order, so behind the ring's prefill their wait would be a wait for the whole prefill
+    // (56 KiB at the ~11 B/clk a CU gets from a cold start: measured 11.9k cycles of prologue per workgroup, 14 % of its life) ----------------------------------------
+    bf16x8 kv_[8], vv_[8];
+    if (active) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int kb = f >> 2, ks = f & 3;
+            const int key = min(key0 + 32 * kb + r32, N - 1);
+            kv_[f] = *reinterpret_cast<const bf16x8*>(base + D + (int64_t)key * RS + 16 * ks + 8 * hi);
+            vv_[f] = *reinterpret_cast<const bf16x8*>(base + 2 * D + (int64_t)key * RS + 16 * ks + 8 * hi);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) {
+        dma_s(s);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) { dma_q(s, s * STAGE_BYTES, k); dma_o(s, s * STAGE_BYTES, k); }
+    }
+    // Counted waits: all but the DPS * n youngest LDS-DMA instructions of this wave have landed.  (A statistics piece among the youngest makes the wait stricter by
+    // one instruction, never laxer; the piece a slice needs is issued in front of that slice's own pieces or earlier.)
+#define WAIT_SLICES_BUT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (n)) : "memory");
+
+    if (!active) {
+        WAIT_SLICES_BUT(NST - 2)
+        if constexpr (NW > 1) __builtin_amdgcn_s_barrier();
+        int st_d = (NST - 1) * STAGE_BYTES;
+        for (int i = 0; i < nsl; ++i) {
+            WAIT_SLICES_BUT(NST - 3)
+            if constexpr (NW > 1) __builtin_amdgcn_s_barrier();
+            dma_s(i + NST - 1);
+#pragma unroll
+            for (int k = 0; k < PPW; ++k) { dma_q(i + NST - 1, st_d, k); dma_o(i + NST - 1, st_d, k); }
+            st_d += STAGE_BYTES; if (st_d == RING) st_d = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NW > 1) __builtin_amdgcn_s_barrier();       // (the epilogue's barrier)
+        return;
+    }
+
+    // ---- K / V fragments -> AGPRs (B operands: lane = key r32 of key block kb, d = 16 ks + 8 hi .. + 8); accumulators = 0 ------------------------------------------
+    agpr_claim();
+    {
+        const float ksc = scale * LOG2E;
+        sfor<8>([&](auto I) {
+            constexpr int f = decltype(I)::value;
+            sfor<4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                agpr_write1<A_K + f * 4 + j>(cvt_pk_bf16((float)kv_[f][2 * j] * ksc, (float)kv_[f][2 * j + 1] * ksc));
+                agpr_write1<A_V + f * 4 + j>(cvt_pk_bf16((float)vv_[f][2 * j], (float)vv_[f][2 * j + 1]));
+            });
+        });
+        sfor<128>([&](auto I) { agpr_zero1<decltype(I)::value>(); });
+    }
+
+    // ---- loop-invariant LDS byte offsets (the stage offset is added once per slice: nine vector adds) ----------------------------------------------------------------
+    int row_a[4], tr_a[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) row_a[ks] = img_off(r32, 2 * ks + hi);
+    {
+        const int g16 = (lane >> 4) & 1, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) tr_a[t][db] = img_off(8 * t + 4 * hi + q, 4 * db + 2 * g16 + (p >> 1)) + 8 * (p & 1);     // (+ 2048 s, + IMG_BYTES for dO)
+    }
+    const int st_a = RING + 16 * hi;                                   // row constants of a slice: floats 8 jj + 4 hi .. + 4 of its 256 B (+ 128: delta)
+    const lds_cptr lbase = (lds_cptr)smem;
+
+    // ---- pipeline state ----------------------------------------------------------------------------------------------------------------------------------------
+    f32x16 S0, P0, S1, P1;                  // score / dP tiles of the two units in flight (unit = slice x 32-key block kb)
+    f32x16 cL, cD;                          // the slice's row constants in accumulator layout: -lse2 / -delta of query (j & 3) + 8 (j >> 2) + 4 hi
+    bf16x8 rq[4], ro[4];                    // Q / dO row fragments of the slice (A operands of S / dP)
+    u32x2 tq[2][2][2], to[2][2][2];         // transposed Q / dO fragments [s][db][t] (A operands of dK^T / dV^T), as the two 8-byte reads they arrive in
+    unsigned pw0[8], dw0[8], pw1[8], dw1[8];    // packed P / dS of units kb = 0 / 1 (register pairs (2 m, 2 m + 1) of the tile -> one word)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { pw0[m] = 0u; dw0[m] = 0u; pw1[m] = 0u; dw1[m] = 0u; }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { tq[s][db][t] = u32x2{0u, 0u}; to[s][db][t] = u32x2{0u, 0u}; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { P1[j] = 0.f; if constexpr (DKDV_ABL & 256) { S0[j] = 0.f; P0[j] = 0.f; S1[j] = 0.f; } }     // (iteration 0 finishes "score 15 of unit (-1, 1)": 0 * 0)
+
+#define LD_ROW_(ptr, img) (*reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((ptr) + (img)))
+#define LD_C4_(ptr, which, jj) (*reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((ptr) + 128 * (which) + 32 * (jj)))
+#define SET_C4(V, jj, X) { const f32x4 x_ = (X); V[4 * (jj)] = x_[0]; V[4 * (jj) + 1] = x_[1]; V[4 * (jj) + 2] = x_[2]; V[4 * (jj) + 3] = x_[3]; }
+    auto frag = [&](const u32x2& lo, const u32x2& hi2) -> bf16x8 {
+        const u32x4 w = {lo[0], lo[1], hi2[0], hi2[1]};
+        return *reinterpret_cast<const bf16x8*>(&w);
+    };
+    auto pfrag = [&](const unsigned (&w)[8], int s) -> bf16x8 {
+        const u32x4 v = {w[4 * s], w[4 * s + 1], w[4 * s + 2], w[4 * s + 3]};
+        return *reinterpret_cast<const bf16x8*>(&v);
+    };
+    // softmax arithmetic, one score per MFMA gap, software-pipelined by one gap so that no v_mul waits on the v_exp in front of it: FIN finishes the score started one
+    // gap earlier (p * dPn; every second score packs a register pair), EXPG starts score g (p = exp2(-Sn))
+    float ev[2][16], dvv[2] = {0.f, 0.f};      // (per-score exponentials of the two units in flight: registers, every index is a constant)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { ev[0][g] = 0.f; ev[1][g] = 0.f; }
+#define EXP_(x) ((DKDV_ABL & 64) ? (x) * 0.25f : fast_exp2(x))
+#define PK_(a, b) ((DKDV_ABL & 128) ? __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u) : cvt_pk_bf16(a, b))
+#define EXPG(S_, g) if constexpr (!(DKDV_ABL & 4)) { ev[&S_ == &S1][g] = EXP_(S_[g]); }
+#define FIN(P_, PW_, DW_, g) if constexpr (!(DKDV_ABL & 4)) { constexpr int u_ = 0; (void)u_; const int uu = (&P_ == &P1); if ((g) & 1) { const float d1_ = ev[uu][g] * P_[g]; PW_[(g) >> 1] = PK_(ev[uu][((g) | 1) - 1], ev[uu][g]); DW_[(g) >> 1] = PK_(dvv[uu], d1_); } else dvv[uu] = ev[uu][g] * P_[g]; }
+    // which scores' arithmetic sits in which MFMA gap (gaps 0-7 / 16-23 are beside MFMAs that write VGPRs, 8-15 / 24-31 beside MFMAs that write AGPRs): DKDV_SPLIT
+    // 0 = one score per gap, each finished one gap behind its v_exp; 1 = none beside the VGPR-writing MFMAs, two per other gap; 2 = one v_exp beside each VGPR-writing
+    // MFMA, v_exp + two finishes per other gap; 3 = half a score / one and a half
+#ifndef DKDV_SPLIT
+#define DKDV_SPLIT 0
+#endif
+#if DKDV_SPLIT == 0
+#define SM_0 FIN(P1, pw1, dw1, 15) EXPG(S0, 0)
+#define SM_1 FIN(P0, pw0, dw0, 0) EXPG(S0, 1)
+#define SM_2 FIN(P0, pw0, dw0, 1) EXPG(S0, 2)
+#define SM_3 FIN(P0, pw0, dw0, 2) EXPG(S0, 3)
+#define SM_4 FIN(P0, pw0, dw0, 3) EXPG(S0, 4)
+#define SM_5 FIN(P0, pw0, dw0, 4) EXPG(S0, 5)
+#define SM_6 FIN(P0, pw0, dw0, 5) EXPG(S0, 6)
+#define SM_7 FIN(P0, pw0, dw0, 6) EXPG(S0, 7)
+#define SM_8 FIN(P0, pw0, dw0, 7) EXPG(S0, 8)
+#define SM_9 FIN(P0, pw0, dw0, 8) EXPG(S0, 9)
+#define SM_10 FIN(P0, pw0, dw0, 9) EXPG(S0, 10)
+#define SM_11 FIN(P0, pw0, dw0, 10) EXPG(S0, 11)
+#define SM_12 FIN(P0, pw0, dw0, 11) EXPG(S0, 12)
+#define SM_13 FIN(P0, pw0, dw0, 12) EXPG(S0, 13)
+#define SM_14 FIN(P0, pw0, dw0, 13) EXPG(S0, 14)
+#define SM_15 FIN(P0, pw0, dw0, 14) EXPG(S0, 15)
+#define SM_16 FIN(P0, pw0, dw0, 15) EXPG(S1, 0)
+#define SM_17 FIN(P1, pw1, dw1, 0) EXPG(S1, 1)
+#define SM_18 FIN(P1, pw1, dw1, 1) EXPG(S1, 2)
+#define SM_19 FIN(P1, pw1, dw1, 2) EXPG(S1, 3)
+#define SM_20 FIN(P1, pw1, dw1, 3) EXPG(S1, 4)
+#define SM_21 FIN(P1, pw1, dw1, 4) EXPG(S1, 5)
+#define SM_22 FIN(P1, pw1, dw1, 5) EXPG(S1, 6)
+#define SM_23 FIN(P1, pw1, dw1, 6) EXPG(S1, 7)
+#define SM_24 FIN(P1, pw1, dw1, 7) EXPG(S1, 8)
+#define SM_25 FIN(P1, pw1, dw1, 8) EXPG(S1, 9)
+#define SM_26 FIN(P1, pw1, dw1, 9) EXPG(S1, 10)
+#define SM_27 FIN(P1, pw1, dw1, 10) EXPG(S1, 11)
+#define SM_28 FIN(P1, pw1, dw1, 11) EXPG(S1, 12)
+#define SM_29 FIN(P1, pw1, dw1, 12) EXPG(S1, 13)
+#define SM_30 FIN(P1, pw1, dw1, 13) EXPG(S1, 14)
+#define SM_31 FIN(P1, pw1, dw1, 14) EXPG(S1, 15)
+#define SM_TAIL FIN(P1, pw1, dw1, 15)
+#elif DKDV_SPLIT == 1
+#define SM_0 
+#define SM_1 
+#define SM_2 
+#define SM_3 
+#define SM_4 
+#define SM_5 
+#define SM_6 
+#define SM_7 
+#define SM_8 EXPG(S0, 0) EXPG(S0, 1) FIN(P0, pw0, dw0, 0) FIN(P0, pw0, dw0, 1)
+#define SM_9 EXPG(S0, 2) EXPG(S0, 3) FIN(P0, pw0, dw0, 2) FIN(P0, pw0, dw0, 3)
+#define SM_10 EXPG(S0, 4) EXPG(S0, 5) FIN(P0, pw0, dw0, 4) FIN(P0, pw0, dw0, 5)
+#define SM_11 EXPG(S0, 6) EXPG(S0, 7) FIN(P0, pw0, dw0, 6) FIN(P0, pw0, dw0, 7)
+#define SM_12 EXPG(S0, 8) EXPG(S0, 9) FIN(P0, pw0, dw0, 8) FIN(P0, pw0, dw0, 9)
+#define SM_13 EXPG(S0, 10) EXPG(S0, 11) FIN(P0, pw0, dw0, 10) FIN(P0, pw0, dw0, 11)
+#define SM_14 EXPG(S0, 12) EXPG(S0, 13) FIN(P0, pw0, dw0, 12) FIN(P0, pw0, dw0, 13)
+#define SM_15 EXPG(S0, 14) EXPG(S0, 15) FIN(P0, pw0, dw0, 14) FIN(P0, pw0, dw0, 15)
+#define SM_16 
+#define SM_17 
+#define SM_18 
+#define SM_19 
+#define SM_20 
+#define SM_21 
+#define SM_22 
+#define SM_23 
+#define SM_24 EXPG(S1, 0) EXPG(S1, 1) FIN(P1, pw1, dw1, 0) FIN(P1, pw1, dw1, 1)
+#define SM_25 EXPG(S1, 2) EXPG(S1, 3) FIN(P1, pw1, dw1, 2) FIN(P1, pw1, dw1, 3)
+#define SM_26 EXPG(S1, 4) EXPG(S1, 5) FIN(P1, pw1, dw1, 4) FIN(P1, pw1, dw1, 5)
+#define SM_27 EXPG(S1, 6) EXPG(S1, 7) FIN(P1, pw1, dw1, 6) FIN(P1, pw1, dw1, 7)
+#define SM_28 EXPG(S1, 8) EXPG(S1, 9) FIN(P1, pw1, dw1, 8) FIN(P1, pw1, dw1, 9)
+#define SM_29 EXPG(S1, 10) EXPG(S1, 11) FIN(P1, pw1, dw1, 10) FIN(P1, pw1, dw1, 11)
+#define SM_30 EXPG(S1, 12) EXPG(S1, 13) FIN(P1, pw1, dw1, 12) FIN(P1, pw1, dw1, 13)
+#define SM_31 EXPG(S1, 14) EXPG(S1, 15) FIN(P1, pw1, dw1, 14) FIN(P1, pw1, dw1, 15)
+#define SM_TAIL 
+#elif DKDV_SPLIT == 2
+#define SM_0 EXPG(S0, 0)
+#define SM_1 EXPG(S0, 1)
+#define SM_2 EXPG(S0, 2)
+#define SM_3 EXPG(S0, 3)
+#define SM_4 EXPG(S0, 4)
+#define SM_5 EXPG(S0, 5)
+#define SM_6 EXPG(S0, 6)
+#define SM_7 EXPG(S0, 7)
+#define SM_8 EXPG(S0, 8) FIN(P0, pw0, dw0, 0) FIN(P0, pw0, dw0, 1)
+#define SM_9 EXPG(S0, 9) FIN(P0, pw0, dw0, 2) FIN(P0, pw0, dw0, 3)
+#define SM_10 EXPG(S0, 10) FIN(P0, pw0, dw0, 4) FIN(P0, pw0, dw0, 5)
+#define SM_11 EXPG(S0, 11) FIN(P0, pw0, dw0, 6) FIN(P0, pw0, dw0, 7)
+#define SM_12 EXPG(S0, 12) FIN(P0, pw0, dw0, 8) FIN(P0, pw0, dw0, 9)
+#define SM_13 EXPG(S0, 13) FIN(P0, pw0, dw0, 10) FIN(P0, pw0, dw0, 11)
+#define SM_14 EXPG(S0, 14) FIN(P0, pw0, dw0, 12) FIN(P0, pw0, dw0, 13)
+#define SM_15 EXPG(S0, 15) FIN(P0, pw0, dw0, 14) FIN(P0, pw0, dw0, 15)
+#define SM_16 EXPG(S1, 0)
+#define SM_17 EXPG(S1, 1)
+#define SM_18 EXPG(S1, 2)
+#define SM_19 EXPG(S1, 3)
+#define SM_20 EXPG(S1, 4)
+#define SM_21 EXPG(S1, 5)
+#define SM_22 EXPG(S1, 6)
+#define SM_23 EXPG(S1, 7)
+#define SM_24 EXPG(S1, 8) FIN(P1, pw1, dw1, 0) FIN(P1, pw1, dw1, 1)
+#define SM_25 EXPG(S1, 9) FIN(P1, pw1, dw1, 2) FIN(P1, pw1, dw1, 3)
+#define SM_26 EXPG(S1, 10) FIN(P1, pw1, dw1, 4) FIN(P1, pw1, dw1, 5)
+#define SM_27 EXPG(S1, 11) FIN(P1, pw1, dw1, 6) FIN(P1, pw1, dw1, 7)
+#define SM_28 EXPG(S1, 12) FIN(P1, pw1, dw1, 8) FIN(P1, pw1, dw1, 9)
+#define SM_29 EXPG(S1, 13) FIN(P1, pw1, dw1, 10) FIN(P1, pw1, dw1, 11)
+#define SM_30 EXPG(S1, 14) FIN(P1, pw1, dw1, 12) FIN(P1, pw1, dw1, 13)
+#define SM_31 EXPG(S1, 15) FIN(P1, pw1, dw1, 14) FIN(P1, pw1, dw1, 15)
+#define SM_TAIL 
+#elif DKDV_SPLIT == 3
+#define SM_0 EXPG(S0, 0)
+#define SM_1 FIN(P0, pw0, dw0, 0)
+#define SM_2 EXPG(S0, 1)
+#define SM_3 FIN(P0, pw0, dw0, 1)
+#define SM_4 EXPG(S0, 2)
+#define SM_5 FIN(P0, pw0, dw0, 2)
+#define SM_6 EXPG(S0, 3)
+#define SM_7 FIN(P0, pw0, dw0, 3)
+#define SM_8 EXPG(S0, 4) EXPG(S0, 5) FIN(P0, pw0, dw0, 4) FIN(P0, pw0, dw0, 5)
+#define SM_9 EXPG(S0, 6) FIN(P0, pw0, dw0, 6)
+#define SM_10 EXPG(S0, 7) EXPG(S0, 8) FIN(P0, pw0, dw0, 7) FIN(P0, pw0, dw0, 8)
+#define SM_11 EXPG(S0, 9) FIN(P0, pw0, dw0, 9)
+#define SM_12 EXPG(S0, 10) EXPG(S0, 11) FIN(P0, pw0, dw0, 10) FIN(P0, pw0, dw0, 11)
+#define SM_13 EXPG(S0, 12) FIN(P0, pw0, dw0, 12)
+#define SM_14 EXPG(S0, 13) EXPG(S0, 14) FIN(P0, pw0, dw0, 13) FIN(P0, pw0, dw0, 14)
+#define SM_15 EXPG(S0, 15) FIN(P0, pw0, dw0, 15)
+#define SM_16 EXPG(S1, 0)
+#define SM_17 FIN(P1, pw1, dw1, 0)
+#define SM_18 EXPG(S1, 1)
+#define SM_19 FIN(P1, pw1, dw1, 1)
+#define SM_20 EXPG(S1, 2)
+#define SM_21 FIN(P1, pw1, dw1, 2)
+#define SM_22 EXPG(S1, 3)
+#define SM_23 FIN(P1, pw1, dw1, 3)
+#define SM_24 EXPG(S1, 4) EXPG(S1, 5) FIN(P1, pw1, dw1, 4) FIN(P1, pw1, dw1, 5)
+#define SM_25 EXPG(S1, 6) FIN(P1, pw1, dw1, 6)
+#define SM_26 EXPG(S1, 7) EXPG(S1, 8) FIN(P1, pw1, dw1, 7) FIN(P1, pw1, dw1, 8)
+#define SM_27 EXPG(S1, 9) FIN(P1, pw1, dw1, 9)
+#define SM_28 EXPG(S1, 10) EXPG(S1, 11) FIN(P1, pw1, dw1, 10) FIN(P1, pw1, dw1, 11)
+#define SM_29 EXPG(S1, 12) FIN(P1, pw1, dw1, 12)
+#define SM_30 EXPG(S1, 13) EXPG(S1, 14) FIN(P1, pw1, dw1, 13) FIN(P1, pw1, dw1, 14)
+#define SM_31 EXPG(S1, 15) FIN(P1, pw1, dw1, 15)
+#define SM_TAIL 
+#endif
+    // an asm MFMA reads its C operand while it runs; the compiler, which does not see the MFMA, would hand a dead C's registers to the next temporaries
+    // (v_exp results) and overwrite them under it: KEEP extends the operand's life past the hazard window (no instruction)
+#define KEEP(V) asm volatile("" ::"v"(V));
+#define LDL_C4(V, jj, ptr, which) if constexpr (!(DKDV_ABL & 8)) SET_C4(V, jj, LD_C4_(ptr, which, jj))
+#define LDL_ROW(dst, ptr, img) if constexpr (!(DKDV_ABL & 8)) dst = LD_ROW_(ptr, img);
+#define TRL(dst, OFF, a) if constexpr (!(DKDV_ABL & 16)) dst = lds_tr_off<OFF>(a);
+#define DMA_Q(k) if constexpr (!(DKDV_ABL & 1) && (k) < PPW) dma_q(i + NST - 1, st_d, (k) < PPW ? (k) : 0);
+#define DMA_O(k) if constexpr (!(DKDV_ABL & 1) && (k) < PPW) dma_o(i + NST - 1, st_d, (k) < PPW ? (k) : 0);
+
+    // ---- prologue: slice 0's row fragments and constants, S / dP of unit (0, 0) -----------------------------------------------------------------------------------
+    WAIT_SLICES_BUT(NST - 2)
+    if constexpr (NW > 1) __builtin_amdgcn_s_barrier();
+    {
+        const lds_cptr cp = lbase + st_a;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { SET_C4(cL, jj, LD_C4_(cp, 0, jj)); SET_C4(cD, jj, LD_C4_(cp, 1, jj)); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { rq[ks] = LD_ROW_(lbase + row_a[ks], 0); ro[ks] = LD_ROW_(lbase + row_a[ks], IMG_BYTES); }
+    }
+    SB
+    mfma_init<A_K + 0>(S0, rq[0], cL);  mfma_init<A_V + 0>(P0, ro[0], cD);
+    mfma_more<A_K + 4>(S0, rq[1]);      mfma_more<A_V + 4>(P0, ro[1]);
+    mfma_more<A_K + 8>(S0, rq[2]);      mfma_more<A_V + 8>(P0, ro[2]);
+    mfma_more<A_K + 12>(S0, rq[3]);     mfma_more<A_V + 12>(P0, ro[3]);
+    SB
+
+    STAMP(1)
+    int st_i = 0, st_n = STAGE_BYTES, st_d = (NST - 1) * STAGE_BYTES;      // stage offsets of slice i, slice i + 1, and of the slice the DMA of this iteration fills
+    int sc_n = 256;                                                          // offset of slice i + 1's constants in the statistics ring
+    // LDS reads of the loop.  The row constants (cL / cD: sixteen registers each, filled four at a time) are plain loads: the compiler, which counts only its own LDS
+    // instructions, waits for them at CWAIT -- placed BEFORE the first asm read of the iteration, so that its lgkmcnt(0) never sits behind a young read it does not
+    // see.  Row fragments (RLD) and transposed fragments (TRL) are asm reads with hand-counted waits: they return in issue order, and lgkmcnt is a 4-bit counter --
+    // LWAIT(n) = all but the n <= 15 youngest LDS reads are back.  Issue order per iteration: rq0 ro0 rq1 | ro1 T0 | rq2 T1 | ro2 T2 | rq3 T3 | ro3 T4 | T5 | T6 | T7
+    // (Tk = the two reads of transposed fragment k), one `|` per MFMA gap from gap 6 on; every wait below is for a read issued at least five gaps earlier.
+#define RLD(dst, a, OFF) if constexpr (!(DKDV_ABL & 8)) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(a), "i"(OFF) : "memory");
+#define LWAIT(n, x) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(n) : "memory");
+#define CWAIT asm volatile("" ::"v"(cL), "v"(cD));
+    for (int i = 0; i < nsl; ++i) {
+        // slice i + 1 has landed for this wave ... and for every wave; everyone is done with slice i - 1's stage
+        if constexpr (!(DKDV_ABL & 32)) WAIT_SLICES_BUT(NST - 3)
+        if constexpr (NW > 1 && !(DKDV_ABL & 2)) __builtin_amdgcn_s_barrier();
+        const unsigned rp0 = (unsigned)(st_n + row_a[0]), rp1 = (unsigned)(st_n + row_a[1]), rp2 = (unsigned)(st_n + row_a[2]), rp3 = (unsigned)(st_n + row_a[3]);
+        const lds_cptr cp = lbase + sc_n + st_a;
+        const unsigned t00 = (unsigned)(st_i + tr_a[0][0]), t10 = (unsigned)(st_i + tr_a[1][0]), t01 = (unsigned)(st_i + tr_a[0][1]), t11 = (unsigned)(st_i + tr_a[1][1]);
+        SB
+        // ---- group 1: S / dP of unit (i, 1)   || softmax of unit (i, 0), scores 0..7; the DMA of slice i + NST - 1; the row constants of slice i + 1
+        mfma_init<A_K + 16>(S1, rq[0], cL);  SM_0  if constexpr (!(DKDV_ABL & 1)) dma_s(i + NST - 1);  DMA_Q(0)  SB
+        mfma_init<A_V + 16>(P1, ro[0], cD);  SM_1  DMA_O(0)  SB
+        mfma_more<A_K + 20>(S1, rq[1]);      SM_2  DMA_Q(1)  KEEP(cL)  LDL_C4(cL, 0, cp, 0) LDL_C4(cL, 1, cp, 0) LDL_C4(cL, 2, cp, 0) LDL_C4(cL, 3, cp, 0)  SB
+        mfma_more<A_V + 20>(P1, ro[1]);      SM_3  DMA_O(1)  KEEP(cD)  LDL_C4(cD, 0, cp, 1) LDL_C4(cD, 1, cp, 1) LDL_C4(cD, 2, cp, 1) LDL_C4(cD, 3, cp, 1)  SB
+        mfma_more<A_K + 24>(S1, rq[2]);      SM_4  DMA_Q(2)  SB
+        mfma_more<A_V + 24>(P1, ro[2]);      SM_5  DMA_O(2)  SB
+        mfma_more<A_K + 28>(S1, rq[3]);      SM_6  DMA_Q(3)  CWAIT  RLD(rq[0], rp0, 0)  SB
+        mfma_more<A_V + 28>(P1, ro[3]);      SM_7  DMA_O(3)  RLD(ro[0], rp0, IMG_BYTES)  SB
+        // ---- group 2: dV^T / dK^T of unit (i - 1, 1)   || softmax of unit (i, 0), scores 8..15; the row fragments of slice i + 1 (each behind the MFMA that read
+        //      the old one) and the transposed fragments of slice i (each behind the MFMA that consumed its previous contents, in the order group 4 consumes them)
+        {
+            const bf16x8 b0 = pfrag(pw1, 0), e0 = pfrag(dw1, 0), b1 = pfrag(pw1, 1), e1 = pfrag(dw1, 1);
+            mfma_agpr<A_DV + 16>(frag(to[0][0][0], to[0][0][1]), b0);  SM_8   RLD(rq[1], rp1, 0)  SB
+            mfma_agpr<A_DK + 16>(frag(tq[0][0][0], tq[0][0][1]), e0);  SM_9   RLD(ro[1], rp1, IMG_BYTES)  TRL(to[0][0][0], IMG_BYTES, t00)  TRL(to[0][0][1], IMG_BYTES, t10)  SB
+            mfma_agpr<A_DV + 48>(frag(to[0][1][0], to[0][1][1]), b0);  SM_10  RLD(rq[2], rp2, 0)          TRL(tq[0][0][0], 0, t00)          TRL(tq[0][0][1], 0, t10)          SB
+            mfma_agpr<A_DK + 48>(frag(tq[0][1][0], tq[0][1][1]), e0);  SM_11  RLD(ro[2], rp2, IMG_BYTES)  TRL(to[0][1][0], IMG_BYTES, t01)  TRL(to[0][1][1], IMG_BYTES, t11)  SB
+            mfma_agpr<A_DV + 16>(frag(to[1][0][0], to[1][0][1]), b1);  SM_12  RLD(rq[3], rp3, 0)          TRL(tq[0][1][0], 0, t01)          TRL(tq[0][1][1], 0, t11)          SB
+            mfma_agpr<A_DK + 16>(frag(tq[1][0][0], tq[1][0][1]), e1);  SM_13  RLD(ro[3], rp3, IMG_BYTES)  TRL(to[1][0][0], IMG_BYTES + 2048, t00)  TRL(to[1][0][1], IMG_BYTES + 2048, t10)  SB
+            mfma_agpr<A_DV + 48>(frag(to[1][1][0], to[1][1][1]), b1);  SM_14  TRL(tq[1][0][0], 2048, t00)  TRL(tq[1][0][1], 2048, t10)  SB
+            mfma_agpr<A_DK + 48>(frag(tq[1][1][0], tq[1][1][1]), e1);  SM_15  TRL(to[1][1][0], IMG_BYTES + 2048, t01)  TRL(to[1][1][1], IMG_BYTES + 2048, t11)  SB
+        }
+        // ---- group 3: S / dP of unit (i + 1, 0)   || softmax of unit (i, 1), scores 0..7; the last transposed fragment.  (reads issued after rq0: 21, after ro0: 22
+        //      incl. the two of this group, ... : the counted waits below)
+        LWAIT(15, rq[0])  mfma_init<A_K + 0>(S0, rq[0], cL);   TRL(tq[1][1][0], 2048, t01)  TRL(tq[1][1][1], 2048, t11)  SM_16  SB
+        LWAIT(15, ro[0])  mfma_init<A_V + 0>(P0, ro[0], cD);   SM_17  SB
+        LWAIT(15, rq[1])  mfma_more<A_K + 4>(S0, rq[1]);       SM_18  SB
+        LWAIT(15, ro[1])  mfma_more<A_V + 4>(P0, ro[1]);       SM_19  SB
+        LWAIT(15, rq[2])  mfma_more<A_K + 8>(S0, rq[2]);       SM_20  SB
+        LWAIT(14, ro[2])  mfma_more<A_V + 8>(P0, ro[2]);       SM_21  SB
+        LWAIT(11, rq[3])  mfma_more<A_K + 12>(S0, rq[3]);      SM_22  SB
+        LWAIT(8, ro[3])   mfma_more<A_V + 12>(P0, ro[3]);      SM_23  SB
+        // ---- group 4: dV^T / dK^T of unit (i, 0)   || softmax of unit (i, 1), scores 8..15.  The last transposed read was issued eight MFMAs ago: one wait covers all
+        {
+            const bf16x8 b0 = pfrag(pw0, 0), e0 = pfrag(dw0, 0), b1 = pfrag(pw0, 1), e1 = pfrag(dw0, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(to[0][0][0]), "+v"(to[0][0][1]), "+v"(tq[0][0][0]), "+v"(tq[0][0][1]), "+v"(to[0][1][0]), "+v"(to[0][1][1]),
+                         "+v"(tq[0][1][0]), "+v"(tq[0][1][1]) :: "memory");
+            asm volatile("" : "+v"(to[1][0][0]), "+v"(to[1][0][1]), "+v"(tq[1][0][0]), "+v"(tq[1][0][1]), "+v"(to[1][1][0]), "+v"(to[1][1][1]),
+                         "+v"(tq[1][1][0]), "+v"(tq[1][1][1]) :: "memory");
+            mfma_agpr<A_DV + 0>(frag(to[0][0][0], to[0][0][1]), b0);   SM_24   SB
+            mfma_agpr<A_DK + 0>(frag(tq[0][0][0], tq[0][0][1]), e0);   SM_25   SB
+            mfma_agpr<A_DV + 32>(frag(to[0][1][0], to[0][1][1]), b0);  SM_26  SB
+            mfma_agpr<A_DK + 32>(frag(tq[0][1][0], tq[0][1][1]), e0);  SM_27  SB
+            mfma_agpr<A_DV + 0>(frag(to[1][0][0], to[1][0][1]), b1);   SM_28  SB
+            mfma_agpr<A_DK + 0>(frag(tq[1][0][0], tq[1][0][1]), e1);   SM_29  SB
+            mfma_agpr<A_DV + 32>(frag(to[1][1][0], to[1][1][1]), b1);  SM_30  SB
+            mfma_agpr<A_DK + 32>(frag(tq[1][1][0], tq[1][1][1]), e1);  SM_31  SB
+        }
+        st_d = st_i; st_i = st_n; st_n += STAGE_BYTES; if (st_n == RING) st_n = 0;
+        sc_n = (sc_n + 256) & (NSTATG * 1024 - 1);
+    }
+    STAMP(2)
+    // ---- drain: the last score of unit (nsl - 1, 1), then its dV^T / dK^T ---------------------------------------------------------------------------------------------
+    SM_TAIL
+    SB
+    {
+        const bf16x8 b0 = pfrag(pw1, 0), e0 = pfrag(dw1, 0), b1 = pfrag(pw1, 1), e1 = pfrag(dw1, 1);
+        mfma_agpr<A_DV + 16>(frag(to[0][0][0], to[0][0][1]), b0);  mfma_agpr<A_DK + 16>(frag(tq[0][0][0], tq[0][0][1]), e0);
+        mfma_agpr<A_DV + 48>(frag(to[0][1][0], to[0][1][1]), b0);  mfma_agpr<A_DK + 48>(frag(tq[0][1][0], tq[0][1][1]), e0);
+        mfma_agpr<A_DV + 16>(frag(to[1][0][0], to[1][0][1]), b1);  mfma_agpr<A_DK + 16>(frag(tq[1][0][0], tq[1][0][1]), e1);
+        mfma_agpr<A_DV + 48>(frag(to[1][1][0], to[1][1][1]), b1);  mfma_agpr<A_DK + 48>(frag(tq[1][1][0], tq[1][1][1]), e1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // trailing re-reads have landed; the last MFMAs' results are readable (asm MFMAs: nobody pads this)
+    if constexpr (NW > 1) __builtin_amdgcn_s_barrier();                        // every wave is past its last read of the rings: they become the epilogue's tiles
+
+    // ---- epilogue: the wave's [64 keys][dK 64 | dV 64] tile through LDS (its own 16 KiB: row = key, 256 B, 16-byte chunk c at (c ^ (row & 7)) inside each 128-byte
+    // half), then stores of eight whole rows per instruction.  Lane (hi, key r32 of block kb) holds d = 32 db + 8 jj + 4 hi .. + 4 of its key's rows ----------------
+    {
+        char* tile = smem + wave * 16384;
+        const float dksc = scale;
+        sfor<16>([&](auto I) {
+            constexpr int db = (decltype(I)::value >> 3) & 1, kb = (decltype(I)::value >> 2) & 1, jj = decltype(I)::value & 3;
+            constexpr int ra = (db * 2 + kb) * 16 + 4 * jj;
+            const int row = 32 * kb + r32;
+            const int c16 = (4 * db + jj) ^ (row & 7), off = row * 256 + (c16 << 4) + 8 * hi;     // this lane's 8 bytes of 16-byte chunk 4 db + jj (d = 32 db + 8 jj + 4 hi)
+            const f32x4 dk = f32x4{agpr_read1<A_DK + ra>(), agpr_read1<A_DK + ra + 1>(), agpr_read1<A_DK + ra + 2>(), agpr_read1<A_DK + ra + 3>()} * dksc;
+            const f32x4 dv = {agpr_read1<A_DV + ra>(), agpr_read1<A_DV + ra + 1>(), agpr_read1<A_DV + ra + 2>(), agpr_read1<A_DV + ra + 3>()};
+            *reinterpret_cast<u32x2*>(tile + off) = u32x2{cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3])};
+            *reinterpret_cast<u32x2*>(tile + off + 128) = u32x2{cvt_pk_bf16(dv[0], dv[1]), cvt_pk_bf16(dv[2], dv[3])};
+        });
+        // (each wave reads back only what it wrote itself: no barrier, the compiler's lgkmcnt wait orders the reads behind the writes)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = 8 * it + (lane >> 3), c = lane & 7, key = key0 + row;
+            const u32x4 vk = *reinterpret_cast<const u32x4*>(tile + row * 256 + ((c ^ (row & 7)) << 4));
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(tile + row * 256 + 128 + ((c ^ (row & 7)) << 4));
+            if (key < N) {
+                bf16* dst = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 8 * c;
+                *reinterpret_cast<u32x4*>(dst + D) = vk;
+                *reinterpret_cast<u32x4*>(dst + 2 * D) = vv;
+            }
+        }
+    }
+    STAMP(3)
+}
+
+}  // namespace
+
+extern "C" int devias_debug_dkdv_stamps(uint64_t* out, int32_t n) {
+#ifdef DKDV_STAMP
+    DEVIAS_REQUIRE(out && n > 0 && n <= 4096, "devias_debug_dkdv_stamps: bad args");
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dkdv_stamp), sizeof(unsigned long long) * 4 * n, 0, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return devias_set_error(DEVIAS_ELAUNCH, "devias_debug_dkdv_stamps: copy failed");
+    }
+    return DEVIAS_OK;
+#else
+    (void)out; (void)n;
+    return devias_set_error(DEVIAS_EUNSUPPORTED, "devias_debug_dkdv_stamps: the library was not built with -DDKDV_STAMP (tools/build_variant_file.sh stamp attn_bwd1w -DDKDV_STAMP)");
+#endif
+}
+
+// launched by attention.hip (mhsa_bwd_impl) behind the dQ kernel, which has written `stat`: the whole 256-key blocks of every head, then the ragged rest
+int devias_attn_dkdv1w_launch(const void* qkv, const void* d_o, const float* stat, void* dqkv, int B, int N, int Npad, int H, float scale, int xcd_flag, hipStream_t st) {
+    const int nfull = N / 256, rest = N - nfull * 256;
+#define DKDV_ARGS (const bf16*)qkv, (const bf16*)d_o, stat, (bf16*)dqkv, N, Npad, H, B, scale, xcd_flag
+    if (nfull > 0) {
+        const dim3 grid = (xcd_flag & 1) ? dim3(nfull * H * B) : dim3(nfull, H, B);
+        hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8>), grid, dim3(256), 0, st, DKDV_ARGS, 0, nfull);
+    }
+    if (rest > 0) {
+        const dim3 grid = (xcd_flag & 1) ? dim3(H * B) : dim3(1, H, B);
+        if (rest <= 64) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<1, 4>), grid, dim3(64), 0, st, DKDV_ARGS, nfull * 256, 1);
+        else if (rest <= 128) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<2, 4>), grid, dim3(128), 0, st, DKDV_ARGS, nfull * 256, 1);
+        else hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8>), grid, dim3(256), 0, st, DKDV_ARGS, nfull * 256, 1);
+    }
+#undef DKDV_ARGS
+    DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv, one wave per SIMD)");
+    return DEVIAS_OK;
+}

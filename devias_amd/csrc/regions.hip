@@ -230,11 +230,13 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
         g1 = t.g;
     }
     RUN(wgrad(c, g1, s.o, g->dWp, M, D, D));
-    { Epi e; RUN(gemm(c, g1, a->Wp, t.small, M, D, D, D, D, 0, 1, e)); }                                                                        // d_o
+    // v_bias gradient: the column sum of d_o where the attention backward says so (softmax rows sum to one: sum_keys dV = sum_queries dO), from this GEMM's epilogue
+    const bool dv_from_do = g->dbq && g->dbv && devias_mhsa_bwd_bias_dv_from_do(a->dtype, 1.0f);
+    { Epi e; if (dv_from_do) e.colsum = g->dbv; RUN(gemm(dv_from_do ? with_ws(t.p_v) : c, g1, a->Wp, t.small, M, D, D, D, D, 0, 1, e)); }   // (p_v: the attention backward does not use it then)                                     // d_o
     if (g->dbq && g->dbv)                                                   // dqkv + the q_bias / v_bias gradients (each to its own destination) from the same two kernels
-        RUN(devias_mhsa_bwd_bias(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, 1.0f, 0, g->dbq, g->dbv, t.p_q, t.p_v, stream));
+        RUN(devias_mhsa_bwd_bias(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, 1.0f, 0, g->dbq, dv_from_do ? nullptr : g->dbv, t.p_q, t.p_v, stream));
     else
-        RUN(devias_mhsa_bwd(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, nullptr, stream));                          // dqkv
+        RUN(devias_mhsa_bwd(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, t.p_q, stream));                          // dqkv
     RUN(wgrad(c, t.big, s.u, g->dWqkv, M, 3 * D, D));
     if (g->dbq && g->dbv) {
     } else {

@@ -366,9 +366,14 @@ class EncoderBlockFn(Function):
             dbp = ops.colsum(g1, out=dbp)
         with lane.after_main():
             dWp = ops.wgrad(g1, o, out=_gout(p_pw))
-        d_o = ops.gemm(g1, Wp, trans_b=True)
         dbq, dbv = dst(p_qb, D), dst(p_vb, D)                                  # q_bias | (k: no bias) | v_bias, each to its own destination
-        dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop, bias_out=(dbq, dbv))
+        if ops.mhsa_bwd_dv_from_do(g1.dtype, adrop):
+            # softmax rows sum to one: sum_keys dV = sum_queries dO -- the v_bias gradient is the column sum of d_o, taken from the GEMM that produces it
+            d_o = ops.gemm(g1, Wp, trans_b=True, colsum=dbv)
+            dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop, bias_out=(dbq, None))
+        else:
+            d_o = ops.gemm(g1, Wp, trans_b=True)
+            dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop, bias_out=(dbq, dbv))
         with lane.after_main():
             dWqkv = ops.wgrad(dqkv, u, out=_gout(p_qkvw))
         du = ops.gemm(dqkv, Wqkv, trans_b=True)

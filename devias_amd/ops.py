@@ -302,6 +302,13 @@ def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, out: Optio
     return o, lse
 
 
+def mhsa_bwd_dv_from_do(dtype: torch.dtype, drop=None) -> bool:
+    """True where the v_bias gradient is the column sum of d_o (devias_mhsa_bwd_bias_dv_from_do: bf16, no attention dropout, one-wave-per-SIMD dK / dV kernel):
+    the caller asks the GEMM that produces d_o for its column sums and passes bias_out = (dbq, None)"""
+    keep = float(drop[0]) if drop is not None else 1.0
+    return bool(_lib.load().devias_mhsa_bwd_bias_dv_from_do(dt_code(dtype), keep))
+
+
 def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None, bias_out=None):
     """bias_out = (dbq, dbv): fp32 [H * 64] destinations of the q_bias / v_bias gradients (column sums of dQ / dV over all rows), produced by the same call
     (devias_mhsa_bwd_bias: from the kernels' accumulators in bf16, by two column-sum passes in fp32)"""
@@ -309,13 +316,13 @@ def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None, 
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     if bias_out is not None:
-        dbq, dbv = (_chk(t, "mhsa_bwd.bias_out", torch.float32) for t in bias_out)
-        assert dbq.numel() == H * 64 and dbv.numel() == H * 64
+        dbq, dbv = (None if t is None else _chk(t, "mhsa_bwd.bias_out", torch.float32) for t in bias_out)
+        assert dbq.numel() == H * 64 and (dbv is None or dbv.numel() == H * 64)      # (dbv = None: only where mhsa_bwd_dv_from_do() says the caller has it from colsum(d_o))
         wsb = int(_lib.load().devias_mhsa_bwd_bias_workspace_bytes(B, N, H))
         ws = torch.empty((2, (wsb + 3) // 4), dtype=torch.float32, device=qkv.device)
         keep, seed = (float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF) if drop is not None else (1.0, 0)
         _lib.check(_lib.load().devias_mhsa_bwd_bias(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N, H, scale,
-                                                    dt_code(qkv.dtype), keep, seed, dbq.data_ptr(), dbv.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), _stream()),
+                                                    dt_code(qkv.dtype), keep, seed, dbq.data_ptr(), None if dbv is None else dbv.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), _stream()),
                    "devias_mhsa_bwd_bias")
         return dqkv
     if drop is not None and float(drop[0]) < 1.0:
@@ -323,8 +330,10 @@ def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None, 
                                                        B, N, H, scale, dt_code(qkv.dtype), float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, _stream()),
                    "devias_mhsa_bwd_dropout")
         return dqkv
+    wsb = int(_lib.load().devias_mhsa_bwd_workspace_bytes(B, N, H))      # row statistics of the one-wave-per-SIMD dK / dV kernel (bf16)
+    ws = torch.empty(((wsb + 3) // 4,), dtype=torch.float32, device=qkv.device)
     _lib.check(_lib.load().devias_mhsa_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                           dqkv.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), None, _stream()), "devias_mhsa_bwd")
+                                           dqkv.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), ws.data_ptr(), _stream()), "devias_mhsa_bwd")
     return dqkv
 
 

@@ -122,6 +122,9 @@ int64_t devias_debug_mfma_probe_flops(int32_t n_workgroups, int32_t iters);
  * launches behind it).  The dims are devias_gemm_args' M, N, K. */
 int devias_debug_gemm_timer_arm(int32_t M, int32_t N, int32_t K, int32_t trans_a, int32_t trans_b);
 int devias_debug_gemm_timer_read(int32_t* count, float* total_ms);
+/* Diagnostic builds (-DDKDV_STAMP on csrc/attn_bwd1w.hip) only, DEVIAS_EUNSUPPORTED otherwise: shader-clock stamps of the one-wave-per-SIMD dK / dV kernel's last
+ * launch -- per workgroup (the first n <= 4096) kernel entry, loop entry, loop exit, kernel exit -- copied to host memory out[n][4]. */
+int devias_debug_dkdv_stamps(uint64_t* out, int32_t n);
 
 /* fills: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes per block, [3]=wavefront size, [4]=gfx arch number (e.g. 950) */
 int devias_device_info(int device, int64_t* out5);
@@ -227,8 +230,10 @@ int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
  * head dim 64.  qkv: T [B,N,3,H,64] exactly as F.linear produces it (:101-102, no permute copy); o: T [B,N,H*64];
  * lse: fp32 [B,H,N] = log sum_j exp(scale * q.k_j).  The N x N score matrix is never materialised.
  * backward: dqkv T [B,N,3,H,64]; delta fp32 [B,H,N] scratch (rowsum(dO*O)).  Two kernels (dQ; dK/dV), seven matrix products per tile pair (S and dP
- *   are recomputed in both so that no gradient needs a sum across workgroups: bitwise reproducible, no atomics).  `ws` is unused since ABI 150 and may
- *   be NULL (ABI 140 offered an opt-in single-pass backward with an ordered dQ hand-off; measured slower -- DESIGN.md -- and removed).
+ *   are recomputed in both so that no gradient needs a sum across workgroups: bitwise reproducible, no atomics).  `ws` (ABI 164): devias_mhsa_bwd_workspace_bytes()
+ *   bytes, 16-byte aligned -- the row statistics (lse * log2 e, delta, per 32-query slice) that the dQ kernel leaves for the one-wave-per-SIMD dK / dV kernel
+ *   (csrc/attn_bwd1w.hip, bf16: one wave owns a SIMD and all 512 registers, dK / dV accumulators in AGPRs, the softmax arithmetic placed in the MFMAs' gaps);
+ *   with ws = NULL, or option "attn_dkdv" = 0, the two-waves-per-SIMD dK / dV kernel of rounds 2-4 runs instead (same semantics, results equal to rounding).
  * ------------------------------------------------------------------------------------------------- */
 int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
                     int32_t dtype, void* stream);
@@ -248,7 +253,12 @@ int devias_mhsa_bwd_dropout(const void* qkv, const void* o, const void* d_o, con
 /* Backward + the q_bias / v_bias gradients dbq, dbv: fp32 [H*64] each = the column sums of the dQ and dV thirds of dqkv over all B*N rows (the bias enters the QKV
  * projection, modeling_slot.py:97-101), ABI 162.  bf16: the two kernels emit one partial per (batch entry, 128-row block) from their fp32 accumulators and a
  * fixed-order second stage sums them -- no pass over the stored tensor (it replaces two devias_colsum calls per block: 2 x 77 MB read at ViT-B); fp32: the plain
- * backward followed by the two column sums.  keep = 1: no attention dropout (seed ignored).  ws_q, ws_v: devias_mhsa_bwd_bias_workspace_bytes() bytes each. */
+ * backward followed by the two column sums.  keep = 1: no attention dropout (seed ignored).  ws_q, ws_v: devias_mhsa_bwd_bias_workspace_bytes() bytes each.
+ * ABI 164: where devias_mhsa_bwd_bias_dv_from_do(dtype, keep) returns 1 (bf16, no dropout, option "attn_dkdv" != 0: the one-wave-per-SIMD dK / dV kernel), the
+ * v_bias gradient is the column sum of d_o (every softmax row sums to one: sum_keys dV = sum_queries dO) and dbv MAY be NULL -- the caller then takes it from the
+ * producer of d_o (devias_gemm's colsum epilogue on the projection's dgrad GEMM, as devias_encoder_block_bwd does); with dbv given, one column-sum pass over d_o
+ * here.  The q_bias gradient still comes from the dQ kernel's accumulators. */
+int32_t devias_mhsa_bwd_bias_dv_from_do(int32_t dtype, float keep);
 int devias_mhsa_bwd_bias(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
                          float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, void* stream);
 int64_t devias_mhsa_bwd_bias_workspace_bytes(int32_t B, int32_t N, int32_t H);

@@ -248,7 +248,8 @@ def test_mhsa_dropout_matches_the_reference_with_the_same_mask(dtype, B, N, H, k
 def test_mhsa_bwd_emits_the_bias_gradients(dtype, B, N, H, keep):
     """devias_mhsa_bwd_bias: dqkv is bitwise that of the plain backward, and dbq / dbv are the column sums of its dQ / dV thirds over all rows -- in bf16 taken
     from the kernels' fp32 accumulators (one partial per batch entry and 128-row block, fixed-order second stage), so they agree with the sums of the
-    bf16-ROUNDED stored values to rounding noise and are closer to the fp32 reference than those; ragged N (partly empty blocks) and attention dropout included"""
+    bf16-ROUNDED stored values to rounding noise and are closer to the fp32 reference than those; ragged N (partly empty blocks) and attention dropout included.
+    Since round 5 (one-wave-per-SIMD dK / dV kernel; bf16 without dropout) dbv is the column sum of d_o: the same gradient by the softmax rows' unit sums."""
     o = ops()
     scale = 64 ** -0.5
     D = H * 64
@@ -264,6 +265,12 @@ def test_mhsa_bwd_emits_the_bias_gradients(dtype, B, N, H, keep):
     rq, rv = g[:, 0].sum(0), g[:, 2].sum(0)
     tol = 1e-5 if dtype == torch.float32 else 4e-3
     assert rel(dbq, rq) < tol and rel(dbv, rv) < tol
+    if o.mhsa_bwd_dv_from_do(dtype, drop):
+        # one-wave-per-SIMD dK / dV kernel (bf16, no dropout): softmax rows sum to one, so sum_keys dV = sum_queries dO -- the v_bias gradient is the column sum of
+        # d_o itself (exact; the sum of the bf16-rounded dV rows above is the noisier of the two), and a caller that has it from the producer of d_o passes None
+        assert rel(dbv, d_o.float().sum(0)) < 1e-5
+        dbq3 = torch.empty_like(dbq)
+        assert torch.equal(o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale, drop=drop, bias_out=(dbq3, None)), plain) and torch.equal(dbq3, dbq)
     dbq2 = torch.empty_like(dbq); dbv2 = torch.empty_like(dbv)
     o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale, drop=drop, bias_out=(dbq2, dbv2))
     assert torch.equal(dbq, dbq2) and torch.equal(dbv, dbv2)            # run to run
