@@ -116,3 +116,86 @@ def test_inline_asm_vmem_never_reads_an_sgpr_the_valu_just_wrote():
                 j -= 1
         assert checked > 500, (extra, checked)          # the epilogue stores alone are thousands
         assert not bad, bad[:5]
+
+
+def _reg_set(tok: str):
+    """VGPR numbers named by an operand token: v12, v[4:7]; anything else -> empty"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+@pytest.mark.timeout(600)
+def test_one_wave_dkdv_kernels_own_their_agprs_and_keep_their_hazard_windows():
+    """Audit of the one-wave-per-SIMD attention dK / dV kernels (mhsa_bwd_dkdv1w_kernel, devias_amd/csrc/attn_bwd1w.hip).  (1) a[0:191] -- dK / dV accumulators and
+    the K / V fragments -- are named literally in inline asm: the compiler must touch no AGPR itself and spill nothing.  (2) Its MFMAs are inline asm, so the
+    compiler's hazard recognizer does not see them; the source keeps the windows by construction and this test checks the result in the ISA of every
+    instantiation: behind an MFMA that writes VGPRs no other instruction reads or writes those VGPRs before two further MFMAs have issued (XDL write -> VALU /
+    LDS access needs 11 wait states at 8 passes), and no vector-ALU instruction overwrites the VGPRs of its C operand before one further MFMA has issued (the
+    MFMA reads C while it runs: 7 wait states; LDS loads into those registers return much later and are fine).  (3) the slice loop holds exactly 32 MFMAs."""
+    src = os.path.join(ROOT, "devias_amd", "csrc", "attn_bwd1w.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "attn_bwd1w.s")
+        cmd = [build.HIPCC] + list(build._flags("attn_bwd1w.hip")) + ["--cuda-device-only", "-S", src, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = open(out).read().split("\n")
+    found = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\S*mhsa_bwd_dkdv1w_kernel\S*):", l)
+        if not m:
+            continue
+        name = m.group(1)
+        found += 1
+        j = i
+        while "s_endpgm" not in lines[j]:
+            j += 1
+        inasm, compiler_agpr, scratch, in_loop = False, [], 0, False
+        body = []                                            # (opcode, operand tokens, in_asm) of every instruction
+        loops = []                                           # MFMA count per innermost loop
+        for b in lines[i:j + 1]:
+            code = b.split(";")[0].strip()
+            if "ASMSTART" in b:
+                inasm = True; continue
+            if "ASMEND" in b:
+                inasm = False; continue
+            if "Inner Loop Header" in b:
+                loops.append(0); in_loop = b.split(":")[0].strip()             # the header's label; the loop ends at the branch back to it
+            if not code or code.endswith(":") or code.startswith("."):
+                continue
+            if not inasm and re.search(r"v_accvgpr|\ba\[\d+:\d+\]|\ba\d+\b", code):
+                compiler_agpr.append(code)
+            scratch += "scratch_" in code
+            parts = code.replace(",", " ").split()
+            body.append((parts[0], parts[1:], inasm))
+            if parts[0].startswith("v_mfma") and in_loop:
+                loops[-1] += 1
+            if (parts[0].startswith("s_cbranch") or parts[0] == "s_branch") and in_loop and parts[1] == in_loop:
+                in_loop = False
+        assert not compiler_agpr, (name, compiler_agpr[:5])
+        assert scratch == 0, name
+        assert 32 in loops, (name, loops)                    # the active waves' slice loop
+        for k, (op, args, _) in enumerate(body):
+            if not op.startswith("v_mfma") or not args[0].startswith("v"):
+                continue                                     # (MFMAs that write AGPRs: their registers are nobody else's)
+            dst, srcc = _reg_set(args[0]), _reg_set(args[3])
+            seen_mfma = 0
+            for op2, args2, _ in body[k + 1:k + 40]:
+                if op2.startswith("v_mfma"):
+                    seen_mfma += 1
+                    if seen_mfma >= 2:
+                        break
+                    continue
+                if op2.startswith("s_") or op2.startswith("buffer_load") or op2 == "s_nop":
+                    continue
+                touched = set().union(*[_reg_set(a) for a in args2]) if args2 else set()
+                assert not (touched & dst), (name, "an instruction touches the VGPRs an asm MFMA is still writing", op, args, op2, args2)
+                if seen_mfma == 0 and op2.startswith("v_") and srcc != dst:
+                    assert not (_reg_set(args2[0]) & srcc), (name, "a vector instruction overwrites the C operand of a running asm MFMA", op, args, op2, args2)
+        meta = "\n".join(x for x in lines if name in x and (".num_agpr" in x or ".private_seg_size" in x))
+        assert re.search(r"\.num_agpr, 192", meta) and re.search(r"\.private_seg_size, 0\b", meta), meta
+    assert found == 3          # <4 waves, 8 stages> for whole 256-key blocks, <1, 4> and <2, 4> for the ragged rest of a head
