@@ -638,6 +638,12 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
         part += __shfl_xor(part, 32, 64);
         dl[qt] = part;
         lse2[qt] = lse[((int64_t)b * H + h) * N + q] * LOG2E;
+        if constexpr (!DROP) {                                        // Q pre-multiplied by scale * log2 e (as the forward kernel does): with the row constants below no per-score arithmetic is left before the v_exp
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (bf16)((float)qf[qt][ks][j] * sl2);
+        }
         if (g == 0 && q0 + 16 * qt + c < N) delta[((int64_t)b * H + h) * N + q] = part;
         // the row statistics in the form the one-wave-per-SIMD dK / dV kernel (attn_bwd1w.hip) streams them by LDS-DMA: [B, H, Npad / 32, 2, 32], per 32-query
         // slice -lse * log2 e | -delta, the padding rows N .. Npad - 1 as -inf | 0 (their probabilities are then exactly zero without masking code)
@@ -654,6 +660,9 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < QT; ++j) acc_dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cl4[QT], cd4[QT];                                           // the row constants as MFMA C operands (no dropout)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { cl4[qt] = f32x4{-lse2[qt], -lse2[qt], -lse2[qt], -lse2[qt]}; cd4[qt] = f32x4{-dl[qt], -dl[qt], -dl[qt], -dl[qt]}; }
 
     const int nkv = (N + 63) / 64;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -686,11 +695,16 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
         const int k0 = t * 64;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            // Without dropout the row constants ride in the MFMAs' C operand (a query is a lane COLUMN of these tiles: the constant is the same in all four
+            // accumulator registers): S' = s * scale * log2 e - lse2 and dP - delta come out of the matrix cores, and a score costs v_exp, v_mul and half a
+            // v_cvt_pk instead of six vector instructions (these kernels are bound by vector issue, profiles/r3_attn_pmc.txt)
             f32x4 acc_s[2][QT], acc_dp[2][QT];
+            if constexpr (DROP) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < QT; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    for (int j = 0; j < QT; ++j) { acc_s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -700,8 +714,13 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
                     bf16x8 vf = frag_rows(imgV, 16 * kt, ks, lane);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
-                        acc_s[h2][qt] = mfma(kf, qf[qt][ks], acc_s[h2][qt]);
-                        acc_dp[h2][qt] = mfma(vf, dof[qt][ks], acc_dp[h2][qt]);
+                        if (!DROP && ks == 0) {
+                            acc_s[h2][qt] = mfma(kf, qf[qt][ks], cl4[qt]);
+                            acc_dp[h2][qt] = mfma(vf, dof[qt][ks], cd4[qt]);
+                        } else {
+                            acc_s[h2][qt] = mfma(kf, qf[qt][ks], acc_s[h2][qt]);
+                            acc_dp[h2][qt] = mfma(vf, dof[qt][ks], acc_dp[h2][qt]);
+                        }
                     }
                 }
             if (k0 + 64 > N) {                // ragged last tile only: p = exp2(-inf) = 0 for keys >= N
@@ -734,10 +753,14 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
 #else
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {                  // (scalar on purpose: packed fp32 instructions beside MFMAs cost more issue time than the two they replace)
+                            if constexpr (!DROP) {
+                                acc_s[h2][qt][r + u] = fast_exp2(acc_s[h2][qt][r + u]) * acc_dp[h2][qt][r + u];                            // p (dP - delta) = dS^T / scale
+                            } else {
                             const float p1 = fast_exp2(acc_s[h2][qt][r + u] * sl2v[0] + nl[0]);
                             float dp1 = acc_dp[h2][qt][r + u];
-                            if constexpr (DROP) dp1 *= drop_scale(drop, rowkey[qt], (uint32_t)(k0 + 16 * (2 * s + h2) + 4 * g + r + u));   // dP_ij = mask_ij (dO_i . V_j)
+                            dp1 *= drop_scale(drop, rowkey[qt], (uint32_t)(k0 + 16 * (2 * s + h2) + 4 * g + r + u));   // dP_ij = mask_ij (dO_i . V_j)
                             acc_s[h2][qt][r + u] = p1 * (dp1 - dlv[0]);                                                                     // dS^T / scale (scale applied once at the end)
+                            }
                         }
 #endif
                     }

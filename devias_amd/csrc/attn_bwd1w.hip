@@ -93,9 +93,10 @@ template <int OFF> __device__ __forceinline__ u32x2 lds_tr_off(unsigned addr) {
 }
 
 #define SB __builtin_amdgcn_sched_barrier(0);
-// -DDKDV_STAMP builds: wave 0 of the first 4096 workgroups of the 256-key launch records the shader clock at kernel entry, loop entry, loop exit and kernel exit
+// -DDKDV_STAMP builds: wave 0 of the first 4096 workgroups of the 256-key launch records the shader clock at [0] kernel entry, [1] loop entry, [2] loop exit, [3] kernel
+// exit, [4] prefill issued, [5] K / V fragments and accumulators in place, [6] slice 0 landed (wait + barrier), [7] epilogue tile in LDS
 // (devias_debug_dkdv_stamps reads them; each stamp drains the wave's LDS / scalar-memory counter, which is harmless at those four points)
-__device__ unsigned long long g_dkdv_stamp[4096][4];
+__device__ unsigned long long g_dkdv_stamp[4096][8];
 #ifdef DKDV_STAMP
 #define STAMP(k) { if (NW == 4 && wave == 0 && blockIdx.x < 4096) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) g_dkdv_stamp[blockIdx.x][k] = t_; } }
 #else
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 #pragma unroll
         for (int k = 0; k < PPW; ++k) { dma_q(s, s * STAGE_BYTES, k); dma_o(s, s * STAGE_BYTES, k); }
     }
+    STAMP(4)
     // Counted waits: all but the DPS * n youngest LDS-DMA instructions of this wave have landed.  (A statistics piece among the youngest makes the wait stricter by
     // one instruction, never laxer; the piece a slice needs is issued in front of that slice's own pieces or earlier.)
 #define WAIT_SLICES_BUT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS * (n)) : "memory");
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
         sfor<128>([&](auto I) { agpr_zero1<decltype(I)::value>(); });
     }
 
+    STAMP(5)
     // ---- loop-invariant LDS byte offsets (the stage offset is added once per slice: nine vector adds) ----------------------------------------------------------------
     int row_a[4], tr_a[2][2];
 #pragma unroll
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
     // ---- prologue: slice 0's row fragments and constants, S / dP of unit (0, 0) -----------------------------------------------------------------------------------
     WAIT_SLICES_BUT(NST - 2)
     if constexpr (NW > 1) __builtin_amdgcn_s_barrier();
+    STAMP(6)
     {
         const lds_cptr cp = lbase + st_a;
 #pragma unroll
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
             *reinterpret_cast<u32x2*>(tile + off) = u32x2{cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3])};
             *reinterpret_cast<u32x2*>(tile + off + 128) = u32x2{cvt_pk_bf16(dv[0], dv[1]), cvt_pk_bf16(dv[2], dv[3])};
         });
+        STAMP(7)
         // (each wave reads back only what it wrote itself: no barrier, the compiler's lgkmcnt wait orders the reads behind the writes)
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 extern "C" int devias_debug_dkdv_stamps(uint64_t* out, int32_t n) {
 #ifdef DKDV_STAMP
     DEVIAS_REQUIRE(out && n > 0 && n <= 4096, "devias_debug_dkdv_stamps: bad args");
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dkdv_stamp), sizeof(unsigned long long) * 4 * n, 0, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dkdv_stamp), sizeof(unsigned long long) * 8 * n, 0, hipMemcpyDeviceToHost) != hipSuccess) {
         (void)hipGetLastError();
         return devias_set_error(DEVIAS_ELAUNCH, "devias_debug_dkdv_stamps: copy failed");
     }

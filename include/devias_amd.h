@@ -123,7 +123,8 @@ int64_t devias_debug_mfma_probe_flops(int32_t n_workgroups, int32_t iters);
 int devias_debug_gemm_timer_arm(int32_t M, int32_t N, int32_t K, int32_t trans_a, int32_t trans_b);
 int devias_debug_gemm_timer_read(int32_t* count, float* total_ms);
 /* Diagnostic builds (-DDKDV_STAMP on csrc/attn_bwd1w.hip) only, DEVIAS_EUNSUPPORTED otherwise: shader-clock stamps of the one-wave-per-SIMD dK / dV kernel's last
- * launch -- per workgroup (the first n <= 4096) kernel entry, loop entry, loop exit, kernel exit -- copied to host memory out[n][4]. */
+ * launch -- per workgroup (the first n <= 4096) eight stamps (csrc/attn_bwd1w.hip: entry, loop entry, loop exit, exit, and four points of prologue / epilogue) -- copied
+ * to host memory out[n][8]. */
 int devias_debug_dkdv_stamps(uint64_t* out, int32_t n);
 
 /* fills: [0]=CU count, [1]=max clock kHz, [2]=LDS bytes per block, [3]=wavefront size, [4]=gfx arch number (e.g. 950) */
