@@ -18,6 +18,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -605,8 +606,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
                                                                int N, int H, float scale, int xcd, DropP drop = DropP{}, float* __restrict__ part_q = nullptr,
                                                                float* __restrict__ stat = nullptr, int Npad = 0) {
     __shared__ __attribute__((aligned(16))) char smem[32768];     // two stages of (K image | V image), filled by LDS-DMA one tile ahead
-    char* imgKt = smem;            // K, one image for both uses: row reads (S^T = K Q^T) and transposed reads (dQ^T = K^T dS^T)
-    char* imgV = smem + 8192;      // V rows   (dP^T = V dO^T)
+    // per stage: K, one image for both uses -- row reads (S^T = K Q^T) and transposed reads (dQ^T = K^T dS^T) -- | V rows (dP^T = V dO^T)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const HeadMap hm = head_map((N + NW * 16 * QT - 1) / (NW * 16 * QT), H, xcd >> 16, (xcd & 1) != 0);
     const int h = hm.h, b = hm.b;
@@ -675,15 +675,17 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
     }
     dK.issue(0, smem, wv);
     dV.issue(0, smem + 8192, wv);
-    for (int t = 0; t < nkv; ++t) {
+    // (two tiles per trip, the LDS stage a compile-time constant in each: every fragment address is then lane offset + immediate -- the run-time stage cost ~36
+    // vector instructions of address arithmetic per tile, in a kernel bound by vector issue)
+    auto tile = [&](int t, auto STG) {
         // one barrier per tile: tile t has landed for every wave, and everyone is done reading tile t-1's stage (rows past N re-read row N-1:
         // finite data whose probabilities are exactly zero)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        imgKt = smem + (t & 1) * 16384;
-        imgV = imgKt + 8192;
+        const char* imgKt = smem + decltype(STG)::value * 16384;
+        const char* imgV = imgKt + 8192;
         if (t + 1 < nkv) {
-            char* nxt = smem + ((t + 1) & 1) * 16384;
+            char* nxt = smem + (1 - decltype(STG)::value) * 16384;
             dK.issue((t + 1) * 64, nxt, wv);
             dV.issue((t + 1) * 64, nxt + 8192, wv);
         }
@@ -776,6 +778,10 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
             }
         }
         }
+    };
+    for (int t = 0; t < nkv; t += 2) {
+        tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nkv) tile(t + 1, std::integral_constant<int, 1>{});
     }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
