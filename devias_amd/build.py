@@ -18,6 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdevias_amd.so")
 SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "layernorm.hip", "attention.hip", "slot_attn.hip", "loss.hip", "fame.hip", "regions.hip", "probe.hip", "attn_bwd1w.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HEADERS = ["common.h", "roctx_shim.h", "attn1w.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
          "-fno-gpu-rdc", "-mllvm", "-amdgpu-early-inline-all=true",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]   # keep MFMA accumulators in VGPRs: no v_accvgpr_* shuffles around the VALU epilogues
@@ -38,7 +39,7 @@ def source_hash() -> str:
     without needing .git (the GPU box has none).  bench.py quotes PMC traffic only from a profile whose hash matches."""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(SOURCES) + ["common.h", "roctx_shim.h"]:
+    for name in sorted(SOURCES) + HEADERS:
         h.update(name.encode()); h.update(open(os.path.join(CSRC, name), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "devias_amd.h"), "rb").read())
     h.update(" ".join(FLAGS).encode())
@@ -50,14 +51,13 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "roctx_shim.h"),
-                                                       os.path.join(HERE, "..", "include", "devias_amd.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "devias_amd.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def _compile(src: str) -> str:
     obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "roctx_shim.h"), os.path.join(HERE, "..", "include", "devias_amd.h")]
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "devias_amd.h")]
     if os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
         return obj
     cmd = [HIPCC] + _flags(src) + ["-c", os.path.join(CSRC, src), "-o", obj]

@@ -1268,8 +1268,12 @@ static inline int64_t attn_stat_bytes(int B, int N, int H) { return (((int64_t)B
 extern "C" int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H) { return attn_stat_bytes(B, N, H); }
 int devias_attn_dkdv1w_launch(const void* qkv, const void* d_o, const float* stat, void* dqkv, int B, int N, int Npad, int H, float scale, int xcd_flag,
                               hipStream_t st);      // attn_bwd1w.hip
+// (A one-wave-per-SIMD dQ kernel was built the same way and is SLOWER than the three-waves-per-SIMD kernel below after its vector-instruction diet -- 445 us
+// against 337 per layer: tools/exp/attn_bwd1w_dq.hip.txt, profiles/r5_dkdv1w_development.txt.  One wave overlaps its own MFMAs and vector instructions only inside
+// the MFMA's shadow; three waves overlap each other's.  The dK / dV kernel wins as one wave because its 128 accumulator registers leave no room for a second.)
 // true = devias_mhsa_bwd* runs the one-wave-per-SIMD dK / dV kernel for this call (bf16, no attention dropout, option attn_dkdv != 0, room for the statistics)
 static inline bool attn_use_dkdv1w(int dtype, float keep) { return dtype == DEVIAS_BF16 && !(keep < 1.0f) && attn_knobs().dkdv != 0; }
+
 
 static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                          int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream,

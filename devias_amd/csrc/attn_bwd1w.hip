@@ -27,72 +27,35 @@
 // slice -lse * log2 e | -delta; Npad = N rounded up to 32; -inf | 0 in the padding, so padded queries have p = 0 with no masking code).  Keys beyond N are computed on
 // clamped rows and never stored.  No v_bias-gradient partials here: softmax rows sum to one, so sum_keys dV = sum_queries dO -- the caller takes that gradient from the
 // column sums of dO (devias_mhsa_bwd_bias).  Deterministic (no atomics), bitwise run-to-run.
-#include "common.h"
-#include <utility>
+#include "attn1w.h"
 
 namespace {
 
-constexpr float LOG2E = 1.4426950408889634f;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef __attribute__((address_space(3))) const char* lds_cptr;
+constexpr float LOG2E = LOG2E_1W;
+enum { NSTATG = 4 /* statistics ring: groups of four slices, 1 KiB each */ };
 
-enum { IMG_BYTES = 4096, STAGE_BYTES = 2 * IMG_BYTES, NSTATG = 4 /* statistics ring: groups of four slices, 1 KiB each */ };
-
-// ---- the slice image: [32 rows][128 B], 16-byte chunk c of row r at r * 128 + ((c ^ swz(r)) << 4) -------------------------------------------------------------
-// Row reads (ds_read_b128, lane = row, chunk 2 ks + hi): the instruction's 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32) need 16 distinct
-// (row & 1, chunk ^ swz) pairs -> swz must be distinct over the four rows of a group with equal (row & 1, (row >> 1) & 1): (row >> 2) & 3 is.
-// Transposed reads (ds_read_b64_tr_b16, 32 lanes = rows r0 .. r0 + 3 (r0 % 4 == 0) x four consecutive chunks x two halves): rows r0 and r0 + 2 share a bank half and
-// must take disjoint chunk sets -> bit 2 of swz = (row >> 1) & 1.  Both kinds of read are conflict-free (measured: SQ_LDS_BANK_CONFLICT = 0).
-__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
-__device__ __forceinline__ int img_off(int row, int c) { return row * 128 + ((c ^ swz(row)) << 4); }
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-    const bf16x2 t = {(bf16)a, (bf16)b};
-    return *reinterpret_cast<const unsigned*>(&t);
-}
-
-// ---- MFMAs on literal accumulator registers -------------------------------------------------------------------------------------------------------------------
 // AGPR map (asm-owned: claimed once, never touched by the compiler -- audited in tests/test_build_cpu.py):
 //   a[  0.. 63]  dV^T[db][kb]  (16 registers each, index db * 2 + kb)        a[128..159]  K fragments [kb][ks] (4 registers each), pre-multiplied by scale log2 e
 //   a[ 64..127]  dK^T[db][kb]                                                a[160..191]  V fragments [kb][ks]
 enum { A_DV = 0, A_DK = 64, A_K = 128, A_V = 160, A_END = 192 };
-// S / dP: D (VGPRs) = A (VGPRs: a Q / dO row fragment) x B (AGPRs: a K / V fragment) + C (VGPRs: the row constants)
+// Diagnostic builds only (tools/build_variant_file.sh <tag> attn_bwd1w -DDKDV_ABL=<mask>; results are then WRONG, the timing is what is read): leave out of the
+// slice loop  1 = the LDS-DMA, 2 = the barrier, 4 = the softmax arithmetic, 8 = the row-fragment / row-constant reads, 16 = the transposed reads, 32 = the counted vmcnt;
+// 64 = a v_mul in place of every v_exp, 128 = a v_perm in place of every v_cvt_pk, 256 = the S / dP MFMAs write (dummy) AGPRs instead of VGPRs,
+// 512 = no wait for the transposed fragments in front of group 4, 1024 = no counted waits for the row fragments in group 3
 #ifndef DKDV_ABL
 #define DKDV_ABL 0
 #endif
+// S / dP: D (VGPRs) = A (VGPRs: a Q / dO row fragment) x B (AGPRs: a K / V fragment) + C (VGPRs: the row constants)
 template <int BREG> __device__ __forceinline__ void mfma_init(f32x16& d, const bf16x8& a, const f32x16& c) {
     if constexpr (DKDV_ABL & 256) { asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" :: "v"(a), "i"(192 + (BREG >= 160 ? 16 : 0)), "i"(207 + (BREG >= 160 ? 16 : 0)), "i"(BREG), "i"(BREG + 3) : "a192", "a223"); asm volatile("" : "+v"(d) : "v"(c)); }
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c3:%c4], %2" : "=&v"(d) : "v"(a), "v"(c), "i"(BREG), "i"(BREG + 3));
+    else mfma_vab_init<BREG>(d, a, c);
 }
 template <int BREG> __device__ __forceinline__ void mfma_more(f32x16& d, const bf16x8& a) {
     if constexpr (DKDV_ABL & 256) { asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, a[%c3:%c4], a[%c1:%c2]" :: "v"(a), "i"(192 + (BREG >= 160 ? 16 : 0)), "i"(207 + (BREG >= 160 ? 16 : 0)), "i"(BREG), "i"(BREG + 3)); asm volatile("" : "+v"(d)); }
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(BREG), "i"(BREG + 3));
+    else mfma_vab_more<BREG>(d, a);
 }
-// dV^T / dK^T: D (AGPRs) += A (VGPRs: a transposed dO / Q fragment) x B (VGPRs: packed P / dS)
-template <int DREG> __device__ __forceinline__ void mfma_agpr(const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "i"(DREG), "i"(DREG + 15));
-}
-#define DEVIAS_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
-__device__ __forceinline__ void agpr_claim() {       // (the clobber list is what makes the kernel descriptor allocate a0 .. a191)
-    asm volatile("" ::: DEVIAS_A10(), DEVIAS_A10(1), DEVIAS_A10(2), DEVIAS_A10(3), DEVIAS_A10(4), DEVIAS_A10(5), DEVIAS_A10(6), DEVIAS_A10(7), DEVIAS_A10(8), DEVIAS_A10(9),
-                 DEVIAS_A10(10), DEVIAS_A10(11), DEVIAS_A10(12), DEVIAS_A10(13), DEVIAS_A10(14), DEVIAS_A10(15), DEVIAS_A10(16), DEVIAS_A10(17), DEVIAS_A10(18),
-                 "a190", "a191");
-}
-template <int I> __device__ __forceinline__ void agpr_zero1() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"i"(I)); }
-template <int I> __device__ __forceinline__ void agpr_write1(unsigned v) { asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "i"(I)); }
-template <int I> __device__ __forceinline__ float agpr_read1() { float x; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(I)); return x; }
-template <typename F, int... N> __device__ __forceinline__ void sfor_seq(F&& f, std::integer_sequence<int, N...>) { (f(std::integral_constant<int, N>{}), ...); }
-template <int COUNT, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_seq(f, std::make_integer_sequence<int, COUNT>{}); }
+__device__ __forceinline__ void agpr_claim() { agpr_claim192(); }
 
-template <int OFF> __device__ __forceinline__ u32x2 lds_tr_off(unsigned addr) {
-    u32x2 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(r) : "v"(addr), "i"(OFF) : "memory");
-    return r;
-}
-
-#define SB __builtin_amdgcn_sched_barrier(0);
 // -DDKDV_STAMP builds: wave 0 of the first 4096 workgroups of the 256-key launch records the shader clock at [0] kernel entry, [1] loop entry, [2] loop exit, [3] kernel
 // exit, [4] prefill issued, [5] K / V fragments and accumulators in place, [6] slice 0 landed (wait + barrier), [7] epilogue tile in LDS
 // (devias_debug_dkdv_stamps reads them; each stamp drains the wave's LDS / scalar-memory counter, which is harmless at those four points)
@@ -101,12 +64,6 @@ __device__ unsigned long long g_dkdv_stamp[4096][8];
 #define STAMP(k) { if (NW == 4 && wave == 0 && blockIdx.x < 4096) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) g_dkdv_stamp[blockIdx.x][k] = t_; } }
 #else
 #define STAMP(k)
-#endif
-// Diagnostic builds only (tools/build_variant_file.sh <tag> attn_bwd1w -DDKDV_ABL=<mask>; results are then WRONG, the timing is what is read): leave out of the
-// slice loop  1 = the LDS-DMA, 2 = the barrier, 4 = the softmax arithmetic, 8 = the row-fragment / row-constant reads, 16 = the transposed reads, 32 = the counted vmcnt;
-// 64 = a v_mul in place of every v_exp, 128 = a v_perm in place of every v_cvt_pk, 256 = the S / dP MFMAs write (dummy) AGPRs instead of VGPRs
-#ifndef DKDV_ABL
-#define DKDV_ABL 0
 #endif
 
 // =================================================================================================================================================================
@@ -272,10 +229,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 #define LD_ROW_(ptr, img) (*reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((ptr) + (img)))
 #define LD_C4_(ptr, which, jj) (*reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((ptr) + 128 * (which) + 32 * (jj)))
 #define SET_C4(V, jj, X) { const f32x4 x_ = (X); V[4 * (jj)] = x_[0]; V[4 * (jj) + 1] = x_[1]; V[4 * (jj) + 2] = x_[2]; V[4 * (jj) + 3] = x_[3]; }
-    auto frag = [&](const u32x2& lo, const u32x2& hi2) -> bf16x8 {
-        const u32x4 w = {lo[0], lo[1], hi2[0], hi2[1]};
-        return *reinterpret_cast<const bf16x8*>(&w);
-    };
+    auto frag = [&](const u32x2& lo, const u32x2& hi2) -> bf16x8 { return frag_of(lo, hi2); };
     auto pfrag = [&](const unsigned (&w)[8], int s) -> bf16x8 {
         const u32x4 v = {w[4 * s], w[4 * s + 1], w[4 * s + 2], w[4 * s + 3]};
         return *reinterpret_cast<const bf16x8*>(&v);
@@ -289,13 +243,8 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 #define PK_(a, b) ((DKDV_ABL & 128) ? __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u) : cvt_pk_bf16(a, b))
 #define EXPG(S_, g) if constexpr (!(DKDV_ABL & 4)) { ev[&S_ == &S1][g] = EXP_(S_[g]); }
 #define FIN(P_, PW_, DW_, g) if constexpr (!(DKDV_ABL & 4)) { constexpr int u_ = 0; (void)u_; const int uu = (&P_ == &P1); if ((g) & 1) { const float d1_ = ev[uu][g] * P_[g]; PW_[(g) >> 1] = PK_(ev[uu][((g) | 1) - 1], ev[uu][g]); DW_[(g) >> 1] = PK_(dvv[uu], d1_); } else dvv[uu] = ev[uu][g] * P_[g]; }
-    // which scores' arithmetic sits in which MFMA gap (gaps 0-7 / 16-23 are beside MFMAs that write VGPRs, 8-15 / 24-31 beside MFMAs that write AGPRs): DKDV_SPLIT
-    // 0 = one score per gap, each finished one gap behind its v_exp; 1 = none beside the VGPR-writing MFMAs, two per other gap; 2 = one v_exp beside each VGPR-writing
-    // MFMA, v_exp + two finishes per other gap; 3 = half a score / one and a half
-#ifndef DKDV_SPLIT
-#define DKDV_SPLIT 0
-#endif
-#if DKDV_SPLIT == 0
+    // which score's arithmetic sits in which MFMA gap: one score per gap, each finished one gap behind its v_exp.  (Other placements -- none beside the MFMAs that
+    // write VGPRs and two per other gap, one v_exp beside each of the former, ... -- measure the same within noise: profiles/r5_dkdv1w_development.txt)
 #define SM_0 FIN(P1, pw1, dw1, 15) EXPG(S0, 0)
 #define SM_1 FIN(P0, pw0, dw0, 0) EXPG(S0, 1)
 #define SM_2 FIN(P0, pw0, dw0, 1) EXPG(S0, 2)
@@ -329,109 +278,6 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 #define SM_30 FIN(P1, pw1, dw1, 13) EXPG(S1, 14)
 #define SM_31 FIN(P1, pw1, dw1, 14) EXPG(S1, 15)
 #define SM_TAIL FIN(P1, pw1, dw1, 15)
-#elif DKDV_SPLIT == 1
-#define SM_0 
-#define SM_1 
-#define SM_2 
-#define SM_3 
-#define SM_4 
-#define SM_5 
-#define SM_6 
-#define SM_7 
-#define SM_8 EXPG(S0, 0) EXPG(S0, 1) FIN(P0, pw0, dw0, 0) FIN(P0, pw0, dw0, 1)
-#define SM_9 EXPG(S0, 2) EXPG(S0, 3) FIN(P0, pw0, dw0, 2) FIN(P0, pw0, dw0, 3)
-#define SM_10 EXPG(S0, 4) EXPG(S0, 5) FIN(P0, pw0, dw0, 4) FIN(P0, pw0, dw0, 5)
-#define SM_11 EXPG(S0, 6) EXPG(S0, 7) FIN(P0, pw0, dw0, 6) FIN(P0, pw0, dw0, 7)
-#define SM_12 EXPG(S0, 8) EXPG(S0, 9) FIN(P0, pw0, dw0, 8) FIN(P0, pw0, dw0, 9)
-#define SM_13 EXPG(S0, 10) EXPG(S0, 11) FIN(P0, pw0, dw0, 10) FIN(P0, pw0, dw0, 11)
-#define SM_14 EXPG(S0, 12) EXPG(S0, 13) FIN(P0, pw0, dw0, 12) FIN(P0, pw0, dw0, 13)
-#define SM_15 EXPG(S0, 14) EXPG(S0, 15) FIN(P0, pw0, dw0, 14) FIN(P0, pw0, dw0, 15)
-#define SM_16 
-#define SM_17 
-#define SM_18 
-#define SM_19 
-#define SM_20 
-#define SM_21 
-#define SM_22 
-#define SM_23 
-#define SM_24 EXPG(S1, 0) EXPG(S1, 1) FIN(P1, pw1, dw1, 0) FIN(P1, pw1, dw1, 1)
-#define SM_25 EXPG(S1, 2) EXPG(S1, 3) FIN(P1, pw1, dw1, 2) FIN(P1, pw1, dw1, 3)
-#define SM_26 EXPG(S1, 4) EXPG(S1, 5) FIN(P1, pw1, dw1, 4) FIN(P1, pw1, dw1, 5)
-#define SM_27 EXPG(S1, 6) EXPG(S1, 7) FIN(P1, pw1, dw1, 6) FIN(P1, pw1, dw1, 7)
-#define SM_28 EXPG(S1, 8) EXPG(S1, 9) FIN(P1, pw1, dw1, 8) FIN(P1, pw1, dw1, 9)
-#define SM_29 EXPG(S1, 10) EXPG(S1, 11) FIN(P1, pw1, dw1, 10) FIN(P1, pw1, dw1, 11)
-#define SM_30 EXPG(S1, 12) EXPG(S1, 13) FIN(P1, pw1, dw1, 12) FIN(P1, pw1, dw1, 13)
-#define SM_31 EXPG(S1, 14) EXPG(S1, 15) FIN(P1, pw1, dw1, 14) FIN(P1, pw1, dw1, 15)
-#define SM_TAIL 
-#elif DKDV_SPLIT == 2
-#define SM_0 EXPG(S0, 0)
-#define SM_1 EXPG(S0, 1)
-#define SM_2 EXPG(S0, 2)
-#define SM_3 EXPG(S0, 3)
-#define SM_4 EXPG(S0, 4)
-#define SM_5 EXPG(S0, 5)
-#define SM_6 EXPG(S0, 6)
-#define SM_7 EXPG(S0, 7)
-#define SM_8 EXPG(S0, 8) FIN(P0, pw0, dw0, 0) FIN(P0, pw0, dw0, 1)
-#define SM_9 EXPG(S0, 9) FIN(P0, pw0, dw0, 2) FIN(P0, pw0, dw0, 3)
-#define SM_10 EXPG(S0, 10) FIN(P0, pw0, dw0, 4) FIN(P0, pw0, dw0, 5)
-#define SM_11 EXPG(S0, 11) FIN(P0, pw0, dw0, 6) FIN(P0, pw0, dw0, 7)
-#define SM_12 EXPG(S0, 12) FIN(P0, pw0, dw0, 8) FIN(P0, pw0, dw0, 9)
-#define SM_13 EXPG(S0, 13) FIN(P0, pw0, dw0, 10) FIN(P0, pw0, dw0, 11)
-#define SM_14 EXPG(S0, 14) FIN(P0, pw0, dw0, 12) FIN(P0, pw0, dw0, 13)
-#define SM_15 EXPG(S0, 15) FIN(P0, pw0, dw0, 14) FIN(P0, pw0, dw0, 15)
-#define SM_16 EXPG(S1, 0)
-#define SM_17 EXPG(S1, 1)
-#define SM_18 EXPG(S1, 2)
-#define SM_19 EXPG(S1, 3)
-#define SM_20 EXPG(S1, 4)
-#define SM_21 EXPG(S1, 5)
-#define SM_22 EXPG(S1, 6)
-#define SM_23 EXPG(S1, 7)
-#define SM_24 EXPG(S1, 8) FIN(P1, pw1, dw1, 0) FIN(P1, pw1, dw1, 1)
-#define SM_25 EXPG(S1, 9) FIN(P1, pw1, dw1, 2) FIN(P1, pw1, dw1, 3)
-#define SM_26 EXPG(S1, 10) FIN(P1, pw1, dw1, 4) FIN(P1, pw1, dw1, 5)
-#define SM_27 EXPG(S1, 11) FIN(P1, pw1, dw1, 6) FIN(P1, pw1, dw1, 7)
-#define SM_28 EXPG(S1, 12) FIN(P1, pw1, dw1, 8) FIN(P1, pw1, dw1, 9)
-#define SM_29 EXPG(S1, 13) FIN(P1, pw1, dw1, 10) FIN(P1, pw1, dw1, 11)
-#define SM_30 EXPG(S1, 14) FIN(P1, pw1, dw1, 12) FIN(P1, pw1, dw1, 13)
-#define SM_31 EXPG(S1, 15) FIN(P1, pw1, dw1, 14) FIN(P1, pw1, dw1, 15)
-#define SM_TAIL 
-#elif DKDV_SPLIT == 3
-#define SM_0 EXPG(S0, 0)
-#define SM_1 FIN(P0, pw0, dw0, 0)
-#define SM_2 EXPG(S0, 1)
-#define SM_3 FIN(P0, pw0, dw0, 1)
-#define SM_4 EXPG(S0, 2)
-#define SM_5 FIN(P0, pw0, dw0, 2)
-#define SM_6 EXPG(S0, 3)
-#define SM_7 FIN(P0, pw0, dw0, 3)
-#define SM_8 EXPG(S0, 4) EXPG(S0, 5) FIN(P0, pw0, dw0, 4) FIN(P0, pw0, dw0, 5)
-#define SM_9 EXPG(S0, 6) FIN(P0, pw0, dw0, 6)
-#define SM_10 EXPG(S0, 7) EXPG(S0, 8) FIN(P0, pw0, dw0, 7) FIN(P0, pw0, dw0, 8)
-#define SM_11 EXPG(S0, 9) FIN(P0, pw0, dw0, 9)
-#define SM_12 EXPG(S0, 10) EXPG(S0, 11) FIN(P0, pw0, dw0, 10) FIN(P0, pw0, dw0, 11)
-#define SM_13 EXPG(S0, 12) FIN(P0, pw0, dw0, 12)
-#define SM_14 EXPG(S0, 13) EXPG(S0, 14) FIN(P0, pw0, dw0, 13) FIN(P0, pw0, dw0, 14)
-#define SM_15 EXPG(S0, 15) FIN(P0, pw0, dw0, 15)
-#define SM_16 EXPG(S1, 0)
-#define SM_17 FIN(P1, pw1, dw1, 0)
-#define SM_18 EXPG(S1, 1)
-#define SM_19 FIN(P1, pw1, dw1, 1)
-#define SM_20 EXPG(S1, 2)
-#define SM_21 FIN(P1, pw1, dw1, 2)
-#define SM_22 EXPG(S1, 3)
-#define SM_23 FIN(P1, pw1, dw1, 3)
-#define SM_24 EXPG(S1, 4) EXPG(S1, 5) FIN(P1, pw1, dw1, 4) FIN(P1, pw1, dw1, 5)
-#define SM_25 EXPG(S1, 6) FIN(P1, pw1, dw1, 6)
-#define SM_26 EXPG(S1, 7) EXPG(S1, 8) FIN(P1, pw1, dw1, 7) FIN(P1, pw1, dw1, 8)
-#define SM_27 EXPG(S1, 9) FIN(P1, pw1, dw1, 9)
-#define SM_28 EXPG(S1, 10) EXPG(S1, 11) FIN(P1, pw1, dw1, 10) FIN(P1, pw1, dw1, 11)
-#define SM_29 EXPG(S1, 12) FIN(P1, pw1, dw1, 12)
-#define SM_30 EXPG(S1, 13) EXPG(S1, 14) FIN(P1, pw1, dw1, 13) FIN(P1, pw1, dw1, 14)
-#define SM_31 EXPG(S1, 15) FIN(P1, pw1, dw1, 15)
-#define SM_TAIL 
-#endif
     // an asm MFMA reads its C operand while it runs; the compiler, which does not see the MFMA, would hand a dead C's registers to the next temporaries
     // (v_exp results) and overwrite them under it: KEEP extends the operand's life past the hazard window (no instruction)
 #define KEEP(V) asm volatile("" ::"v"(V));
@@ -468,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
     // LWAIT(n) = all but the n <= 15 youngest LDS reads are back.  Issue order per iteration: rq0 ro0 rq1 | ro1 T0 | rq2 T1 | ro2 T2 | rq3 T3 | ro3 T4 | T5 | T6 | T7
     // (Tk = the two reads of transposed fragment k), one `|` per MFMA gap from gap 6 on; every wait below is for a read issued at least five gaps earlier.
 #define RLD(dst, a, OFF) if constexpr (!(DKDV_ABL & 8)) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(a), "i"(OFF) : "memory");
-#define LWAIT(n, x) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(n) : "memory");
+#define LWAIT(n, x) if constexpr (!(DKDV_ABL & 1024)) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(n) : "memory");
 #define CWAIT asm volatile("" ::"v"(cL), "v"(cD));
     for (int i = 0; i < nsl; ++i) {
         // slice i + 1 has landed for this wave ... and for every wave; everyone is done with slice i - 1's stage
@@ -513,6 +359,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
         // ---- group 4: dV^T / dK^T of unit (i, 0)   || softmax of unit (i, 1), scores 8..15.  The last transposed read was issued eight MFMAs ago: one wait covers all
         {
             const bf16x8 b0 = pfrag(pw0, 0), e0 = pfrag(dw0, 0), b1 = pfrag(pw0, 1), e1 = pfrag(dw0, 1);
+            if constexpr (!(DKDV_ABL & 512))
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(to[0][0][0]), "+v"(to[0][0][1]), "+v"(tq[0][0][0]), "+v"(tq[0][0][1]), "+v"(to[0][1][0]), "+v"(to[0][1][1]),
                          "+v"(tq[0][1][0]), "+v"(tq[0][1][1]) :: "memory");
             asm volatile("" : "+v"(to[1][0][0]), "+v"(to[1][0][1]), "+v"(tq[1][0][0]), "+v"(tq[1][0][1]), "+v"(to[1][1][0]), "+v"(to[1][1][1]),

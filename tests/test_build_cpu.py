@@ -130,23 +130,24 @@ def _reg_set(tok: str):
 
 
 @pytest.mark.timeout(600)
-def test_one_wave_dkdv_kernels_own_their_agprs_and_keep_their_hazard_windows():
-    """Audit of the one-wave-per-SIMD attention dK / dV kernels (mhsa_bwd_dkdv1w_kernel, devias_amd/csrc/attn_bwd1w.hip).  (1) a[0:191] -- dK / dV accumulators and
-    the K / V fragments -- are named literally in inline asm: the compiler must touch no AGPR itself and spill nothing.  (2) Its MFMAs are inline asm, so the
+@pytest.mark.parametrize("stem,kernel,mfmas,agprs", [("attn_bwd1w", "mhsa_bwd_dkdv1w_kernel", 32, 192)])
+def test_one_wave_attention_backward_kernels_own_their_agprs_and_keep_their_hazard_windows(stem, kernel, mfmas, agprs):
+    """Audit of the one-wave-per-SIMD attention backward kernels (mhsa_bwd_dkdv1w_kernel, devias_amd/csrc/attn_bwd1w.hip; parametrised: a dQ kernel of the same build lives under tools/exp).
+    (1) their accumulators and resident operand fragments (a[0:191] / a[0:127]) are named literally in inline asm: the compiler must touch no AGPR itself and spill nothing.  (2) Its MFMAs are inline asm, so the
     compiler's hazard recognizer does not see them; the source keeps the windows by construction and this test checks the result in the ISA of every
     instantiation: behind an MFMA that writes VGPRs no other instruction reads or writes those VGPRs before two further MFMAs have issued (XDL write -> VALU /
     LDS access needs 11 wait states at 8 passes), and no vector-ALU instruction overwrites the VGPRs of its C operand before one further MFMA has issued (the
-    MFMA reads C while it runs: 7 wait states; LDS loads into those registers return much later and are fine).  (3) the slice loop holds exactly 32 MFMAs."""
-    src = os.path.join(ROOT, "devias_amd", "csrc", "attn_bwd1w.hip")
+    MFMA reads C while it runs: 7 wait states; LDS loads into those registers return much later and are fine).  (3) the slice loop holds exactly 32 (dK / dV) or 24 (dQ) MFMAs."""
+    src = os.path.join(ROOT, "devias_amd", "csrc", stem + ".hip")
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "attn_bwd1w.s")
-        cmd = [build.HIPCC] + list(build._flags("attn_bwd1w.hip")) + ["--cuda-device-only", "-S", src, "-o", out]
+        out = os.path.join(td, stem + ".s")
+        cmd = [build.HIPCC] + list(build._flags(stem + ".hip")) + ["--cuda-device-only", "-S", src, "-o", out]
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = open(out).read().split("\n")
     found = 0
     for i, l in enumerate(lines):
-        m = re.match(r"^(_ZN\S*mhsa_bwd_dkdv1w_kernel\S*):", l)
+        m = re.match(r"^(_ZN\S*" + kernel + r"\S*):", l)
         if not m:
             continue
         name = m.group(1)
@@ -178,7 +179,7 @@ def test_one_wave_dkdv_kernels_own_their_agprs_and_keep_their_hazard_windows():
                 in_loop = False
         assert not compiler_agpr, (name, compiler_agpr[:5])
         assert scratch == 0, name
-        assert 32 in loops, (name, loops)                    # the active waves' slice loop
+        assert mfmas in loops, (name, loops)                    # the active waves' slice loop
         for k, (op, args, _) in enumerate(body):
             if not op.startswith("v_mfma") or not args[0].startswith("v"):
                 continue                                     # (MFMAs that write AGPRs: their registers are nobody else's)
@@ -197,5 +198,5 @@ def test_one_wave_dkdv_kernels_own_their_agprs_and_keep_their_hazard_windows():
                 if seen_mfma == 0 and op2.startswith("v_") and srcc != dst:
                     assert not (_reg_set(args2[0]) & srcc), (name, "a vector instruction overwrites the C operand of a running asm MFMA", op, args, op2, args2)
         meta = "\n".join(x for x in lines if name in x and (".num_agpr" in x or ".private_seg_size" in x))
-        assert re.search(r"\.num_agpr, 192", meta) and re.search(r"\.private_seg_size, 0\b", meta), meta
+        assert re.search(r"\.num_agpr, %d" % agprs, meta) and re.search(r"\.private_seg_size, 0\b", meta), meta
     assert found == 3          # <4 waves, 8 stages> for whole 256-key blocks, <1, 4> and <2, 4> for the ragged rest of a head

@@ -20,7 +20,7 @@ def ref_bwd(qkv, d_o, scale):
 
 
 def run(qkv, o, d_o, lse, B, N, H, opt, bias):
-    ops.set_option("attn_dkdv", opt)
+    ops.set_option("attn_dkdv", 1 if opt else 0)        # opt: 0 = the dK / dV kernel of rounds 2-4, != 0 = the one-wave-per-SIMD kernel
     if bias:
         dbq = torch.zeros(H * 64, device="cuda"); dbv = torch.zeros(H * 64, device="cuda")
         g = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, 0.125, bias_out=(dbq, dbv))
@@ -35,7 +35,7 @@ def rel(a, b):
 def check():
     torch.manual_seed(0)
     bad = 0
-    for (B, N, H) in [(2, 1568, 12), (1, 256, 1), (1, 64, 2), (2, 33, 3), (1, 300, 8), (3, 1000, 4), (1, 6400, 2), (2, 257, 12), (1, 1599, 6), (8, 784, 6)]:
+    for (B, N, H) in [(2, 1568, 12), (1, 256, 1), (1, 64, 2), (2, 33, 3), (1, 300, 8), (2, 100, 3), (1, 1569, 1), (3, 1000, 4), (1, 6400, 2), (2, 257, 12), (1, 1599, 6), (8, 784, 6)]:
         qkv = (torch.randn(B, N, 3, H, 64, device="cuda") * 1.5).to(torch.bfloat16)
         d_o = torch.randn(B, N, H * 64, device="cuda").to(torch.bfloat16)
         o, lse = ops.mhsa_fwd(qkv.view(B * N, 3 * H * 64), B, N, H, 0.125)
@@ -43,10 +43,10 @@ def check():
         ref = ref_bwd(qkv, d_o, 0.125) if B * H * N * N <= 4e8 else None
         for bias in (False, True):
             g0, bq0, bv0 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 0, bias)
-            g1, bq1, bv1 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 1, bias)
-            g2, bq2, bv2 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 1, bias)
+            g1, bq1, bv1 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 2, bias)
+            g2, bq2, bv2 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 2, bias)
             torch.cuda.synchronize()
-            same = torch.equal(g1, g2) and (not bias or torch.equal(bv1, bv2))
+            same = torch.equal(g1, g2) and (not bias or (torch.equal(bv1, bv2) and torch.equal(bq1, bq2)))
             fin = bool(torch.isfinite(g1.float()).all())
             e_dq = rel(g1[:, :, 0], g0[:, :, 0]); e_dk = rel(g1[:, :, 1], g0[:, :, 1]); e_dv = rel(g1[:, :, 2], g0[:, :, 2])
             msg = f"B={B} N={N} H={H} bias={int(bias)}: new vs old dQ {e_dq:.1e} dK {e_dk:.1e} dV {e_dv:.1e}"
@@ -55,9 +55,10 @@ def check():
                 msg += f" | dbv vs sum(dV fp32 ref) {rel(bv1, ref[:, :, 2].sum((0, 1)).reshape(-1)):.1e}" if ref is not None else ""
             if ref is not None:
                 msg += f" | vs fp32: old dK {rel(g0[:, :, 1], ref[:, :, 1]):.1e} dV {rel(g0[:, :, 2], ref[:, :, 2]):.1e}; new dK {rel(g1[:, :, 1], ref[:, :, 1]):.1e} dV {rel(g1[:, :, 2], ref[:, :, 2]):.1e}"
-            ok = same and fin and e_dq == 0.0 and e_dk < 2e-2 and e_dv < 2e-2
+            ok = same and fin and e_dq < 2.5e-2 and e_dk < 2.5e-2 and e_dv < 2.5e-2 and (not bias or rel(bq1, bq0) < 5e-3)
             if ref is not None:
-                ok = ok and rel(g1[:, :, 1], ref[:, :, 1]) < 2e-2 and rel(g1[:, :, 2], ref[:, :, 2]) < 2e-2
+                msg += f" dQ old {rel(g0[:, :, 0], ref[:, :, 0]):.1e} new {rel(g1[:, :, 0], ref[:, :, 0]):.1e}"
+                ok = ok and rel(g1[:, :, 0], ref[:, :, 0]) < 2.5e-2 and rel(g1[:, :, 1], ref[:, :, 1]) < 2.5e-2 and rel(g1[:, :, 2], ref[:, :, 2]) < 2.5e-2
             bad += 0 if ok else 1
             print(("ok   " if ok else "FAIL ") + msg + ("" if same else " NOT BITWISE run-to-run") + ("" if fin else " NON-FINITE"), flush=True)
     print("ALL OK" if bad == 0 else f"{bad} FAILED", flush=True)
