@@ -306,7 +306,6 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
     SB
 
     STAMP(1)
-    int st_i = 0, st_n = STAGE_BYTES, st_d = (NST - 1) * STAGE_BYTES;      // stage offsets of slice i, slice i + 1, and of the slice the DMA of this iteration fills
     int sc_n = 256;                                                          // offset of slice i + 1's constants in the statistics ring
     // LDS reads of the loop.  The row constants (cL / cD: sixteen registers each, filled four at a time) are plain loads: the compiler, which counts only its own LDS
     // instructions, waits for them at CWAIT -- placed BEFORE the first asm read of the iteration, so that its lgkmcnt(0) never sits behind a young read it does not
@@ -316,13 +315,17 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 #define RLD(dst, a, OFF) if constexpr (!(DKDV_ABL & 8)) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(a), "i"(OFF) : "memory");
 #define LWAIT(n, x) if constexpr (!(DKDV_ABL & 1024)) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(n) : "memory");
 #define CWAIT asm volatile("" ::"v"(cL), "v"(cD));
-    for (int i = 0; i < nsl; ++i) {
+    // One slice per call; NST calls per trip of the loop below, the ring stage of slice i a compile-time constant in each: the stage offsets of slice i (transposed
+    // reads), slice i + 1 (row reads) and of the slice this iteration's DMA fills fold into the instructions' immediates -- with run-time stages the loop carried nine
+    // vector adds and the scalar bookkeeping of three ring cursors per slice, in a wave whose issue slots are the bound.
+    auto slice_step = [&](const int i, auto STG) {
+        constexpr int st_i = decltype(STG)::value * STAGE_BYTES, st_n = ((decltype(STG)::value + 1) % NST) * STAGE_BYTES, st_d = ((decltype(STG)::value + NST - 1) % NST) * STAGE_BYTES;
         // slice i + 1 has landed for this wave ... and for every wave; everyone is done with slice i - 1's stage
         if constexpr (!(DKDV_ABL & 32)) WAIT_SLICES_BUT(NST - 3)
         if constexpr (NW > 1 && !(DKDV_ABL & 2)) __builtin_amdgcn_s_barrier();
-        const unsigned rp0 = (unsigned)(st_n + row_a[0]), rp1 = (unsigned)(st_n + row_a[1]), rp2 = (unsigned)(st_n + row_a[2]), rp3 = (unsigned)(st_n + row_a[3]);
+        const unsigned rp0 = (unsigned)row_a[0], rp1 = (unsigned)row_a[1], rp2 = (unsigned)row_a[2], rp3 = (unsigned)row_a[3];      // (+ st_n: an immediate of the read)
         const lds_cptr cp = lbase + sc_n + st_a;
-        const unsigned t00 = (unsigned)(st_i + tr_a[0][0]), t10 = (unsigned)(st_i + tr_a[1][0]), t01 = (unsigned)(st_i + tr_a[0][1]), t11 = (unsigned)(st_i + tr_a[1][1]);
+        const unsigned t00 = (unsigned)tr_a[0][0], t10 = (unsigned)tr_a[1][0], t01 = (unsigned)tr_a[0][1], t11 = (unsigned)tr_a[1][1];   // (+ st_i)
         SB
         // ---- group 1: S / dP of unit (i, 1)   || softmax of unit (i, 0), scores 0..7; the DMA of slice i + NST - 1; the row constants of slice i + 1
         mfma_init<A_K + 16>(S1, rq[0], cL);  SM_0  if constexpr (!(DKDV_ABL & 1)) dma_s(i + NST - 1);  DMA_Q(0)  SB
@@ -331,28 +334,28 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
         mfma_more<A_V + 20>(P1, ro[1]);      SM_3  DMA_O(1)  KEEP(cD)  LDL_C4(cD, 0, cp, 1) LDL_C4(cD, 1, cp, 1) LDL_C4(cD, 2, cp, 1) LDL_C4(cD, 3, cp, 1)  SB
         mfma_more<A_K + 24>(S1, rq[2]);      SM_4  DMA_Q(2)  SB
         mfma_more<A_V + 24>(P1, ro[2]);      SM_5  DMA_O(2)  SB
-        mfma_more<A_K + 28>(S1, rq[3]);      SM_6  DMA_Q(3)  CWAIT  RLD(rq[0], rp0, 0)  SB
-        mfma_more<A_V + 28>(P1, ro[3]);      SM_7  DMA_O(3)  RLD(ro[0], rp0, IMG_BYTES)  SB
+        mfma_more<A_K + 28>(S1, rq[3]);      SM_6  DMA_Q(3)  CWAIT  RLD(rq[0], rp0, st_n + 0)  SB
+        mfma_more<A_V + 28>(P1, ro[3]);      SM_7  DMA_O(3)  RLD(ro[0], rp0, st_n + IMG_BYTES)  SB
         // ---- group 2: dV^T / dK^T of unit (i - 1, 1)   || softmax of unit (i, 0), scores 8..15; the row fragments of slice i + 1 (each behind the MFMA that read
         //      the old one) and the transposed fragments of slice i (each behind the MFMA that consumed its previous contents, in the order group 4 consumes them)
         {
             const bf16x8 b0 = pfrag(pw1, 0), e0 = pfrag(dw1, 0), b1 = pfrag(pw1, 1), e1 = pfrag(dw1, 1);
-            mfma_agpr<A_DV + 16>(frag(to[0][0][0], to[0][0][1]), b0);  SM_8   RLD(rq[1], rp1, 0)  SB
-            mfma_agpr<A_DK + 16>(frag(tq[0][0][0], tq[0][0][1]), e0);  SM_9   RLD(ro[1], rp1, IMG_BYTES)  TRL(to[0][0][0], IMG_BYTES, t00)  TRL(to[0][0][1], IMG_BYTES, t10)  SB
-            mfma_agpr<A_DV + 48>(frag(to[0][1][0], to[0][1][1]), b0);  SM_10  RLD(rq[2], rp2, 0)          TRL(tq[0][0][0], 0, t00)          TRL(tq[0][0][1], 0, t10)          SB
-            mfma_agpr<A_DK + 48>(frag(tq[0][1][0], tq[0][1][1]), e0);  SM_11  RLD(ro[2], rp2, IMG_BYTES)  TRL(to[0][1][0], IMG_BYTES, t01)  TRL(to[0][1][1], IMG_BYTES, t11)  SB
-            mfma_agpr<A_DV + 16>(frag(to[1][0][0], to[1][0][1]), b1);  SM_12  RLD(rq[3], rp3, 0)          TRL(tq[0][1][0], 0, t01)          TRL(tq[0][1][1], 0, t11)          SB
-            mfma_agpr<A_DK + 16>(frag(tq[1][0][0], tq[1][0][1]), e1);  SM_13  RLD(ro[3], rp3, IMG_BYTES)  TRL(to[1][0][0], IMG_BYTES + 2048, t00)  TRL(to[1][0][1], IMG_BYTES + 2048, t10)  SB
-            mfma_agpr<A_DV + 48>(frag(to[1][1][0], to[1][1][1]), b1);  SM_14  TRL(tq[1][0][0], 2048, t00)  TRL(tq[1][0][1], 2048, t10)  SB
-            mfma_agpr<A_DK + 48>(frag(tq[1][1][0], tq[1][1][1]), e1);  SM_15  TRL(to[1][1][0], IMG_BYTES + 2048, t01)  TRL(to[1][1][1], IMG_BYTES + 2048, t11)  SB
+            mfma_agpr<A_DV + 16>(frag(to[0][0][0], to[0][0][1]), b0);  SM_8   RLD(rq[1], rp1, st_n + 0)  SB
+            mfma_agpr<A_DK + 16>(frag(tq[0][0][0], tq[0][0][1]), e0);  SM_9   RLD(ro[1], rp1, st_n + IMG_BYTES)  TRL(to[0][0][0], st_i + IMG_BYTES, t00)  TRL(to[0][0][1], st_i + IMG_BYTES, t10)  SB
+            mfma_agpr<A_DV + 48>(frag(to[0][1][0], to[0][1][1]), b0);  SM_10  RLD(rq[2], rp2, st_n + 0)          TRL(tq[0][0][0], st_i + 0, t00)          TRL(tq[0][0][1], st_i + 0, t10)          SB
+            mfma_agpr<A_DK + 48>(frag(tq[0][1][0], tq[0][1][1]), e0);  SM_11  RLD(ro[2], rp2, st_n + IMG_BYTES)  TRL(to[0][1][0], st_i + IMG_BYTES, t01)  TRL(to[0][1][1], st_i + IMG_BYTES, t11)  SB
+            mfma_agpr<A_DV + 16>(frag(to[1][0][0], to[1][0][1]), b1);  SM_12  RLD(rq[3], rp3, st_n + 0)          TRL(tq[0][1][0], st_i + 0, t01)          TRL(tq[0][1][1], st_i + 0, t11)          SB
+            mfma_agpr<A_DK + 16>(frag(tq[1][0][0], tq[1][0][1]), e1);  SM_13  RLD(ro[3], rp3, st_n + IMG_BYTES)  TRL(to[1][0][0], st_i + IMG_BYTES + 2048, t00)  TRL(to[1][0][1], st_i + IMG_BYTES + 2048, t10)  SB
+            mfma_agpr<A_DV + 48>(frag(to[1][1][0], to[1][1][1]), b1);  SM_14  TRL(tq[1][0][0], st_i + 2048, t00)  TRL(tq[1][0][1], st_i + 2048, t10)  SB
+            mfma_agpr<A_DK + 48>(frag(tq[1][1][0], tq[1][1][1]), e1);  SM_15  TRL(to[1][1][0], st_i + IMG_BYTES + 2048, t01)  TRL(to[1][1][1], st_i + IMG_BYTES + 2048, t11)  SB
         }
-        // ---- group 3: S / dP of unit (i + 1, 0)   || softmax of unit (i, 1), scores 0..7; the last transposed fragment.  (reads issued after rq0: 21, after ro0: 22
-        //      incl. the two of this group, ... : the counted waits below)
-        LWAIT(15, rq[0])  mfma_init<A_K + 0>(S0, rq[0], cL);   TRL(tq[1][1][0], 2048, t01)  TRL(tq[1][1][1], 2048, t11)  SM_16  SB
-        LWAIT(15, ro[0])  mfma_init<A_V + 0>(P0, ro[0], cD);   SM_17  SB
-        LWAIT(15, rq[1])  mfma_more<A_K + 4>(S0, rq[1]);       SM_18  SB
-        LWAIT(15, ro[1])  mfma_more<A_V + 4>(P0, ro[1]);       SM_19  SB
-        LWAIT(15, rq[2])  mfma_more<A_K + 8>(S0, rq[2]);       SM_20  SB
+        // ---- group 3: S / dP of unit (i + 1, 0)   || softmax of unit (i, 1), scores 0..7; the last transposed fragment.  22 reads have been issued when the first
+        //      wait runs: lgkmcnt(15) = the seven oldest are back -- rq0 ro0 rq1 ro1 T0 rq2, what the first five MFMAs need; then one counted wait per row fragment
+        LWAIT(15, rq[0])  mfma_init<A_K + 0>(S0, rq[0], cL);   TRL(tq[1][1][0], st_i + 2048, t01)  TRL(tq[1][1][1], st_i + 2048, t11)  SM_16  SB
+                          mfma_init<A_V + 0>(P0, ro[0], cD);   SM_17  SB
+                          mfma_more<A_K + 4>(S0, rq[1]);       SM_18  SB
+                          mfma_more<A_V + 4>(P0, ro[1]);       SM_19  SB
+                          mfma_more<A_K + 8>(S0, rq[2]);       SM_20  SB
         LWAIT(14, ro[2])  mfma_more<A_V + 8>(P0, ro[2]);       SM_21  SB
         LWAIT(11, rq[3])  mfma_more<A_K + 12>(S0, rq[3]);      SM_22  SB
         LWAIT(8, ro[3])   mfma_more<A_V + 12>(P0, ro[3]);      SM_23  SB
@@ -373,8 +376,13 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
             mfma_agpr<A_DV + 32>(frag(to[1][1][0], to[1][1][1]), b1);  SM_30  SB
             mfma_agpr<A_DK + 32>(frag(tq[1][1][0], tq[1][1][1]), e1);  SM_31  SB
         }
-        st_d = st_i; st_i = st_n; st_n += STAGE_BYTES; if (st_n == RING) st_n = 0;
         sc_n = (sc_n + 256) & (NSTATG * 1024 - 1);
+    };
+    for (int i = 0; i < nsl; i += NST) {
+        sfor<NST>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            if (k == 0 || i + k < nsl) slice_step(i + k, K);
+        });
     }
     STAMP(2)
     // ---- drain: the last score of unit (nsl - 1, 1), then its dV^T / dK^T ---------------------------------------------------------------------------------------------
