@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary full-step number (teacher fwd + AdamW)")
+    ap.add_argument("--no-probes", action="store_true", help="skip the kernel probes (dominant kernel, fc1 forward, sustained MFMA rate): for runs under rocprofv3, whose "
+                    "per-step kernel statistics must contain the training steps only")
     ap.add_argument("--comm-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce (N > 1)")
     ap.add_argument("--force-gradsync", action="store_true", help="N = 1 only: run the whole gradient-bucket path (hooks, events, side stream) with the "
                     "collective replaced by a same-size device copy on the side stream")
@@ -445,7 +447,10 @@ def main():
         "host_idle_enqueue_method": "one step enqueued on an idle stream, median of 5, outside the timed region (python + fused-region library calls + HIP launches)",
         "device_ms_per_step": dev_ms / args.steps, "final_loss": loss_value, "peak_mem_gib": peak_mem,
     }
-    if ach is not None:
+    if ach is not None and args.no_probes:
+        line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                            "scope": f"whole step per GPU: {gflop} algorithmic GFLOP/clip x {B} clips / step time", "note": "--no-probes: kernel probes skipped"}
+    elif ach is not None:
         in_step = step if world == 1 else None            # (at N > 1 a step contains collectives: rank 0 cannot run one alone)
         dom = trace_top_kernel_probe(args, device, in_step)
         sus = sustained_mfma_probe(device) if args.dtype == "bf16" else None

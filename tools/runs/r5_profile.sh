@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5p; mkdir -p $O
 cd $R
 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-full-step > $O/bench_profiled.json 2> $O/trace.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-full-step --no-probes > $O/bench_profiled.json 2> $O/trace.err
 cd $R
 S=$(find $O/trace -name "*kernel_stats.csv" | head -1); T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 cp $S $O/kernel_stats.csv; python3 tools/kernel_families.py $S 15 > $O/kernel_families.txt; cat $O/kernel_families.txt
