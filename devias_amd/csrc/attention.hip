@@ -1190,7 +1190,7 @@ AttnKnobs& attn_knobs() {
 static int* attn_option_slot(const char* name) {
     if (!strcmp(name, "attn_cfg")) return &attn_knobs().cfg;
     if (!strcmp(name, "attn_xcd")) return &attn_knobs().xcd;
-    if (!strcmp(name, "attn_dkdv")) return &attn_knobs().dkdv;              // 1 (default): dK / dV by the one-wave-per-SIMD kernel (attn_bwd1w.hip); 0: the two-waves-per-SIMD kernel
+    if (!strcmp(name, "attn_dkdv")) return &attn_knobs().dkdv;              // 1 (default): dK / dV by the one-wave-per-SIMD kernel (attn_bwd1w.hip), one workgroup per 256-key block; 2: the same kernel, one persistent workgroup per CU (the kernel alone -2 %, the step +-0: DESIGN.md section 5 round 5); 0: the two-waves-per-SIMD kernel
     if (!strcmp(name, "attn_bias_fused")) return &attn_knobs().bias_fused;      // 0: devias_mhsa_bwd_bias takes the bias gradients by column-sum passes in bf16 too (A/B aid)
     return nullptr;
 }
@@ -1267,7 +1267,7 @@ static inline int attn_npad(int N) { return (N + 31) & ~31; }
 static inline int64_t attn_stat_bytes(int B, int N, int H) { return (((int64_t)B * H * 2 * attn_npad(N) * 4) + 255) & ~(int64_t)255; }
 extern "C" int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H) { return attn_stat_bytes(B, N, H); }
 int devias_attn_dkdv1w_launch(const void* qkv, const void* d_o, const float* stat, void* dqkv, int B, int N, int Npad, int H, float scale, int xcd_flag,
-                              hipStream_t st);      // attn_bwd1w.hip
+                              int persistent, hipStream_t st);      // attn_bwd1w.hip
 // (A one-wave-per-SIMD dQ kernel was built the same way and is SLOWER than the three-waves-per-SIMD kernel below after its vector-instruction diet -- 445 us
 // against 337 per layer: tools/exp/attn_bwd1w_dq.hip.txt, profiles/r5_dkdv1w_development.txt.  One wave overlaps its own MFMAs and vector instructions only inside
 // the MFMA's shadow; three waves overlap each other's.  The dK / dV kernel wins as one wave because its 128 accumulator registers leave no room for a second.)
@@ -1304,7 +1304,7 @@ static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
 #undef DQ_ARGS
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dq)");
         if (w1) {
-            const int rc = devias_attn_dkdv1w_launch(qkv, d_o, stat, dqkv, B, N, npad, H, scale, xcd, st);
+            const int rc = devias_attn_dkdv1w_launch(qkv, d_o, stat, dqkv, B, N, npad, H, scale, xcd, attn_knobs().dkdv == 2, st);
             if (rc != DEVIAS_OK) return rc;
         } else if (drop) hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<true>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
                                      lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_v);

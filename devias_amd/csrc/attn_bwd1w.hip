@@ -23,6 +23,14 @@
 //     p = exp2(S'), p * (dP - delta) = dS / scale; dK is scaled by `scale` once at the end.
 //   * epilogue: the tile goes through LDS so that every store instruction writes eight whole 128-byte rows (row-per-lane stores touch 64 lines each).
 //
+//   * PERSIST (option attn_dkdv = 2; not the default): one workgroup per CU walks the 256-key blocks w, w + grid, ...: the Q / dO ring never drains (the last
+//     iterations of a block request the next block's first slices instead of re-reads; slice i of a block runs as unrolled copy (k0 + i) mod NST so that ring
+//     stages stay compile-time constants), the next block's K / V rows are requested before the drain and the epilogue of the current one, the epilogue has its own
+//     LDS behind the rings.  Bitwise equal to the one-block-per-workgroup form.  Measured: a block switch costs 9.7k cycles against 9.8k (prologue) + 4.1k (epilogue)
+//     -- most of both is instruction issue (128 + 192 accumulator-register moves, 16 row-scattered K / V loads, the tile's trip through LDS), which nothing hides at
+//     one wave per SIMD; the kernel alone 427 -> 420 us, the step +-0 (+0.06 ms, in-process A/B): DESIGN.md section 5, round 5.  Static lists also lose their
+//     balance when another kernel holds CUs (the GEMMs' round-4 lesson), so the default stays one workgroup per block.
+//
 // The row statistics come pre-scaled and padded from the dQ kernel, which reads lse and computes delta anyway: stat [B, H, Npad / 32, 2, 32] fp32 (per 32-query
 // slice -lse * log2 e | -delta; Npad = N rounded up to 32; -inf | 0 in the padding, so padded queries have p = 0 with no masking code).  Keys beyond N are computed on
 // clamped rows and never stored.  No v_bias-gradient partials here: softmax rows sum to one, so sum_keys dV = sum_queries dO -- the caller takes that gradient from the
@@ -60,48 +68,85 @@ __device__ __forceinline__ void agpr_claim() { agpr_claim192(); }
 // exit, [4] prefill issued, [5] K / V fragments and accumulators in place, [6] slice 0 landed (wait + barrier), [7] epilogue tile in LDS
 // (devias_debug_dkdv_stamps reads them; each stamp drains the wave's LDS / scalar-memory counter, which is harmless at those four points)
 __device__ unsigned long long g_dkdv_stamp[4096][8];
+#ifndef DKDV_STAMP_ITEM
+#define DKDV_STAMP_ITEM 0          // which of a persistent workgroup's items is stamped (0 = its first: with the prefill; 1 = its second: [0] is then the moment the first item is done)
+#endif
 #ifdef DKDV_STAMP
-#define STAMP(k) { if (NW == 4 && wave == 0 && blockIdx.x < 4096) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) g_dkdv_stamp[blockIdx.x][k] = t_; } }
+#define STAMP_REC(idx) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) g_dkdv_stamp[blockIdx.x][idx] = t_; }
+#define STAMP(k) { if (NW == 4 && wave == 0 && blockIdx.x < 4096) { \
+    if (stamp_item == DKDV_STAMP_ITEM && !(DKDV_STAMP_ITEM != 0 && ((k) == 0 || (k) == 4 || (k) == 5))) STAMP_REC(k) \
+    else if (DKDV_STAMP_ITEM != 0 && stamp_item == DKDV_STAMP_ITEM - 1 && ((k) == 2 || (k) == 3)) STAMP_REC((k) + 2) } }      /* ITEM != 0: [4] / [5] = loop exit / stores issued of the item before */
+#define STAMP_NEXT { ++stamp_item; if (NW == 4 && wave == 0 && blockIdx.x < 4096 && stamp_item == DKDV_STAMP_ITEM) STAMP_REC(0) }
 #else
 #define STAMP(k)
+#define STAMP_NEXT
 #endif
 
 // =================================================================================================================================================================
 // NW waves of 64 keys; the workgroup's first key is key_first + 64 NW * (its index within the head): the main launch covers the whole 256-key blocks (key_first = 0),
 // the rest launch the ragged end (key_first = 256 * (N / 256), one workgroup per head).  NST = stages of the Q / dO ring.
-template <int NW, int NST>
+template <int NW, int NST, bool PERSIST>
 __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o, const float* __restrict__ stat,
                                                                   bf16* __restrict__ dqkv, int N, int Npad, int H, int B, float scale, int xcd, int key_first, int nblk) {
     enum { PPW = 4 / NW /* 1 KiB pieces of each image per wave and slice */, DPS = 2 * PPW /* counted DMA instructions per wave and slice */,
-           RING = NST * STAGE_BYTES, EPI = NW * 16384, LDS_BYTES = (RING + NSTATG * 1024) > EPI ? (RING + NSTATG * 1024) : EPI };
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];      // | Q / dO ring | statistics ring |   (epilogue: one 16 KiB tile per wave)
+           RING = NST * STAGE_BYTES, EPI = NW * 16384, EPI_OFF = PERSIST ? RING + NSTATG * 1024 : 0,
+           LDS_BYTES = PERSIST ? EPI_OFF + EPI : ((RING + NSTATG * 1024) > EPI ? (RING + NSTATG * 1024) : EPI) };
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];      // | Q / dO ring | statistics ring |   epilogue: one 16 KiB tile per wave (PERSIST: behind the rings, which stay live)
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, r32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int stamp_item = 0; (void)stamp_item;
     STAMP(0)
-    int blk, h, b;
-    if (xcd & 1) {                                     // all workgroups of one (batch, head) on one XCD (attention.hip head_map): its Q / dO rows stay in that L2
-        const int bid = blockIdx.x, x = bid & 7, slot = bid >> 3, hidx = (slot / nblk) * 8 + x;
-        blk = slot - (slot / nblk) * nblk; h = hidx % H; b = hidx / H;
-    } else { blk = blockIdx.x; h = blockIdx.y; b = blockIdx.z; }
     const int D = H * 64;
     const int64_t RS = 3 * (int64_t)D;
-    const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
-    const bf16* dobase = d_o + (int64_t)b * N * D + h * 64;
-    const float* stbase = stat + ((int64_t)b * H + h) * 2 * Npad;
-    const int key0 = key_first + blk * (64 * NW) + wave * 64;
-    const bool active = key0 < N;                       // (a wave without a valid key only stages and synchronises)
     const int nsl = Npad >> 5;                          // query slices
+    const int ngrp = (nsl + 3) >> 2;                    // statistics pieces (groups of four slices) per head
+    // item -> (batch, head, key block).  xcd & 1: all workgroups of one (batch, head) on one XCD (attention.hip head_map): its Q / dO rows stay in that L2.
+    // PERSIST (whole 256-key blocks, xcd order only): the grid is a multiple of 8 workgroups, workgroup w takes items w, w + grid, ... -- an item stays on the
+    // XCD of its head, and a head's blocks run at the same time on neighbouring workgroups
+    const int nitems = PERSIST ? nblk * H * B : 0, istride = PERSIST ? (int)gridDim.x : 0;
+    int item = blockIdx.x;
+    struct Item { int b, h, blk; };
+    auto decode = [&](int it) -> Item {
+        Item r;
+        if (PERSIST || (xcd & 1)) {
+            const int x = it & 7, slot = it >> 3, hidx = (slot / nblk) * 8 + x;
+            r.blk = slot - (slot / nblk) * nblk; r.h = hidx % H; r.b = hidx / H;
+        } else { r.blk = blockIdx.x; r.h = blockIdx.y; r.b = blockIdx.z; }
+        return r;
+    };
+    Item cur = decode(item);
+    int b = cur.b, h = cur.h;
+    const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
+    int key0 = key_first + cur.blk * (64 * NW) + wave * 64;
+    const bool active = PERSIST || key0 < N;            // (a wave without a valid key only stages and synchronises; the 256-key blocks have none)
 
     // ---- LDS-DMA: per wave and slice PPW 1 KiB pieces of the Q image (piece p = rows 8 p .. + 8), PPW of the dO image; with every fourth slice the 1 KiB of row
     // statistics of four slices (every wave writes the same bytes: the duplicate costs less than a wave-dependent vmcnt count) ----------------------------------------
+    // PERSIST: the descriptors span the whole tensors and an item is a scalar byte offset (offq / offo / offs; *_n: the NEXT item's, whose first NST - 1 slices the
+    // last iterations of this item's loop request in place of the harmless re-reads, so that the ring never drains between items)
     __amdgpu_buffer_rsrc_t rs_q, rs_o, rs_s;
     uint32_t vo_q[PPW], vo_o[PPW];
+    int offq = 0, offo = 0, offs = 0, offq_n = 0, offo_n = 0, offs_n = 0;
+    int gb = 0;                                               // statistics ring: piece g of this item sits in slot (gb + g) mod NSTATG
+    auto item_offsets = [&](const Item& t, int& oq, int& oo, int& os) {
+        oq = (int)((((int64_t)t.b * N) * RS + t.h * 64) * 2); oo = (int)((((int64_t)t.b * N) * D + t.h * 64) * 2); os = (int)((((int64_t)t.b * H + t.h) * 2 * Npad) * 4);
+    };
     {
-        const int64_t left_q = ((int64_t)B - b) * N * RS - h * 64, left_o = ((int64_t)B - b) * N * D - h * 64;
-        const int64_t bq = left_q * 2, bo = left_o * 2;
-        rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base), 0, (int)(bq < 0x7fffffff ? bq : 0x7fffffff), 0x00020000);
-        rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(dobase), 0, (int)(bo < 0x7fffffff ? bo : 0x7fffffff), 0x00020000);
-        rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stbase), 0, 2 * Npad * 4, 0x00020000);
+        if constexpr (PERSIST) {
+            const int64_t bq = (int64_t)B * N * RS * 2, bo = (int64_t)B * N * D * 2, bs = (int64_t)B * H * 2 * Npad * 4;      // (< 2^31: the launcher checks)
+            rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(qkv), 0, (int)bq, 0x00020000);
+            rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(d_o), 0, (int)bo, 0x00020000);
+            rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stat), 0, (int)bs, 0x00020000);
+            item_offsets(cur, offq, offo, offs);
+        } else {
+            const bf16* dobase = d_o + (int64_t)b * N * D + h * 64;
+            const float* stbase = stat + ((int64_t)b * H + h) * 2 * Npad;
+            const int64_t left_q = ((int64_t)B - b) * N * RS - h * 64, left_o = ((int64_t)B - b) * N * D - h * 64;
+            const int64_t bq = left_q * 2, bo = left_o * 2;
+            rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base), 0, (int)(bq < 0x7fffffff ? bq : 0x7fffffff), 0x00020000);
+            rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(dobase), 0, (int)(bo < 0x7fffffff ? bo : 0x7fffffff), 0x00020000);
+            rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(stbase), 0, 2 * Npad * 4, 0x00020000);
+        }
 #pragma unroll
         for (int k = 0; k < PPW; ++k) {
             const int row = (wave + NW * k) * 8 + (lane >> 3), c = (lane & 7) ^ swz(row);
@@ -111,29 +156,35 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
     }
     const uint32_t vo_s = (uint32_t)(lane * 16);
     const int qstride = (int)RS * 64, ostride = D * 64;      // bytes per slice of 32 rows
-    // slice -> stage `stage_off` (a byte offset into the ring, kept in scalar registers by the callers: slice mod NST never becomes a division)
+    // slice -> stage `stage_off` (a byte offset into the ring, a compile-time constant in the loop).  A slice index >= nsl: PERSIST, the next item's slice - nsl;
+    // otherwise a harmless re-read (it keeps the per-iteration DMA count, which the counted vmcnt relies on, constant)
     auto dma_q = [&](int slice, int stage_off, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const int sl = min(slice, nsl - 1);                  // (past the end: harmless re-reads keep the per-iteration DMA count, which the counted vmcnt relies on, constant)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_ptr)(smem + stage_off + (wave + NW * k) * 1024), 16, vo_q[k], sl * qstride, 0, 0);
+        const bool nx = PERSIST && slice >= nsl;
+        const int sl = min(nx ? slice - nsl : slice, nsl - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_ptr)(smem + stage_off + (wave + NW * k) * 1024), 16, vo_q[k], (nx ? offq_n : offq) + sl * qstride, 0, 0);
 #else
         (void)slice; (void)stage_off; (void)k;
 #endif
     };
     auto dma_o = [&](int slice, int stage_off, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const int sl = min(slice, nsl - 1);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_o, (lds_void_ptr)(smem + stage_off + IMG_BYTES + (wave + NW * k) * 1024), 16, vo_o[k], sl * ostride, 0, 0);
+        const bool nx = PERSIST && slice >= nsl;
+        const int sl = min(nx ? slice - nsl : slice, nsl - 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_o, (lds_void_ptr)(smem + stage_off + IMG_BYTES + (wave + NW * k) * 1024), 16, vo_o[k], (nx ? offo_n : offo) + sl * ostride, 0, 0);
 #else
         (void)slice; (void)stage_off; (void)k;
 #endif
     };
-    // the statistics of slices 4 g .. 4 g + 3 (1 KiB, contiguous in `stat`), issued in front of slice 4 g's pieces; beyond Npad the buffer reads zero
+    // the statistics of slices 4 g .. 4 g + 3 (1 KiB, contiguous in `stat`), issued in front of slice 4 g's pieces; beyond Npad the buffer reads zero (PERSIST: the
+    // next head's numbers, which nothing consumes).  At most four pieces are live at a time, also across an item boundary (the last piece of an item may be partial)
     auto dma_s = [&](int slice) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if ((slice & 3) == 0) {
-            const int g = slice >> 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lds_void_ptr)(smem + RING + (g & (NSTATG - 1)) * 1024), 16, vo_s, g * 1024, 0, 0);
+        const bool nx = PERSIST && slice >= nsl;
+        const int sl = nx ? slice - nsl : slice;
+        if ((sl & 3) == 0) {
+            const int g = sl >> 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lds_void_ptr)(smem + RING + ((gb + (nx ? ngrp : 0) + g) & (NSTATG - 1)) * 1024), 16, vo_s, (nx ? offs_n : offs) + g * 1024, 0, 0);
         }
 #else
         (void)slice;
@@ -142,15 +193,16 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
     // ---- K / V fragments: requested FIRST -- vmcnt completes in issue order, so behind the ring's prefill their wait would be a wait for the whole prefill
     // (56 KiB at the ~11 B/clk a CU gets from a cold start: measured 11.9k cycles of prologue per workgroup, 14 % of its life) ----------------------------------------
     bf16x8 kv_[8], vv_[8];
-    if (active) {
+    auto load_kv = [&](const bf16* ibase, int ikey0) {
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             const int kb = f >> 2, ks = f & 3;
-            const int key = min(key0 + 32 * kb + r32, N - 1);
-            kv_[f] = *reinterpret_cast<const bf16x8*>(base + D + (int64_t)key * RS + 16 * ks + 8 * hi);
-            vv_[f] = *reinterpret_cast<const bf16x8*>(base + 2 * D + (int64_t)key * RS + 16 * ks + 8 * hi);
+            const int key = min(ikey0 + 32 * kb + r32, N - 1);
+            kv_[f] = *reinterpret_cast<const bf16x8*>(ibase + D + (int64_t)key * RS + 16 * ks + 8 * hi);
+            vv_[f] = *reinterpret_cast<const bf16x8*>(ibase + 2 * D + (int64_t)key * RS + 16 * ks + 8 * hi);
         }
-    }
+    };
+    if (active) load_kv(base, key0);
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) {
         dma_s(s);
@@ -181,7 +233,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 
     // ---- K / V fragments -> AGPRs (B operands: lane = key r32 of key block kb, d = 16 ks + 8 hi .. + 8); accumulators = 0 ------------------------------------------
     agpr_claim();
-    {
+    auto fill_kv = [&]() {
         const float ksc = scale * LOG2E;
         sfor<8>([&](auto I) {
             constexpr int f = decltype(I)::value;
@@ -192,7 +244,8 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
             });
         });
         sfor<128>([&](auto I) { agpr_zero1<decltype(I)::value>(); });
-    }
+    };
+    fill_kv();
 
     STAMP(5)
     // ---- loop-invariant LDS byte offsets (the stage offset is added once per slice: nine vector adds) ----------------------------------------------------------------
@@ -215,16 +268,22 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
     bf16x8 rq[4], ro[4];                    // Q / dO row fragments of the slice (A operands of S / dP)
     u32x2 tq[2][2][2], to[2][2][2];         // transposed Q / dO fragments [s][db][t] (A operands of dK^T / dV^T), as the two 8-byte reads they arrive in
     unsigned pw0[8], dw0[8], pw1[8], dw1[8];    // packed P / dS of units kb = 0 / 1 (register pairs (2 m, 2 m + 1) of the tile -> one word)
+    float ev[2][16], dvv[2];                // (per-score exponentials of the two units in flight: registers, every index is a constant)
+    auto reset_state = [&]() {              // per item: slice 0 finishes "score 15 of unit (-1, 1)" (0 * 0) and adds "unit (-1, 1)" (zero operands) to the accumulators
 #pragma unroll
-    for (int m = 0; m < 8; ++m) { pw0[m] = 0u; dw0[m] = 0u; pw1[m] = 0u; dw1[m] = 0u; }
+        for (int m = 0; m < 8; ++m) { pw0[m] = 0u; dw0[m] = 0u; pw1[m] = 0u; dw1[m] = 0u; }
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { tq[s][db][t] = u32x2{0u, 0u}; to[s][db][t] = u32x2{0u, 0u}; }
+                for (int t = 0; t < 2; ++t) { tq[s][db][t] = u32x2{0u, 0u}; to[s][db][t] = u32x2{0u, 0u}; }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { P1[j] = 0.f; if constexpr (DKDV_ABL & 256) { S0[j] = 0.f; P0[j] = 0.f; S1[j] = 0.f; } }     // (iteration 0 finishes "score 15 of unit (-1, 1)": 0 * 0)
+        for (int j = 0; j < 16; ++j) { P1[j] = 0.f; if constexpr (DKDV_ABL & 256) { S0[j] = 0.f; P0[j] = 0.f; S1[j] = 0.f; } }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { ev[0][g] = 0.f; ev[1][g] = 0.f; }
+        dvv[0] = 0.f; dvv[1] = 0.f;
+    };
 
 #define LD_ROW_(ptr, img) (*reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((ptr) + (img)))
 #define LD_C4_(ptr, which, jj) (*reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((ptr) + 128 * (which) + 32 * (jj)))
@@ -236,9 +295,6 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
     };
     // softmax arithmetic, one score per MFMA gap, software-pipelined by one gap so that no v_mul waits on the v_exp in front of it: FIN finishes the score started one
     // gap earlier (p * dPn; every second score packs a register pair), EXPG starts score g (p = exp2(-Sn))
-    float ev[2][16], dvv[2] = {0.f, 0.f};      // (per-score exponentials of the two units in flight: registers, every index is a constant)
-#pragma unroll
-    for (int g = 0; g < 16; ++g) { ev[0][g] = 0.f; ev[1][g] = 0.f; }
 #define EXP_(x) ((DKDV_ABL & 64) ? (x) * 0.25f : fast_exp2(x))
 #define PK_(a, b) ((DKDV_ABL & 128) ? __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u) : cvt_pk_bf16(a, b))
 #define EXPG(S_, g) if constexpr (!(DKDV_ABL & 4)) { ev[&S_ == &S1][g] = EXP_(S_[g]); }
@@ -287,26 +343,32 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 #define DMA_Q(k) if constexpr (!(DKDV_ABL & 1) && (k) < PPW) dma_q(i + NST - 1, st_d, (k) < PPW ? (k) : 0);
 #define DMA_O(k) if constexpr (!(DKDV_ABL & 1) && (k) < PPW) dma_o(i + NST - 1, st_d, (k) < PPW ? (k) : 0);
 
-    // ---- prologue: slice 0's row fragments and constants, S / dP of unit (0, 0) -----------------------------------------------------------------------------------
-    WAIT_SLICES_BUT(NST - 2)
-    if constexpr (NW > 1) __builtin_amdgcn_s_barrier();
-    STAMP(6)
-    {
-        const lds_cptr cp = lbase + st_a;
+    // ---- per item: slice 0's row fragments and constants, S / dP of unit (0, 0).  k0s = byte offset of the ring stage that holds the item's slice 0 -------------
+    int sc_n = 0;                                                            // offset of slice i + 1's constants in the statistics ring
+    auto item_prologue = [&](bool first, int k0s) {
+        agpr_claim();                        // (no compiler value may sit in a[0..191] across an item: it hoists the epilogue's addresses out of the item loop and parks them wherever it believes free)
+        reset_state();
+        if (first) { WAIT_SLICES_BUT(NST - 2) }                              // the prefill's slices 0 and 1
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");               // everything older than the previous item's 16 stores: its trailing DMA = this item's slices 0 .. NST - 2
+        if constexpr (NW > 1) __builtin_amdgcn_s_barrier();
+        STAMP(6)
+        const int sc0 = (gb & (NSTATG - 1)) * 1024;
+        {
+            const lds_cptr cp = lbase + st_a + sc0;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { SET_C4(cL, jj, LD_C4_(cp, 0, jj)); SET_C4(cD, jj, LD_C4_(cp, 1, jj)); }
+            for (int jj = 0; jj < 4; ++jj) { SET_C4(cL, jj, LD_C4_(cp, 0, jj)); SET_C4(cD, jj, LD_C4_(cp, 1, jj)); }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { rq[ks] = LD_ROW_(lbase + row_a[ks], 0); ro[ks] = LD_ROW_(lbase + row_a[ks], IMG_BYTES); }
-    }
-    SB
-    mfma_init<A_K + 0>(S0, rq[0], cL);  mfma_init<A_V + 0>(P0, ro[0], cD);
-    mfma_more<A_K + 4>(S0, rq[1]);      mfma_more<A_V + 4>(P0, ro[1]);
-    mfma_more<A_K + 8>(S0, rq[2]);      mfma_more<A_V + 8>(P0, ro[2]);
-    mfma_more<A_K + 12>(S0, rq[3]);     mfma_more<A_V + 12>(P0, ro[3]);
-    SB
-
-    STAMP(1)
-    int sc_n = 256;                                                          // offset of slice i + 1's constants in the statistics ring
+            for (int ks = 0; ks < 4; ++ks) { rq[ks] = LD_ROW_(lbase + k0s + row_a[ks], 0); ro[ks] = LD_ROW_(lbase + k0s + row_a[ks], IMG_BYTES); }
+        }
+        SB
+        mfma_init<A_K + 0>(S0, rq[0], cL);  mfma_init<A_V + 0>(P0, ro[0], cD);
+        mfma_more<A_K + 4>(S0, rq[1]);      mfma_more<A_V + 4>(P0, ro[1]);
+        mfma_more<A_K + 8>(S0, rq[2]);      mfma_more<A_V + 8>(P0, ro[2]);
+        mfma_more<A_K + 12>(S0, rq[3]);     mfma_more<A_V + 12>(P0, ro[3]);
+        SB
+        sc_n = (sc0 + 256) & (NSTATG * 1024 - 1);
+        STAMP(1)
+    };
     // LDS reads of the loop.  The row constants (cL / cD: sixteen registers each, filled four at a time) are plain loads: the compiler, which counts only its own LDS
     // instructions, waits for them at CWAIT -- placed BEFORE the first asm read of the iteration, so that its lgkmcnt(0) never sits behind a young read it does not
     // see.  Row fragments (RLD) and transposed fragments (TRL) are asm reads with hand-counted waits: they return in issue order, and lgkmcnt is a 4-bit counter --
@@ -378,56 +440,95 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
         }
         sc_n = (sc_n + 256) & (NSTATG * 1024 - 1);
     };
-    for (int i = 0; i < nsl; i += NST) {
-        sfor<NST>([&](auto K) {
-            constexpr int k = decltype(K)::value;
-            if (k == 0 || i + k < nsl) slice_step(i + k, K);
-        });
-    }
-    STAMP(2)
-    // ---- drain: the last score of unit (nsl - 1, 1), then its dV^T / dK^T ---------------------------------------------------------------------------------------------
-    SM_TAIL
-    SB
-    {
-        const bf16x8 b0 = pfrag(pw1, 0), e0 = pfrag(dw1, 0), b1 = pfrag(pw1, 1), e1 = pfrag(dw1, 1);
-        mfma_agpr<A_DV + 16>(frag(to[0][0][0], to[0][0][1]), b0);  mfma_agpr<A_DK + 16>(frag(tq[0][0][0], tq[0][0][1]), e0);
-        mfma_agpr<A_DV + 48>(frag(to[0][1][0], to[0][1][1]), b0);  mfma_agpr<A_DK + 48>(frag(tq[0][1][0], tq[0][1][1]), e0);
-        mfma_agpr<A_DV + 16>(frag(to[1][0][0], to[1][0][1]), b1);  mfma_agpr<A_DK + 16>(frag(tq[1][0][0], tq[1][0][1]), e1);
-        mfma_agpr<A_DV + 48>(frag(to[1][1][0], to[1][1][1]), b1);  mfma_agpr<A_DK + 48>(frag(tq[1][1][0], tq[1][1][1]), e1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // trailing re-reads have landed; the last MFMAs' results are readable (asm MFMAs: nobody pads this)
-    if constexpr (NW > 1) __builtin_amdgcn_s_barrier();                        // every wave is past its last read of the rings: they become the epilogue's tiles
-
-    // ---- epilogue: the wave's [64 keys][dK 64 | dV 64] tile through LDS (its own 16 KiB: row = key, 256 B, 16-byte chunk c at (c ^ (row & 7)) inside each 128-byte
-    // half), then stores of eight whole rows per instruction.  Lane (hi, key r32 of block kb) holds d = 32 db + 8 jj + 4 hi .. + 4 of its key's rows ----------------
-    {
-        char* tile = smem + wave * 16384;
-        const float dksc = scale;
-        sfor<16>([&](auto I) {
-            constexpr int db = (decltype(I)::value >> 3) & 1, kb = (decltype(I)::value >> 2) & 1, jj = decltype(I)::value & 3;
-            constexpr int ra = (db * 2 + kb) * 16 + 4 * jj;
-            const int row = 32 * kb + r32;
-            const int c16 = (4 * db + jj) ^ (row & 7), off = row * 256 + (c16 << 4) + 8 * hi;     // this lane's 8 bytes of 16-byte chunk 4 db + jj (d = 32 db + 8 jj + 4 hi)
-            const f32x4 dk = f32x4{agpr_read1<A_DK + ra>(), agpr_read1<A_DK + ra + 1>(), agpr_read1<A_DK + ra + 2>(), agpr_read1<A_DK + ra + 3>()} * dksc;
-            const f32x4 dv = {agpr_read1<A_DV + ra>(), agpr_read1<A_DV + ra + 1>(), agpr_read1<A_DV + ra + 2>(), agpr_read1<A_DV + ra + 3>()};
-            *reinterpret_cast<u32x2*>(tile + off) = u32x2{cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3])};
-            *reinterpret_cast<u32x2*>(tile + off + 128) = u32x2{cvt_pk_bf16(dv[0], dv[1]), cvt_pk_bf16(dv[2], dv[3])};
-        });
-        STAMP(7)
-        // (each wave reads back only what it wrote itself: no barrier, the compiler's lgkmcnt wait orders the reads behind the writes)
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = 8 * it + (lane >> 3), c = lane & 7, key = key0 + row;
-            const u32x4 vk = *reinterpret_cast<const u32x4*>(tile + row * 256 + ((c ^ (row & 7)) << 4));
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(tile + row * 256 + 128 + ((c ^ (row & 7)) << 4));
-            if (key < N) {
-                bf16* dst = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 8 * c;
-                *reinterpret_cast<u32x4*>(dst + D) = vk;
-                *reinterpret_cast<u32x4*>(dst + 2 * D) = vv;
+    // ---- the items of this workgroup (one unless PERSIST).  The ring runs on across items: slice j of the next item sits in stage (k0 + nsl + j) mod NST -----------
+    int k0 = 0;                                                             // ring stage of the current item's slice 0
+    for (bool first = true;; first = false) {
+        bool has_next = false;
+        Item nxt = cur;
+        if constexpr (PERSIST) {
+            has_next = item + istride < nitems;
+            if (has_next) nxt = decode(item + istride);
+            item_offsets(nxt, offq_n, offo_n, offs_n);                      // (the last item's trailing DMA re-reads its own first slices: harmless)
+        }
+        item_prologue(first, k0 * STAGE_BYTES);
+        // slice i of the item runs as unrolled copy (k0 + i) mod NST, whose ring stage is a compile-time constant: the first trip starts in the middle
+        for (int i = -k0; i < nsl; i += NST) {
+            sfor<NST>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                if ((unsigned)(i + k) < (unsigned)nsl) slice_step(i + k, K);
+            });
+        }
+        STAMP(2)
+        agpr_claim();
+        // the next item's K / V rows: requested before the drain and the epilogue, which hide their latency; vmcnt completes in order, so they are back before the
+        // 16 stores the epilogue issues behind them
+        const bf16* nbase = base;
+        int nkey0 = key0;
+        if constexpr (PERSIST) {
+            if (has_next) {
+                nbase = qkv + (int64_t)nxt.b * N * RS + nxt.h * 64;
+                nkey0 = key_first + nxt.blk * (64 * NW) + wave * 64;
+                load_kv(nbase, nkey0);
             }
         }
+        // ---- drain: the last score of unit (nsl - 1, 1), then its dV^T / dK^T ---------------------------------------------------------------------------------------
+        SM_TAIL
+        SB
+        {
+            const bf16x8 b0 = pfrag(pw1, 0), e0 = pfrag(dw1, 0), b1 = pfrag(pw1, 1), e1 = pfrag(dw1, 1);
+            mfma_agpr<A_DV + 16>(frag(to[0][0][0], to[0][0][1]), b0);  mfma_agpr<A_DK + 16>(frag(tq[0][0][0], tq[0][0][1]), e0);
+            mfma_agpr<A_DV + 48>(frag(to[0][1][0], to[0][1][1]), b0);  mfma_agpr<A_DK + 48>(frag(tq[0][1][0], tq[0][1][1]), e0);
+            mfma_agpr<A_DV + 16>(frag(to[1][0][0], to[1][0][1]), b1);  mfma_agpr<A_DK + 16>(frag(tq[1][0][0], tq[1][0][1]), e1);
+            mfma_agpr<A_DV + 48>(frag(to[1][1][0], to[1][1][1]), b1);  mfma_agpr<A_DK + 48>(frag(tq[1][1][0], tq[1][1][1]), e1);
+        }
+        if constexpr (PERSIST) {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                   // the last MFMAs' results are readable (asm MFMAs: nobody pads this)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // ... and the trailing re-reads have landed
+            if constexpr (NW > 1) __builtin_amdgcn_s_barrier();                  // every wave is past its last read of the rings: they become the epilogue's tiles
+        }
+
+        // ---- epilogue: the wave's [64 keys][dK 64 | dV 64] tile through LDS (its own 16 KiB: row = key, 256 B, 16-byte chunk c at (c ^ (row & 7)) inside each
+        // 128-byte half), then stores of eight whole rows per instruction.  Lane (hi, key r32 of block kb) holds d = 32 db + 8 jj + 4 hi .. + 4 of its key's rows ------
+        {
+            char* tile = smem + EPI_OFF + wave * 16384;
+            const float dksc = scale;
+            sfor<16>([&](auto I) {
+                constexpr int db = (decltype(I)::value >> 3) & 1, kb = (decltype(I)::value >> 2) & 1, jj = decltype(I)::value & 3;
+                constexpr int ra = (db * 2 + kb) * 16 + 4 * jj;
+                const int row = 32 * kb + r32;
+                const int c16 = (4 * db + jj) ^ (row & 7), off = row * 256 + (c16 << 4) + 8 * hi;     // this lane's 8 bytes of 16-byte chunk 4 db + jj (d = 32 db + 8 jj + 4 hi)
+                const f32x4 dk = f32x4{agpr_read1<A_DK + ra>(), agpr_read1<A_DK + ra + 1>(), agpr_read1<A_DK + ra + 2>(), agpr_read1<A_DK + ra + 3>()} * dksc;
+                const f32x4 dv = {agpr_read1<A_DV + ra>(), agpr_read1<A_DV + ra + 1>(), agpr_read1<A_DV + ra + 2>(), agpr_read1<A_DV + ra + 3>()};
+                *reinterpret_cast<u32x2*>(tile + off) = u32x2{cvt_pk_bf16(dk[0], dk[1]), cvt_pk_bf16(dk[2], dk[3])};
+                *reinterpret_cast<u32x2*>(tile + off + 128) = u32x2{cvt_pk_bf16(dv[0], dv[1]), cvt_pk_bf16(dv[2], dv[3])};
+            });
+            STAMP(7)
+            // (each wave reads back only what it wrote itself: no barrier, the compiler's lgkmcnt wait orders the reads behind the writes)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 8 * it + (lane >> 3), c = lane & 7, key = key0 + row;
+                const u32x4 vk = *reinterpret_cast<const u32x4*>(tile + row * 256 + ((c ^ (row & 7)) << 4));
+                const u32x4 vv = *reinterpret_cast<const u32x4*>(tile + row * 256 + 128 + ((c ^ (row & 7)) << 4));
+                if (PERSIST || key < N) {       // (PERSIST: whole blocks only -- and an unconditional store is one the compiler can count: behind conditional ones it waits for them all before the next K / V)
+                    bf16* dst = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 8 * c;
+                    *reinterpret_cast<u32x4*>(dst + D) = vk;
+                    *reinterpret_cast<u32x4*>(dst + 2 * D) = vv;
+                }
+            }
+        }
+        STAMP(3)
+        agpr_claim();
+        if (!PERSIST || !has_next) break;
+        // ---- switch: the next item's K / V into the AGPRs (its Q / dO slices 0 .. NST - 2 are in the ring or on their way), accumulators = 0 --------------------------
+        fill_kv();
+        item += istride; cur = nxt; b = nxt.b; h = nxt.h; base = nbase; key0 = nkey0;
+        offq = offq_n; offo = offo_n; offs = offs_n;
+        gb = (gb + ngrp) & (NSTATG - 1);
+        k0 = (k0 + nsl) % NST;
+        STAMP_NEXT
     }
-    STAMP(3)
+    if constexpr (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the last item's trailing re-reads)
 }
 
 }  // namespace
@@ -446,19 +547,27 @@ extern "C" int devias_debug_dkdv_stamps(uint64_t* out, int32_t n) {
 #endif
 }
 
-// launched by attention.hip (mhsa_bwd_impl) behind the dQ kernel, which has written `stat`: the whole 256-key blocks of every head, then the ragged rest
-int devias_attn_dkdv1w_launch(const void* qkv, const void* d_o, const float* stat, void* dqkv, int B, int N, int Npad, int H, float scale, int xcd_flag, hipStream_t st) {
+// launched by attention.hip (mhsa_bwd_impl) behind the dQ kernel, which has written `stat`: the whole 256-key blocks of every head, then the ragged rest.
+// persistent != 0 (and the XCD order, and tensors below 2 GiB so that an item is a 32-bit buffer offset): one workgroup per CU walks the 256-key blocks
+int devias_attn_dkdv1w_launch(const void* qkv, const void* d_o, const float* stat, void* dqkv, int B, int N, int Npad, int H, float scale, int xcd_flag, int persistent,
+                              hipStream_t st) {
     const int nfull = N / 256, rest = N - nfull * 256;
 #define DKDV_ARGS (const bf16*)qkv, (const bf16*)d_o, stat, (bf16*)dqkv, N, Npad, H, B, scale, xcd_flag
     if (nfull > 0) {
-        const dim3 grid = (xcd_flag & 1) ? dim3(nfull * H * B) : dim3(nfull, H, B);
-        hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8>), grid, dim3(256), 0, st, DKDV_ARGS, 0, nfull);
+        const int64_t qbytes = (int64_t)B * N * 3 * H * 64 * 2;
+        const int items = nfull * H * B, ncu = devias_device_cus() & ~7;
+        if (persistent && (xcd_flag & 1) && qbytes < 0x7fffffff && ncu >= 8 && items > ncu) {
+            hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8, true>), dim3(ncu), dim3(256), 0, st, DKDV_ARGS, 0, nfull);
+        } else {
+            const dim3 grid = (xcd_flag & 1) ? dim3(items) : dim3(nfull, H, B);
+            hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8, false>), grid, dim3(256), 0, st, DKDV_ARGS, 0, nfull);
+        }
     }
     if (rest > 0) {
         const dim3 grid = (xcd_flag & 1) ? dim3(H * B) : dim3(1, H, B);
-        if (rest <= 64) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<1, 4>), grid, dim3(64), 0, st, DKDV_ARGS, nfull * 256, 1);
-        else if (rest <= 128) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<2, 4>), grid, dim3(128), 0, st, DKDV_ARGS, nfull * 256, 1);
-        else hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8>), grid, dim3(256), 0, st, DKDV_ARGS, nfull * 256, 1);
+        if (rest <= 64) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<1, 4, false>), grid, dim3(64), 0, st, DKDV_ARGS, nfull * 256, 1);
+        else if (rest <= 128) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<2, 4, false>), grid, dim3(128), 0, st, DKDV_ARGS, nfull * 256, 1);
+        else hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8, false>), grid, dim3(256), 0, st, DKDV_ARGS, nfull * 256, 1);
     }
 #undef DKDV_ARGS
     DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv, one wave per SIMD)");

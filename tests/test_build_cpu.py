@@ -133,7 +133,7 @@ def _reg_set(tok: str):
 @pytest.mark.parametrize("stem,kernel,mfmas,agprs", [("attn_bwd1w", "mhsa_bwd_dkdv1w_kernel", 32, 192)])
 def test_one_wave_attention_backward_kernels_own_their_agprs_and_keep_their_hazard_windows(stem, kernel, mfmas, agprs):
     """Audit of the one-wave-per-SIMD attention backward kernels (mhsa_bwd_dkdv1w_kernel, devias_amd/csrc/attn_bwd1w.hip; parametrised: a dQ kernel of the same build lives under tools/exp).
-    (1) their accumulators and resident operand fragments (a[0:191] / a[0:127]) are named literally in inline asm: the compiler must touch no AGPR itself and spill nothing.  (2) Its MFMAs are inline asm, so the
+    (1) their accumulators and resident operand fragments (a[0:191] / a[0:127]) are named literally in inline asm: the compiler must touch none of THOSE AGPRs itself and spill nothing.  (2) Its MFMAs are inline asm, so the
     compiler's hazard recognizer does not see them; the source keeps the windows by construction and this test checks the result in the ISA of every
     instantiation: behind an MFMA that writes VGPRs no other instruction reads or writes those VGPRs before two further MFMAs have issued (XDL write -> VALU /
     LDS access needs 11 wait states at 8 passes), and no vector-ALU instruction overwrites the VGPRs of its C operand before one further MFMA has issued (the
@@ -153,7 +153,7 @@ def test_one_wave_attention_backward_kernels_own_their_agprs_and_keep_their_haza
         name = m.group(1)
         found += 1
         j = i
-        while "s_endpgm" not in lines[j]:
+        while not lines[j].startswith(".Lfunc_end"):        # (not the first s_endpgm: a wave without keys leaves early)
             j += 1
         inasm, compiler_agpr, scratch, in_loop = False, [], 0, False
         body = []                                            # (opcode, operand tokens, in_asm) of every instruction
@@ -168,8 +168,10 @@ def test_one_wave_attention_backward_kernels_own_their_agprs_and_keep_their_haza
                 loops.append(0); in_loop = b.split(":")[0].strip()             # the header's label; the loop ends at the branch back to it
             if not code or code.endswith(":") or code.startswith("."):
                 continue
-            if not inasm and re.search(r"v_accvgpr|\ba\[\d+:\d+\]|\ba\d+\b", code):
-                compiler_agpr.append(code)
+            if not inasm:                                      # the compiler may use AGPRs of its own ABOVE the claimed ones (the persistent form parks the next block's K / V rows there)
+                used = [int(x) for x in re.findall(r"\ba(\d+)\b", code)] + [int(x) for y in re.findall(r"\ba\[(\d+):(\d+)\]", code) for x in y]
+                if any(u < agprs for u in used):
+                    compiler_agpr.append(code)
             scratch += "scratch_" in code
             parts = code.replace(",", " ").split()
             body.append((parts[0], parts[1:], inasm))
@@ -199,5 +201,6 @@ def test_one_wave_attention_backward_kernels_own_their_agprs_and_keep_their_haza
                 if seen_mfma == 0 and op2.startswith("v_") and srcc != dst:
                     assert not (_reg_set(args2[0]) & srcc), (name, "a vector instruction overwrites the C operand of a running asm MFMA", op, args, op2, args2)
         meta = "\n".join(x for x in lines if name in x and (".num_agpr" in x or ".private_seg_size" in x))
-        assert re.search(r"\.num_agpr, %d" % agprs, meta) and re.search(r"\.private_seg_size, 0\b", meta), meta
-    assert found == 3          # <4 waves, 8 stages> for whole 256-key blocks, <1, 4> and <2, 4> for the ragged rest of a head
+        m2 = re.search(r"\.num_agpr, (\d+)", meta)
+        assert m2 and int(m2.group(1)) >= agprs and re.search(r"\.private_seg_size, 0\b", meta), meta
+    assert found == 4          # <4 waves, 8 stages> for whole 256-key blocks (persistent / one block per workgroup), <1, 4> and <2, 4> for the ragged rest of a head

@@ -770,6 +770,35 @@ def test_mhsa_bwd_grids_and_ragged_shapes(B, N, H, xcd, attn_options):
         assert torch.equal(o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale), res), it
 
 
+@pytest.mark.parametrize("B,N,H", [(40, 512, 8), (8, 1568, 12), (11, 2048, 24), (16, 1311, 16), (2, 257, 12)])
+def test_mhsa_bwd_dkdv_forms_agree(B, N, H, attn_options):
+    """the dK / dV kernel in its three forms (option attn_dkdv): 1 = one wave per SIMD, a workgroup per 256-key block (default); 2 = the same kernel with one
+    PERSISTENT workgroup per CU walking the blocks (the Q / dO ring keeps running across blocks, the next block's K / V rows are requested before the
+    epilogue of the current one; shapes with more blocks than CUs -- otherwise the launcher falls back to form 1) -- BITWISE equal to form 1, run to run
+    too; 0 = the two-waves-per-SIMD kernel of rounds 2-4: equal within bf16 rounding (a different summation order)"""
+    o = attn_options
+    scale = 0.125
+    qkv = rnd(B * N, 3 * H * 64, dtype=torch.bfloat16, seed=70)
+    d_o = rnd(B * N, H * 64, dtype=torch.bfloat16, seed=71)
+    out, lse = o.mhsa_fwd(qkv, B, N, H, scale)
+    try:
+        res = {}
+        for form in (1, 2, 0, 2, 1):
+            o.set_option("attn_dkdv", form)
+            r = o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale)
+            assert torch.isfinite(r.float()).all(), form
+            if form in res:
+                assert torch.equal(r, res[form]), form
+            res[form] = r
+        assert torch.equal(res[1], res[2])
+        a, b = res[1].float().reshape(B, N, 3, H, 64), res[0].float().reshape(B, N, 3, H, 64)
+        assert torch.equal(a[:, :, 0], b[:, :, 0])                       # dQ: the same kernel in every form
+        for w in (1, 2):
+            assert rel(a[:, :, w], b[:, :, w]) < 2.5e-2, w
+    finally:
+        o.set_option("attn_dkdv", 1)
+
+
 # ------------------------------------------------------------------------------------------------ folded slot attention
 def _slotf_ref(qp, c, B, S, N, h, D, scale):
     q = qp.reshape(B, S, h, D).permute(0, 2, 1, 3)                    # [B,h,S,D]

@@ -20,7 +20,7 @@ def ref_bwd(qkv, d_o, scale):
 
 
 def run(qkv, o, d_o, lse, B, N, H, opt, bias):
-    ops.set_option("attn_dkdv", 1 if opt else 0)        # opt: 0 = the dK / dV kernel of rounds 2-4, != 0 = the one-wave-per-SIMD kernel
+    ops.set_option("attn_dkdv", opt)        # opt: 0 = the dK / dV kernel of rounds 2-4, 1 = the one-wave-per-SIMD kernel, one workgroup per 256-key block, 2 = the same kernel, persistent workgroups
     if bias:
         dbq = torch.zeros(H * 64, device="cuda"); dbv = torch.zeros(H * 64, device="cuda")
         g = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, 0.125, bias_out=(dbq, dbv))
@@ -35,7 +35,8 @@ def rel(a, b):
 def check():
     torch.manual_seed(0)
     bad = 0
-    for (B, N, H) in [(2, 1568, 12), (1, 256, 1), (1, 64, 2), (2, 33, 3), (1, 300, 8), (2, 100, 3), (1, 1569, 1), (3, 1000, 4), (1, 6400, 2), (2, 257, 12), (1, 1599, 6), (8, 784, 6)]:
+    for (B, N, H) in [(2, 1568, 12), (32, 1568, 12), (1, 256, 1), (1, 64, 2), (2, 33, 3), (1, 300, 8), (2, 100, 3), (1, 1569, 1), (3, 1000, 4), (1, 6400, 2), (2, 257, 12), (1, 1599, 6), (8, 784, 6), (16, 1311, 16),
+                      (40, 512, 8), (11, 2048, 24)]:
         qkv = (torch.randn(B, N, 3, H, 64, device="cuda") * 1.5).to(torch.bfloat16)
         d_o = torch.randn(B, N, H * 64, device="cuda").to(torch.bfloat16)
         o, lse = ops.mhsa_fwd(qkv.view(B * N, 3 * H * 64), B, N, H, 0.125)
@@ -43,10 +44,11 @@ def check():
         ref = ref_bwd(qkv, d_o, 0.125) if B * H * N * N <= 4e8 else None
         for bias in (False, True):
             g0, bq0, bv0 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 0, bias)
-            g1, bq1, bv1 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 2, bias)
-            g2, bq2, bv2 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 2, bias)
+            g1, bq1, bv1 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 1, bias)
+            g2, bq2, bv2 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 1, bias)
+            g3, bq3, bv3 = run(qkv.view(B * N, -1), o.view(B * N, -1), d_o.view(B * N, -1), lse, B, N, H, 2, bias)
             torch.cuda.synchronize()
-            same = torch.equal(g1, g2) and (not bias or (torch.equal(bv1, bv2) and torch.equal(bq1, bq2)))
+            same = torch.equal(g1, g2) and torch.equal(g1, g3) and (not bias or (torch.equal(bv1, bv2) and torch.equal(bq1, bq2)))      # run to run, and persistent = one block per workgroup
             fin = bool(torch.isfinite(g1.float()).all())
             e_dq = rel(g1[:, :, 0], g0[:, :, 0]); e_dk = rel(g1[:, :, 1], g0[:, :, 1]); e_dv = rel(g1[:, :, 2], g0[:, :, 2])
             msg = f"B={B} N={N} H={H} bias={int(bias)}: new vs old dQ {e_dq:.1e} dK {e_dk:.1e} dV {e_dv:.1e}"
@@ -73,8 +75,8 @@ def timing():
     o, lse = ops.mhsa_fwd(qkv, B, N, H, 0.125)
     dbq = torch.zeros(H * 64, device="cuda"); dbv = torch.zeros(H * 64, device="cuda")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ts = {0: [], 1: []}
-    for opt in [0, 1, 1, 0] * 3:
+    ts = {0: [], 1: [], 2: []}
+    for opt in [0, 1, 2, 2, 1, 0] * 3:
         ops.set_option("attn_dkdv", opt)
         for _ in range(3):
             ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, 0.125, bias_out=(dbq, dbv))
@@ -84,7 +86,7 @@ def timing():
             ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, 0.125, bias_out=(dbq, dbv))
         e1.record(); torch.cuda.synchronize()
         ts[opt].append(e0.elapsed_time(e1) / 12 * 1e3)
-    for opt in (0, 1):
+    for opt in (0, 1, 2):
         v = sorted(ts[opt])
         print(f"attn_dkdv={opt}: backward (dQ + dK/dV + bias finish) median {v[len(v) // 2]:.1f} us  (min {v[0]:.1f}, max {v[-1]:.1f}) at B={B} N={N} H={H}", flush=True)
 
@@ -115,7 +117,24 @@ def time_only():
     print(f"{os.environ.get('DEVIAS_LIB_PATH', 'default library')}: backward with attn_dkdv=1 {out[0]:.1f} us, with attn_dkdv=0 {out[1]:.1f} us -> one-wave dK/dV kernel = old kernel {out[0] - out[1]:+.1f} us", flush=True)
 
 
+def time_three():
+    """under rocprofv3: the three dK / dV forms, 40 backward passes each, interleaved (the kernel names tell them apart in the stats)"""
+    B, N, H = 32, 1568, 12
+    torch.manual_seed(1)
+    qkv = (torch.randn(B * N, 3 * H * 64, device="cuda") * 1.5).to(torch.bfloat16)
+    d_o = torch.randn(B * N, H * 64, device="cuda").to(torch.bfloat16)
+    o, lse = ops.mhsa_fwd(qkv, B, N, H, 0.125)
+    for rep in range(8):
+        for opt in (1, 2, 0):
+            ops.set_option("attn_dkdv", opt)
+            for _ in range(5):
+                ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, 0.125)
+        torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
+    if "timeonly3" in sys.argv[1:]:
+        time_three(); sys.exit(0)
     if "timeonly" in sys.argv[1:]:
         time_only(); sys.exit(0)
     rc = check()
