@@ -6,8 +6,10 @@
 //
 //   * a wave keeps dK^T and dV^T of its 64 keys in 128 accumulator registers (AGPRs named literally in inline asm, the technique of gemm256w_kernel) and its K / V
 //     fragments in 64 more: the arch VGPRs carry only what flows -- S / dP tiles, Q / dO fragments, packed P / dS.  Workgroup = NW waves = NW x 64 keys of one
-//     (batch, head): NW = 4 for the whole 256-key blocks, and the ragged rest of a head (N mod 256 keys) goes to a second, small launch of one- or two-wave workgroups
-//     (four / two of them share a CU) instead of a 256-key workgroup with idle waves (at N = 1568: 6.125 blocks -- a seventh workgroup with one busy wave would cost 14 %);
+//     (batch, head): NW = 4 for the whole 256-key blocks, and the ragged rest of a head (N mod 256 keys) goes to a second, small launch instead of a 256-key workgroup
+//     with idle waves (at N = 1568: 6.125 blocks -- a seventh workgroup with one busy wave would cost 14 %).  A rest of at most 64 keys (N = 1568: 32) is ONE wave
+//     tile per head, and one wave walking all 49 slices is a latency chain (37 us for 384 lone waves on a 256-CU chip): QS = 2 / 4 puts that many waves on those keys, each with
+//     its own rings and every QS-th slice, and adds their fp32 tiles through LDS in wave order at the end (QS chosen so that the launch stays one round of one wave per SIMD);
 //   * Q / dO arrive in slices of 32 queries (one 4 KiB image each, read by rows for S / dP and transposed for dK^T / dV^T: a swizzle that is conflict-free for both
 //     kinds of read at the 32x32x16 lane shapes -- SQ_LDS_BANK_CONFLICT = 0) by LDS-DMA into a ring of NST stages, counted vmcnt, one barrier per slice; the row
 //     statistics of four slices ride in one more 1 KiB piece;
@@ -85,21 +87,28 @@ __device__ unsigned long long g_dkdv_stamp[4096][8];
 // =================================================================================================================================================================
 // NW waves of 64 keys; the workgroup's first key is key_first + 64 NW * (its index within the head): the main launch covers the whole 256-key blocks (key_first = 0),
 // the rest launch the ragged end (key_first = 256 * (N / 256), one workgroup per head).  NST = stages of the Q / dO ring.
-template <int NW, int NST, bool PERSIST>
-__global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o, const float* __restrict__ stat,
+template <int NW, int NST, bool PERSIST, int QS = 1>
+__global__ __launch_bounds__(NW * QS * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o, const float* __restrict__ stat,
                                                                   bf16* __restrict__ dqkv, int N, int Npad, int H, int B, float scale, int xcd, int key_first, int nblk) {
     enum { PPW = 4 / NW /* 1 KiB pieces of each image per wave and slice */, DPS = 2 * PPW /* counted DMA instructions per wave and slice */,
-           RING = NST * STAGE_BYTES, EPI = NW * 16384, EPI_OFF = PERSIST ? RING + NSTATG * 1024 : 0,
-           LDS_BYTES = PERSIST ? EPI_OFF + EPI : ((RING + NSTATG * 1024) > EPI ? (RING + NSTATG * 1024) : EPI) };
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];      // | Q / dO ring | statistics ring |   epilogue: one 16 KiB tile per wave (PERSIST: behind the rings, which stay live)
+           RING = NST * STAGE_BYTES, EPI = NW * 16384, EPI_OFF = PERSIST ? RING + NSTATG * 1024 : 0, WAVE_LDS = RING + NSTATG * 1024 /* QS > 1: rings per wave */,
+           LDS_BYTES = QS > 1 ? (QS * WAVE_LDS > QS * 32768 ? QS * WAVE_LDS : QS * 32768) : PERSIST ? EPI_OFF + EPI : ((RING + NSTATG * 1024) > EPI ? (RING + NSTATG * 1024) : EPI) };
+    static_assert(QS == 1 || ((QS == 2 || QS == 4) && NW == 1 && !PERSIST), "query split: one 64-key wave tile, two or four shares of the queries");
+    // | Q / dO ring | statistics ring |   epilogue: one 16 KiB tile per wave (PERSIST: behind the rings, which stay live).  QS > 1: one such pair of rings PER WAVE
+    // (the waves share their keys and split the query slices: slice j of wave w is slice QS j + w of the head), then one 32 KiB fp32 partial tile per wave
+    __shared__ __attribute__((aligned(16))) char smem_all[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, r32 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = QS > 1 ? 0 : wave_id;              // index of the wave's 64 keys within the workgroup
+    const int wq = QS > 1 ? wave_id : 0;                // its share of the query slices
+    char* const smem = smem_all + (QS > 1 ? wq * WAVE_LDS : 0);
     int stamp_item = 0; (void)stamp_item;
     STAMP(0)
     const int D = H * 64;
     const int64_t RS = 3 * (int64_t)D;
-    const int nsl = Npad >> 5;                          // query slices
-    const int ngrp = (nsl + 3) >> 2;                    // statistics pieces (groups of four slices) per head
+    const int nsl_all = Npad >> 5;                      // query slices
+    const int nsl = QS > 1 ? (nsl_all - wq + QS - 1) / QS : nsl_all;      // ... of this wave
+    const int ngrp = (nsl_all + 3) >> 2;                // statistics pieces (groups of four slices) per head
     // item -> (batch, head, key block).  xcd & 1: all workgroups of one (batch, head) on one XCD (attention.hip head_map): its Q / dO rows stay in that L2.
     // PERSIST (whole 256-key blocks, xcd order only): the grid is a multiple of 8 workgroups, workgroup w takes items w, w + grid, ... -- an item stays on the
     // XCD of its head, and a head's blocks run at the same time on neighbouring workgroups
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
     auto dma_q = [&](int slice, int stage_off, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const bool nx = PERSIST && slice >= nsl;
-        const int sl = min(nx ? slice - nsl : slice, nsl - 1);
+        const int sl = QS * max(min(nx ? slice - nsl : slice, nsl - 1), 0) + wq;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_void_ptr)(smem + stage_off + (wave + NW * k) * 1024), 16, vo_q[k], (nx ? offq_n : offq) + sl * qstride, 0, 0);
 #else
         (void)slice; (void)stage_off; (void)k;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
     auto dma_o = [&](int slice, int stage_off, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const bool nx = PERSIST && slice >= nsl;
-        const int sl = min(nx ? slice - nsl : slice, nsl - 1);
+        const int sl = QS * max(min(nx ? slice - nsl : slice, nsl - 1), 0) + wq;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_o, (lds_void_ptr)(smem + stage_off + IMG_BYTES + (wave + NW * k) * 1024), 16, vo_o[k], (nx ? offo_n : offo) + sl * ostride, 0, 0);
 #else
         (void)slice; (void)stage_off; (void)k;
@@ -182,8 +191,8 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 #if defined(__HIP_DEVICE_COMPILE__)
         const bool nx = PERSIST && slice >= nsl;
         const int sl = nx ? slice - nsl : slice;
-        if ((sl & 3) == 0) {
-            const int g = sl >> 2;
+        if (((QS * sl) & 3) == 0) {                          // (QS > 1: a wave's slice j is slice QS j + wq of the head: piece (QS j) >> 2)
+            const int g = (QS * sl) >> 2;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lds_void_ptr)(smem + RING + ((gb + (nx ? ngrp : 0) + g) & (NSTATG - 1)) * 1024), 16, vo_s, (nx ? offs_n : offs) + g * 1024, 0, 0);
         }
 #else
@@ -259,8 +268,20 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
 #pragma unroll
             for (int db = 0; db < 2; ++db) tr_a[t][db] = img_off(8 * t + 4 * hi + q, 4 * db + 2 * g16 + (p >> 1)) + 8 * (p & 1);     // (+ 2048 s, + IMG_BYTES for dO)
     }
-    const int st_a = RING + 16 * hi;                                   // row constants of a slice: floats 8 jj + 4 hi .. + 4 of its 256 B (+ 128: delta)
+    const int st_a = RING + 16 * hi + (QS > 1 ? wq * 256 : 0);        // row constants of a slice: floats 8 jj + 4 hi .. + 4 of its 256 B (+ 128: delta)
+    constexpr int SC_STEP = QS * 256;                                  // from a slice's constants to the next one's
     const lds_cptr lbase = (lds_cptr)smem;
+    // the asm reads take LDS byte addresses (the kernel's one LDS array starts at 0): the same offsets plus the base of this wave's rings
+    int row_w[4], tr_w[2][2];
+    {
+        const int wbase = QS > 1 ? wq * WAVE_LDS : 0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) row_w[ks] = row_a[ks] + wbase;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) tr_w[t][db] = tr_a[t][db] + wbase;
+    }
 
     // ---- pipeline state ----------------------------------------------------------------------------------------------------------------------------------------
     f32x16 S0, P0, S1, P1;                  // score / dP tiles of the two units in flight (unit = slice x 32-key block kb)
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
         mfma_more<A_K + 8>(S0, rq[2]);      mfma_more<A_V + 8>(P0, ro[2]);
         mfma_more<A_K + 12>(S0, rq[3]);     mfma_more<A_V + 12>(P0, ro[3]);
         SB
-        sc_n = (sc0 + 256) & (NSTATG * 1024 - 1);
+        sc_n = (sc0 + SC_STEP) & (NSTATG * 1024 - 1);
         STAMP(1)
     };
     // LDS reads of the loop.  The row constants (cL / cD: sixteen registers each, filled four at a time) are plain loads: the compiler, which counts only its own LDS
@@ -385,9 +406,9 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
         // slice i + 1 has landed for this wave ... and for every wave; everyone is done with slice i - 1's stage
         if constexpr (!(DKDV_ABL & 32)) WAIT_SLICES_BUT(NST - 3)
         if constexpr (NW > 1 && !(DKDV_ABL & 2)) __builtin_amdgcn_s_barrier();
-        const unsigned rp0 = (unsigned)row_a[0], rp1 = (unsigned)row_a[1], rp2 = (unsigned)row_a[2], rp3 = (unsigned)row_a[3];      // (+ st_n: an immediate of the read)
+        const unsigned rp0 = (unsigned)row_w[0], rp1 = (unsigned)row_w[1], rp2 = (unsigned)row_w[2], rp3 = (unsigned)row_w[3];      // (+ st_n: an immediate of the read)
         const lds_cptr cp = lbase + sc_n + st_a;
-        const unsigned t00 = (unsigned)tr_a[0][0], t10 = (unsigned)tr_a[1][0], t01 = (unsigned)tr_a[0][1], t11 = (unsigned)tr_a[1][1];   // (+ st_i)
+        const unsigned t00 = (unsigned)tr_w[0][0], t10 = (unsigned)tr_w[1][0], t01 = (unsigned)tr_w[0][1], t11 = (unsigned)tr_w[1][1];   // (+ st_i)
         SB
         // ---- group 1: S / dP of unit (i, 1)   || softmax of unit (i, 0), scores 0..7; the DMA of slice i + NST - 1; the row constants of slice i + 1
         mfma_init<A_K + 16>(S1, rq[0], cL);  SM_0  if constexpr (!(DKDV_ABL & 1)) dma_s(i + NST - 1);  DMA_Q(0)  SB
@@ -438,7 +459,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
             mfma_agpr<A_DV + 32>(frag(to[1][1][0], to[1][1][1]), b1);  SM_30  SB
             mfma_agpr<A_DK + 32>(frag(tq[1][1][0], tq[1][1][1]), e1);  SM_31  SB
         }
-        sc_n = (sc_n + 256) & (NSTATG * 1024 - 1);
+        sc_n = (sc_n + SC_STEP) & (NSTATG * 1024 - 1);
     };
     // ---- the items of this workgroup (one unless PERSIST).  The ring runs on across items: slice j of the next item sits in stage (k0 + nsl + j) mod NST -----------
     int k0 = 0;                                                             // ring stage of the current item's slice 0
@@ -480,6 +501,46 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dkdv1w_kernel(const bf16* __
             mfma_agpr<A_DV + 48>(frag(to[0][1][0], to[0][1][1]), b0);  mfma_agpr<A_DK + 48>(frag(tq[0][1][0], tq[0][1][1]), e0);
             mfma_agpr<A_DV + 16>(frag(to[1][0][0], to[1][0][1]), b1);  mfma_agpr<A_DK + 16>(frag(tq[1][0][0], tq[1][0][1]), e1);
             mfma_agpr<A_DV + 48>(frag(to[1][1][0], to[1][1][1]), b1);  mfma_agpr<A_DK + 48>(frag(tq[1][1][0], tq[1][1][1]), e1);
+        }
+        if constexpr (QS > 1) {
+            // ---- query split: the four waves hold partial dK^T / dV^T of the SAME 64 keys.  Each drops its fp32 tile into LDS ([64 keys][dK 64 | dV 64] floats, 512 B a
+            // row, 16-byte chunk c at c ^ (row & 15) inside each 256-byte half: conflict-free for these writes and for the reads below), then wave w adds the four tiles
+            // of keys 16 w .. + 16 in wave order -- deterministic -- and stores whole rows
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                        // every wave is done with its rings
+            char* part = smem_all + wq * 32768;
+            sfor<16>([&](auto I) {
+                constexpr int db = (decltype(I)::value >> 3) & 1, kb = (decltype(I)::value >> 2) & 1, jj = decltype(I)::value & 3;
+                constexpr int ra = (db * 2 + kb) * 16 + 4 * jj;
+                const int row = 32 * kb + r32;
+                const int off = row * 512 + (((8 * db + 2 * jj + hi) ^ (row & 15)) << 4);      // floats d = 32 db + 8 jj + 4 hi .. + 4
+                *reinterpret_cast<f32x4*>(part + off) = f32x4{agpr_read1<A_DK + ra>(), agpr_read1<A_DK + ra + 1>(), agpr_read1<A_DK + ra + 2>(), agpr_read1<A_DK + ra + 3>()};
+                *reinterpret_cast<f32x4*>(part + off + 256) = f32x4{agpr_read1<A_DV + ra>(), agpr_read1<A_DV + ra + 1>(), agpr_read1<A_DV + ra + 2>(), agpr_read1<A_DV + ra + 3>()};
+            });
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int pass = 0; pass < 8 / QS; ++pass) {
+                const int row = (64 / QS) * wq + 8 * pass + (lane >> 3), c8 = lane & 7, key = key0 + row;
+                f32x4 sk[2], sv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int off = row * 512 + (((2 * c8 + e) ^ (row & 15)) << 4);
+                    sk[e] = *reinterpret_cast<const f32x4*>(smem_all + off);
+                    sv[e] = *reinterpret_cast<const f32x4*>(smem_all + off + 256);
+#pragma unroll
+                    for (int w = 1; w < QS; ++w) {
+                        sk[e] += *reinterpret_cast<const f32x4*>(smem_all + w * 32768 + off);
+                        sv[e] += *reinterpret_cast<const f32x4*>(smem_all + w * 32768 + off + 256);
+                    }
+                    sk[e] *= scale;
+                }
+                if (key < N) {
+                    bf16* dst = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 8 * c8;
+                    *reinterpret_cast<u32x4*>(dst + D) = u32x4{cvt_pk_bf16(sk[0][0], sk[0][1]), cvt_pk_bf16(sk[0][2], sk[0][3]), cvt_pk_bf16(sk[1][0], sk[1][1]), cvt_pk_bf16(sk[1][2], sk[1][3])};
+                    *reinterpret_cast<u32x4*>(dst + 2 * D) = u32x4{cvt_pk_bf16(sv[0][0], sv[0][1]), cvt_pk_bf16(sv[0][2], sv[0][3]), cvt_pk_bf16(sv[1][0], sv[1][1]), cvt_pk_bf16(sv[1][2], sv[1][3])};
+                }
+            }
+            break;
         }
         if constexpr (PERSIST) {
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                   // the last MFMAs' results are readable (asm MFMAs: nobody pads this)
@@ -565,7 +626,13 @@ int devias_attn_dkdv1w_launch(const void* qkv, const void* d_o, const float* sta
     }
     if (rest > 0) {
         const dim3 grid = (xcd_flag & 1) ? dim3(H * B) : dim3(1, H, B);
-        if (rest <= 64) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<1, 4, false>), grid, dim3(64), 0, st, DKDV_ARGS, nfull * 256, 1);
+        if (rest <= 64) {
+            // one wave tile per head: as many waves on it (each with a share of the query slices) as keep the launch inside ONE round of one wave per SIMD
+            const int heads = H * B, slots = 4 * devias_device_cus();
+            if (4 * heads <= slots) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<1, 4, false, 4>), grid, dim3(256), 0, st, DKDV_ARGS, nfull * 256, 1);
+            else if (2 * heads <= slots) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<1, 4, false, 2>), grid, dim3(128), 0, st, DKDV_ARGS, nfull * 256, 1);
+            else hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<1, 4, false, 1>), grid, dim3(64), 0, st, DKDV_ARGS, nfull * 256, 1);
+        }
         else if (rest <= 128) hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<2, 4, false>), grid, dim3(128), 0, st, DKDV_ARGS, nfull * 256, 1);
         else hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8, false>), grid, dim3(256), 0, st, DKDV_ARGS, nfull * 256, 1);
     }

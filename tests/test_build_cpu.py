@@ -203,4 +203,4 @@ def test_one_wave_attention_backward_kernels_own_their_agprs_and_keep_their_haza
         meta = "\n".join(x for x in lines if name in x and (".num_agpr" in x or ".private_seg_size" in x))
         m2 = re.search(r"\.num_agpr, (\d+)", meta)
         assert m2 and int(m2.group(1)) >= agprs and re.search(r"\.private_seg_size, 0\b", meta), meta
-    assert found == 4          # <4 waves, 8 stages> for whole 256-key blocks (persistent / one block per workgroup), <1, 4> and <2, 4> for the ragged rest of a head
+    assert found == 6          # <4 waves, 8 stages> for whole 256-key blocks (persistent / one block per workgroup); for the ragged rest of a head <1, 4> (1, 2 or 4 waves share its queries) and <2, 4>

@@ -36,7 +36,7 @@ def check():
     torch.manual_seed(0)
     bad = 0
     for (B, N, H) in [(2, 1568, 12), (32, 1568, 12), (1, 256, 1), (1, 64, 2), (2, 33, 3), (1, 300, 8), (2, 100, 3), (1, 1569, 1), (3, 1000, 4), (1, 6400, 2), (2, 257, 12), (1, 1599, 6), (8, 784, 6), (16, 1311, 16),
-                      (40, 512, 8), (11, 2048, 24)]:
+                      (40, 512, 8), (11, 2048, 24), (40, 288, 16), (3, 1568, 16)]:
         qkv = (torch.randn(B, N, 3, H, 64, device="cuda") * 1.5).to(torch.bfloat16)
         d_o = torch.randn(B, N, H * 64, device="cuda").to(torch.bfloat16)
         o, lse = ops.mhsa_fwd(qkv.view(B * N, 3 * H * 64), B, N, H, 0.125)
