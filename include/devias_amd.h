@@ -234,7 +234,8 @@ int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
  *   are recomputed in both so that no gradient needs a sum across workgroups: bitwise reproducible, no atomics).  `ws` (ABI 164): devias_mhsa_bwd_workspace_bytes()
  *   bytes, 16-byte aligned -- the row statistics (lse * log2 e, delta, per 32-query slice) that the dQ kernel leaves for the one-wave-per-SIMD dK / dV kernel
  *   (csrc/attn_bwd1w.hip, bf16: one wave owns a SIMD and all 512 registers, dK / dV accumulators in AGPRs, the softmax arithmetic placed in the MFMAs' gaps);
- *   with ws = NULL, or option "attn_dkdv" = 0, the two-waves-per-SIMD dK / dV kernel of rounds 2-4 runs instead (same semantics, results equal to rounding).
+ *   with ws = NULL, or option "attn_dkdv" = 0, the two-waves-per-SIMD dK / dV kernel of rounds 2-4 runs instead (same semantics, results equal to rounding);
+ *   "attn_dkdv" = 2 runs the one-wave kernel as one persistent workgroup per CU (bitwise equal to the default, one workgroup per 256-key block).
  * ------------------------------------------------------------------------------------------------- */
 int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
                     int32_t dtype, void* stream);
