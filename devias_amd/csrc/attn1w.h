@@ -1,4 +1,4 @@
-// Shared pieces of the one-wave-per-SIMD attention kernels (attn_bwd1w.hip: dK / dV; attn_fwd1w.hip: forward; a dQ kernel of the same build is kept under tools/exp): the 32-row slice image and its swizzle,
+// Shared pieces of the one-wave-per-SIMD attention kernels (attn_bwd1w.hip: dK / dV; a dQ kernel and a forward kernel of the same build are kept, retired, under tools/exp): the 32-row slice image and its swizzle,
 // MFMAs on literal accumulator registers, AGPR helpers.  Both kernels stream 32-row slices of two [rows][64] bf16 operands (Q | dO, resp. K | V) through an LDS ring
 // and keep their per-wave operands and accumulators in AGPRs named literally in inline asm (the compiler must touch no AGPR itself: tests/test_build_cpu.py).
 #pragma once
@@ -47,7 +47,7 @@ __device__ __forceinline__ void agpr_claim128() {
     asm volatile("" ::: DEVIAS_A10(), DEVIAS_A10(1), DEVIAS_A10(2), DEVIAS_A10(3), DEVIAS_A10(4), DEVIAS_A10(5), DEVIAS_A10(6), DEVIAS_A10(7), DEVIAS_A10(8), DEVIAS_A10(9),
                  DEVIAS_A10(10), DEVIAS_A10(11), "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
 }
-__device__ __forceinline__ void agpr_claim96() {
+__device__ __forceinline__ void agpr_claim96() {      // (the retired forward kernel's 64 + 32)
     asm volatile("" ::: DEVIAS_A10(), DEVIAS_A10(1), DEVIAS_A10(2), DEVIAS_A10(3), DEVIAS_A10(4), DEVIAS_A10(5), DEVIAS_A10(6), DEVIAS_A10(7), DEVIAS_A10(8),
                  "a90", "a91", "a92", "a93", "a94", "a95");
 }
