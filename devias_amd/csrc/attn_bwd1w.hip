@@ -199,6 +199,10 @@ __global__ __launch_bounds__(NW * QS * 64) void mhsa_bwd_dkdv1w_kernel(const bf1
         (void)slice;
 #endif
     };
+    // (Tried: the 64 K rows and 64 V rows of a wave as whole 128-byte rows by LDS-DMA into a staging area, fragments by ds_read_b128, instead of the sixteen row-per-lane
+    // loads below, which touch 32 cache lines per instruction for 32 bytes each: bitwise equal, 808.9 us against 807.4 for the whole backward -- the wave waits for the
+    // rings' prefill either way.  An ablation build WITHOUT the loads is 87 us faster, but it multiplies zeros: the matrix cores draw less and the clock rises --
+    // ablations that change the DATA measure the power management, not the code: profiles/r5_dkdv1w_development.txt.)
     // ---- K / V fragments: requested FIRST -- vmcnt completes in issue order, so behind the ring's prefill their wait would be a wait for the whole prefill
     // (56 KiB at the ~11 B/clk a CU gets from a cold start: measured 11.9k cycles of prologue per workgroup, 14 % of its life) ----------------------------------------
     bf16x8 kv_[8], vv_[8];
