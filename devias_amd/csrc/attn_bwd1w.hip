@@ -51,7 +51,8 @@ enum { A_DV = 0, A_DK = 64, A_K = 128, A_V = 160, A_END = 192 };
 // Diagnostic builds only (tools/build_variant_file.sh <tag> attn_bwd1w -DDKDV_ABL=<mask>; results are then WRONG, the timing is what is read): leave out of the
 // slice loop  1 = the LDS-DMA, 2 = the barrier, 4 = the softmax arithmetic, 8 = the row-fragment / row-constant reads, 16 = the transposed reads, 32 = the counted vmcnt;
 // 64 = a v_mul in place of every v_exp, 128 = a v_perm in place of every v_cvt_pk, 256 = the S / dP MFMAs write (dummy) AGPRs instead of VGPRs,
-// 512 = no wait for the transposed fragments in front of group 4, 1024 = no counted waits for the row fragments in group 3
+// 512 = no wait for the transposed fragments in front of group 4, 1024 = no counted waits for the row fragments in group 3, 2048 = no epilogue (nothing is stored),
+// 4096 = no K / V loads (zeros in the AGPRs: the MFMAs then draw less power and the clock rises -- this one measures the power management, not the loads)
 #ifndef DKDV_ABL
 #define DKDV_ABL 0
 #endif
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(NW * QS * 64) void mhsa_bwd_dkdv1w_kernel(const bf1
             vv_[f] = *reinterpret_cast<const bf16x8*>(ibase + 2 * D + (int64_t)key * RS + 16 * ks + 8 * hi);
         }
     };
+    if constexpr (DKDV_ABL & 4096) { _Pragma("unroll") for (int f = 0; f < 8; ++f) { kv_[f] = bf16x8{}; vv_[f] = bf16x8{}; } } else
     if (active) load_kv(base, key0);
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) {
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(NW * QS * 64) void mhsa_bwd_dkdv1w_kernel(const bf1
 
         // ---- epilogue: the wave's [64 keys][dK 64 | dV 64] tile through LDS (its own 16 KiB: row = key, 256 B, 16-byte chunk c at (c ^ (row & 7)) inside each
         // 128-byte half), then stores of eight whole rows per instruction.  Lane (hi, key r32 of block kb) holds d = 32 db + 8 jj + 4 hi .. + 4 of its key's rows ------
-        {
+        if constexpr (!(DKDV_ABL & 2048)) {
             char* tile = smem + EPI_OFF + wave * 16384;
             const float dksc = scale;
             sfor<16>([&](auto I) {
