@@ -1841,13 +1841,13 @@ __global__ void splitk_reduce_kernel(GemmP p) {
 // staging), PD k-steps of loads in flight per wave; the waves' partial tiles meet in LDS in a fixed order (deterministic) and wave 0 applies
 // the epilogue of splitk_reduce_kernel (same arithmetic, same order).
 // =====================================================================================================================
-enum { SM_PD = 4 };
-template <int MT>      // MT = 16-row tiles of the output (M <= 16 MT)
+template <int MT, int SM_PD = 4>      // MT = 16-row tiles of the output per workgroup; SM_PD = k-steps of loads in flight per wave (a launch of these is a latency chain: K / (4 * 32 * SM_PD) round trips to memory)
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) f32x4 red[3][MT][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lm = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
+    const int mbase = blockIdx.y * (16 * MT);                // (grid.y > 1: every MT row tiles their own workgroup -- the launch policy for few column groups)
     const int kw = p.K / 4;                                  // this wave's share of K (a multiple of 32: host)
     const int k0 = wave * kw;
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
@@ -1857,7 +1857,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmP p) {
     bool aok[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        const int m = t * 16 + lm;
+        const int m = mbase + t * 16 + lm;
         aok[t] = m < p.M;
         arow[t] = A + (int64_t)(aok[t] ? m : 0) * p.lda + k0 + 8 * g;
     }
@@ -1875,7 +1875,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmP p) {
         if (p.bias) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const int m = t * 16 + lm;
+            const int m = mbase + t * 16 + lm;
             if (res && m < p.M) resv[t] = *reinterpret_cast<const bf16x4*>(res + (int64_t)(p.res_mod > 0 ? m % p.res_mod : m) * p.ldr + n);
             if (dact && m < p.M) auxv[t] = *reinterpret_cast<const bf16x4*>(aux_in + (int64_t)m * p.ld_aux + n);
         }
@@ -1911,7 +1911,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmP p) {
     bf16* C = reinterpret_cast<bf16*>(p.C);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        const int m = t * 16 + lm;
+        const int m = mbase + t * 16 + lm;
         f32x4 v = acc[t];
 #pragma unroll
         for (int w = 0; w < 3; ++w) v += red[w][t][lane];
@@ -1990,7 +1990,7 @@ struct GemmKnobs {
     int group_m;       // "gemm_groupm"     DEVIAS_GEMM_GROUPM   0 = measured policy, > 0 forces the rasterisation group height
     int persistent;    // "gemm_persistent" DEVIAS_GEMM_PERSIST  != 0: persistent 256x256 kernel where it applies (default), 0 = one tile per workgroup
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
-    int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K)
+    int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K), a workgroup per 16-row tile where there are few column groups; 2: one workgroup per column group always (A/B aid)
     int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups (1), whose idle waves
                        //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
     int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
@@ -2202,9 +2202,16 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
         p.split_k = 1; p.k_per_split = a->K;
         const int mt = cdiv(a->M, 16);
         dim3 grid(a->N / 16), block(256);
-        if (mt <= 1) hipLaunchKernelGGL((gemm_smallm_kernel<1>), grid, block, 0, st, p);
+        // few column groups (N = 768: 48 workgroups on 256 CUs, each streaming all M rows of A over a long K): one workgroup per 16-row tile as well -- the same
+        // arithmetic in the same order per output element (bitwise equal), four times the workgroups, a quarter of the A bytes per workgroup.  In the step
+        // (R = 64 rows, K = 3072, N = 768: the slot MLP's second layer, the composite output projection and their two dgrad twins; 32 launches of 17.5 us per step):
+        // -0.13 ms with the split alone, -0.25 ms with twelve instead of four k-steps of loads in flight per wave (a wave's 24 k-steps are then two round trips to
+        // memory instead of six) -- tools/ab_inproc.py gemm_smallm=2,1
+        if (kn.smallm == 1 && mt > 1 && a->N / 16 < 128) { grid = dim3(a->N / 16, mt); hipLaunchKernelGGL((gemm_smallm_kernel<1, 12>), grid, block, 0, st, p); }
+        else
+        if (mt <= 1) hipLaunchKernelGGL((gemm_smallm_kernel<1, 12>), grid, block, 0, st, p);
         else if (mt <= 2) hipLaunchKernelGGL((gemm_smallm_kernel<2>), grid, block, 0, st, p);
-        else if (mt <= 4) hipLaunchKernelGGL((gemm_smallm_kernel<4>), grid, block, 0, st, p);
+        else if (mt <= 4) hipLaunchKernelGGL((gemm_smallm_kernel<4>), grid, block, 0, st, p);      // (all six k-steps of a K = 768 wave in flight, <4, 6>: no gain in the step)
         else if (mt <= 6) hipLaunchKernelGGL((gemm_smallm_kernel<6>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_smallm_kernel<8>), grid, block, 0, st, p);
         devias_count(DEVIAS_CNT_GEMM_SMALLM);
