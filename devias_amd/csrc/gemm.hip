@@ -1841,9 +1841,14 @@ __global__ void splitk_reduce_kernel(GemmP p) {
 // staging), PD k-steps of loads in flight per wave; the waves' partial tiles meet in LDS in a fixed order (deterministic) and wave 0 applies
 // the epilogue of splitk_reduce_kernel (same arithmetic, same order).
 // =====================================================================================================================
-template <int MT, int SM_PD = 4>      // MT = 16-row tiles of the output per workgroup; SM_PD = k-steps of loads in flight per wave (a launch of these is a latency chain: K / (4 * 32 * SM_PD) round trips to memory)
+// TB: W is stored [K, N] (the dgrad twins of the same layers: dX = dY W with W in nn.Linear layout [out, in] = [K, N]).  A lane then cannot load its fragment -- eight
+// consecutive k of ONE column -- directly; the wave loads the [32 k][16 columns] block by rows (16 bytes per lane), drops it into a 1 KiB LDS block of its own and
+// reads it back with the transposing ds_read_b64_tr_b16 (LDS executes a wave's instructions in order: no barrier).  These products used to take the 128 x 128 kernel
+// plus a split-K reduce (two launches, 12-15 us in the step).
+template <int MT, int SM_PD = 4, bool TB = false>      // MT = 16-row tiles of the output per workgroup; SM_PD = k-steps of loads in flight per wave (a launch of these is a latency chain: K / (4 * 32 * SM_PD) round trips to memory)
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) f32x4 red[3][MT][64];
+    __shared__ __attribute__((aligned(16))) char wstage[TB ? 4 : 1][TB ? 1024 : 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lm = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
@@ -1852,7 +1857,8 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmP p) {
     const int k0 = wave * kw;
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* W = reinterpret_cast<const bf16*>(p.B);
-    const bf16* wrow = W + (int64_t)(n0 + lm) * p.ldb + k0 + 8 * g;
+    const bf16* wrow = TB ? W + (int64_t)(k0 + (lane >> 1)) * p.ldb + n0 + 8 * (lane & 1)      // row k0 + lane / 2 of the block, its left or right eight columns
+                          : W + (int64_t)(n0 + lm) * p.ldb + k0 + 8 * g;
     const bf16* arow[MT];
     bool aok[MT];
 #pragma unroll
@@ -1883,7 +1889,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmP p) {
     const int nks = kw / 32;
     bf16x8 fb[SM_PD], fa[SM_PD][MT];
     auto issue = [&](int slot, int ks) {
-        fb[slot] = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+        fb[slot] = *reinterpret_cast<const bf16x8*>(wrow + (TB ? (int64_t)ks * 32 * p.ldb : (int64_t)ks * 32));
 #pragma unroll
         for (int t = 0; t < MT; ++t) fa[slot][t] = *reinterpret_cast<const bf16x8*>(arow[t] + ks * 32);
     };
@@ -1894,8 +1900,18 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(GemmP p) {
         for (int d = 0; d < SM_PD; ++d) {
             const int ks = ks0 + d;
             if (ks < nks) {
+                bf16x8 wf = fb[d];
+                if constexpr (TB) {          // rows -> this lane's column: through the wave's LDS block
+                    char* blk = wstage[wave];
+                    *reinterpret_cast<bf16x8*>(blk + lane * 16) = fb[d];
+                    typedef __attribute__((address_space(3))) bf16x4* lp;
+                    const int q = lm >> 2, pp = lm & 3;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(blk + (8 * g + q) * 32 + 8 * pp));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(blk + (8 * g + q + 4) * 32 + 8 * pp));
+                    wf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
 #pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = mfma16(fb[d], fa[d][t], acc[t]);
+                for (int t = 0; t < MT; ++t) acc[t] = mfma16(wf, fa[d][t], acc[t]);
                 if (ks + SM_PD < nks) issue(d, ks + SM_PD);
             }
         }
@@ -2194,7 +2210,7 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
         if (kn.use_ss < 0 || nt) ss = false;
     }
     // small-M products (the aggregation block's and the head's B*S-row GEMMs): one launch, no split-K (gemm_smallm_kernel)
-    const bool smallm = kn.smallm && a->dtype == DEVIAS_BF16 && !a->trans_a && !a->trans_b && a->M <= 128 && batch == 1 && !p.c_f32 && !a->colsum && vec && vc &&
+    const bool smallm = kn.smallm && a->dtype == DEVIAS_BF16 && !a->trans_a && (!a->trans_b || kn.smallm == 1) && a->M <= 128 && batch == 1 && !p.c_f32 && !a->colsum && vec && vc &&
                         (a->N % 16 == 0) && (a->K % 128 == 0) && (a->lda % 8 == 0) && (a->ldb % 8 == 0) && (a->ldc % 4 == 0) && aligned8(a->C) &&
                         (!a->bias || aligned16(a->bias)) && (!a->res || (a->ldr % 4 == 0 && aligned8(a->res))) &&
                         (!a->aux_in || (a->ld_aux % 4 == 0 && aligned8(a->aux_in))) && (!a->aux_out || (a->ld_aux % 4 == 0 && aligned8(a->aux_out)));
@@ -2204,10 +2220,11 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
         dim3 grid(a->N / 16), block(256);
         // few column groups (N = 768: 48 workgroups on 256 CUs, each streaming all M rows of A over a long K): one workgroup per 16-row tile as well -- the same
         // arithmetic in the same order per output element (bitwise equal), four times the workgroups, a quarter of the A bytes per workgroup.  In the step
-        // (R = 64 rows, K = 3072, N = 768: the slot MLP's second layer, the composite output projection and their two dgrad twins; 32 launches of 17.5 us per step):
+        // (R = 64 rows, K = 3072, N = 768: the slot MLP's second layer and the composite output projection; 16 launches of 17.5 us per step):
         // -0.13 ms with the split alone, -0.25 ms with twelve instead of four k-steps of loads in flight per wave (a wave's 24 k-steps are then two round trips to
         // memory instead of six) -- tools/ab_inproc.py gemm_smallm=2,1
-        if (kn.smallm == 1 && mt > 1 && a->N / 16 < 128) { grid = dim3(a->N / 16, mt); hipLaunchKernelGGL((gemm_smallm_kernel<1, 12>), grid, block, 0, st, p); }
+        if (a->trans_b) { grid = dim3(a->N / 16, mt); hipLaunchKernelGGL((gemm_smallm_kernel<1, 12, true>), grid, block, 0, st, p); }      // W stored [K, N]: always a workgroup per row tile
+        else if (kn.smallm == 1 && mt > 1 && a->N / 16 < 128) { grid = dim3(a->N / 16, mt); hipLaunchKernelGGL((gemm_smallm_kernel<1, 12>), grid, block, 0, st, p); }
         else
         if (mt <= 1) hipLaunchKernelGGL((gemm_smallm_kernel<1, 12>), grid, block, 0, st, p);
         else if (mt <= 2) hipLaunchKernelGGL((gemm_smallm_kernel<2>), grid, block, 0, st, p);

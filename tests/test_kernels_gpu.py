@@ -924,7 +924,8 @@ def test_gemm_small_m_kernel(M, N, K, epi, gemm_options):
         res = rnd(S, N, dtype=torch.bfloat16, seed=36); rs = (torch.arange(M, device=DEV) % 3).float() * 0.5
         kw = dict(bias=bias, res=res, res_mod=S, row_scale=rs, rows_per_scale=1); ref = (ref + bias) * rs[:, None] + res.float().repeat(M // S, 1)
     outs = {}
-    for mode in (1, 0):
+    Wt = W.t().contiguous()                                  # the same matrix stored [K, N]: the dgrad twins of these layers (trans_b), served by the kernel's transposing variant
+    for mode in (1, 2, 0):                                   # 1: the default policy (a workgroup per 16-row tile where there are few column groups); 2: one workgroup per column group; 0: off
         o.set_option("gemm_smallm", mode)
         kw2 = dict(kw)
         if epi == "gelu_aux":
@@ -935,9 +936,26 @@ def test_gemm_small_m_kernel(M, N, K, epi, gemm_options):
         served = N % 16 == 0 and K % 128 == 0
         assert o.counters()["gemm_smallm"] == (1 if mode and served else 0), (mode, o.counters())
         outs[mode] = (c, kw2.get("aux_out"))
+        if mode != 2:
+            kw3 = dict(kw)
+            if epi == "gelu_aux":
+                kw3["aux_out"] = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            o.counters(reset=True)
+            ct = o.gemm(A, Wt, trans_b=True, **kw3)
+            torch.cuda.synchronize()
+            assert o.counters()["gemm_smallm"] == (1 if mode == 1 and served else 0), (mode, o.counters())
+            outs[("t", mode)] = (ct, kw3.get("aux_out"))
     o.set_option("gemm_smallm", 1)
     c, aux = outs[1]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]
     assert rel(c.float(), outs[0][0].float()) < TOL[torch.bfloat16]
+    assert torch.equal(c, outs[2][0])                        # the row split changes which workgroup computes an element, not how
     if aux is not None:
         assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16] and rel(aux.float(), outs[0][1].float()) < TOL[torch.bfloat16]
+        assert torch.equal(aux, outs[2][1])
+    ct, auxt = outs[("t", 1)]
+    if served:
+        assert torch.equal(ct, c)                            # same fragments, same K order: the transposing variant equals the k-contiguous one bit for bit
+        if aux is not None:
+            assert torch.equal(auxt, aux)
+    assert rel(ct.float(), ref) < TOL[torch.bfloat16] and rel(ct.float(), outs[("t", 0)][0].float()) < TOL[torch.bfloat16]
