@@ -470,7 +470,8 @@ __device__ __forceinline__ float sum_strided8(const float* __restrict__ p, int n
     return s;
 }
 
-// finish: rsum[bh,i] = sum_chunks ws_r + 1e-7 ; z[b,i,hh*D+d] = sum_chunks ws_z / rsum
+// finish: rsum[bh,i] = sum_chunks ws_r + 1e-7 ; z[b,i,hh*D+d] = sum_chunks ws_z / rsum.  (bf16 path: launched with one thread per column -- with 256 threads a
+// thread summed D / 256 columns one after the other, each a round trip to memory: 8.0 -> see DESIGN.md section 5 round 5)
 template <typename T>
 __global__ void slotf_fwd_finish_kernel(const float* __restrict__ ws_r, const float* __restrict__ ws_z, float* __restrict__ rsum,
                                         T* __restrict__ z, int S, int h, int D, int nchunks) {
@@ -938,7 +939,7 @@ extern "C" int devias_slotf_fwd(const void* qp, const void* ctx, float* attn, fl
         if (D == 512) SLOTM_F(2); else if (D == 768) SLOTM_F(3); else SLOTM_F(4);
 #undef SLOTM_F
         DEVIAS_CHECK_LAUNCH("devias_slotf_fwd(mfma)");
-        hipLaunchKernelGGL((slotf_fwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws_r, ws_z, rsum, (bf16*)z, S, h, D, nchunks);
+        hipLaunchKernelGGL((slotf_fwd_finish_kernel<bf16>), dim3(B * h * S), dim3(D <= 1024 ? (D + 63) / 64 * 64 : 256), 0, st, ws_r, ws_z, rsum, (bf16*)z, S, h, D, nchunks);
         DEVIAS_CHECK_LAUNCH("devias_slotf_fwd(finish)");
         return DEVIAS_OK;
     }
@@ -946,7 +947,7 @@ extern "C" int devias_slotf_fwd(const void* qp, const void* ctx, float* attn, fl
     if (dtype == DEVIAS_BF16) {
         SLOTF_DISPATCH(slotf_fwd_kernel, bf16, (const bf16*)qp, (const bf16*)ctx, attn, ws_r, ws_z, S, N, h, scale);
         DEVIAS_CHECK_LAUNCH("devias_slotf_fwd");
-        hipLaunchKernelGGL((slotf_fwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws_r, ws_z, rsum, (bf16*)z, S, h, D, nchunks);
+        hipLaunchKernelGGL((slotf_fwd_finish_kernel<bf16>), dim3(B * h * S), dim3(D <= 1024 ? (D + 63) / 64 * 64 : 256), 0, st, ws_r, ws_z, rsum, (bf16*)z, S, h, D, nchunks);
     } else {
         SLOTF_DISPATCH(slotf_fwd_kernel, float, (const float*)qp, (const float*)ctx, attn, ws_r, ws_z, S, N, h, scale);
         DEVIAS_CHECK_LAUNCH("devias_slotf_fwd");
@@ -972,7 +973,7 @@ extern "C" int devias_slotf_bwd(const void* ctx, const float* attn, const float*
         if (D == 512) SLOTM_B(2); else if (D == 768) SLOTM_B(3); else SLOTM_B(4);
 #undef SLOTM_B
         DEVIAS_CHECK_LAUNCH("devias_slotf_bwd(mfma)");
-        hipLaunchKernelGGL((slotf_bwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws, (bf16*)dqp, S, h, D, nchunks);
+        hipLaunchKernelGGL((slotf_bwd_finish_kernel<bf16>), dim3(B * h * S), dim3(D <= 1024 ? (D + 63) / 64 * 64 : 256), 0, st, ws, (bf16*)dqp, S, h, D, nchunks);
         DEVIAS_CHECK_LAUNCH("devias_slotf_bwd(finish)");
         return DEVIAS_OK;
     }
@@ -980,7 +981,7 @@ extern "C" int devias_slotf_bwd(const void* ctx, const float* attn, const float*
     if (dtype == DEVIAS_BF16) {
         SLOTF_DISPATCH(slotf_bwd_kernel, bf16, (const bf16*)ctx, attn, rsum, (const bf16*)z, (const bf16*)dz, d_attn_ext, ds, ws, S, N, h, scale);
         DEVIAS_CHECK_LAUNCH("devias_slotf_bwd");
-        hipLaunchKernelGGL((slotf_bwd_finish_kernel<bf16>), dim3(B * h * S), dim3(256), 0, st, ws, (bf16*)dqp, S, h, D, nchunks);
+        hipLaunchKernelGGL((slotf_bwd_finish_kernel<bf16>), dim3(B * h * S), dim3(D <= 1024 ? (D + 63) / 64 * 64 : 256), 0, st, ws, (bf16*)dqp, S, h, D, nchunks);
     } else {
         SLOTF_DISPATCH(slotf_bwd_kernel, float, (const float*)ctx, attn, rsum, (const float*)z, (const float*)dz, d_attn_ext, ds, ws, S, N, h, scale);
         DEVIAS_CHECK_LAUNCH("devias_slotf_bwd");
