@@ -60,6 +60,9 @@ struct DeviasDeferList { enum { MAX = 16 }; DeviasReduceJob jobs[MAX]; int n; };
 DeviasDeferList*& devias_defer_slot();                            // api.hip: thread-local; non-null only while a region is collecting
 int& devias_defer_enabled();                                      // api.hip: option "regions_defer" / DEVIAS_REGIONS_DEFER (1, default; 0 = every second stage its own launch)
 int devias_flush_deferred(DeviasDeferList* l, hipStream_t st);    // elementwise.hip
+int64_t devias_layernorm_bwd_parts_count(int M);                  // layernorm.hip: partial rows that devias_layernorm_bwd_parts writes for M rows ([count][3][D] floats)
+int devias_layernorm_bwd_parts(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* part,
+                               int M, int D, int dtype, hipStream_t st);   // layernorm.hip: few rows, partials only (the caller reduces them, stacked over layers)
 int devias_colsum_finish(const float* part, int nparts, int N, float* out, float beta, hipStream_t st);   // elementwise.hip: second stage of a column sum (deferred when a region collects)
 int devias_row_scale_colsum(const void* x, const float* scale, int rps, void* y, int dtype, int M, int N, float* out, float beta, float* ws, hipStream_t st);   // elementwise.hip: y = x * scale[row / rps] and its column sums in one pass
 // true = the `count` second stages described by `j` were taken over by the collecting region (the caller must NOT launch them)

@@ -277,6 +277,26 @@ int ln_bwd_dispatch(const T* dy, const T* x, const float* g, const float* mean, 
 
 }  // namespace
 
+// LayerNorm backward of a FEW rows (the B * S slot rows of the aggregation block), partials only: workgroups of four waves, one row per wave, write
+// part[workgroup][3][D] (dgamma | dbeta | dx column sums) and nobody reduces them -- the caller stacks the partials of every layer that shares the parameters and
+// runs ONE fixed-order reduce per parameter at the end (csrc/regions.hip, devias_agg_block_bwd).  The single-workgroup form of devias_layernorm_bwd, which writes
+// the results itself, is 16 waves sharing one CU's four SIMDs for four rows each: 13.5 us per call, 18 calls per step.
+enum { LNB_SMALL_ROWS = 4 };
+int64_t devias_layernorm_bwd_parts_count(int M) { return cdiv(M, LNB_SMALL_ROWS); }
+int devias_layernorm_bwd_parts(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* part,
+                               int M, int D, int dtype, hipStream_t st) {
+    DEVIAS_REQUIRE(dy && x && gamma && mean && rstd && dx && part && M > 0 && D > 0 && D % 4 == 0 && D <= 2048, "devias_layernorm_bwd_parts: bad args");
+    const int nwg = cdiv(M, LNB_SMALL_ROWS), nit = cdiv(D, 256);
+#define LNBS(T, N) hipLaunchKernelGGL((ln_bwd_kernel<T, N, 4>), dim3(nwg), dim3(4 * 64), (4 / 2) * 3 * N * 256 * sizeof(float), st, (const T*)dy, (const T*)x, gamma, mean, rstd, \
+                                      (const T*)dres, (T*)dx, part, M, D, (int)LNB_SMALL_ROWS, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f)
+    if (dtype == DEVIAS_BF16) { if (nit <= 2) LNBS(bf16, 2); else if (nit <= 3) LNBS(bf16, 3); else if (nit <= 4) LNBS(bf16, 4); else LNBS(bf16, 8); }
+    else if (dtype == DEVIAS_F32) { if (nit <= 2) LNBS(float, 2); else if (nit <= 3) LNBS(float, 3); else if (nit <= 4) LNBS(float, 4); else LNBS(float, 8); }
+    else return devias_set_error(DEVIAS_EINVAL, "devias_layernorm_bwd_parts: bad dtype %d", dtype);
+#undef LNBS
+    DEVIAS_CHECK_LAUNCH("devias_layernorm_bwd_parts");
+    return DEVIAS_OK;
+}
+
 extern "C" int devias_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                     float* rstd, int32_t M, int32_t D, float eps, int32_t dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;

@@ -391,6 +391,8 @@ struct AggScratch {
     char *coef, *vec, *dc, *dfeats[2];                 // deferred context gradient
     float *gWqk[DEVIAS_AGG_MAX_DEPTH], *gWov[DEVIAS_AGG_MAX_DEPTH];   // fp32 gradient accumulators of the composite weights
     char *gqk_t, *gov_t;                               // their compute-dtype copies (bf16 mode)
+    float *lnp_ffn[DEVIAS_AGG_MAX_DEPTH], *lnp_q[DEVIAS_AGG_MAX_DEPTH];   // per weight set: LayerNorm parameter-gradient partials of all its layers, [layer][part][3][D]
+    int64_t lnp_layer;                                 // floats of one layer's partials
     int64_t dz_layer, ds_layer;
     int64_t bytes;
     AggScratch(void* base, const devias_agg_args* a) {
@@ -411,6 +413,8 @@ struct AggScratch {
         dfeats[0] = take(M * D * es); dfeats[1] = take(M * D * es);
         for (int i = 0; i < nset; ++i) { gWqk[i] = (float*)take(hD * D * 4); gWov[i] = (float*)take(D * hD * 4); }
         gqk_t = take(hD * D * es); gov_t = take(D * hD * es);
+        lnp_layer = devias_layernorm_bwd_parts_count((int)R) * 3 * D;
+        for (int i = 0; i < nset; ++i) { lnp_ffn[i] = (float*)take(nl * lnp_layer * 4); lnp_q[i] = (float*)take(nl * lnp_layer * 4); }
         bytes = off;
     }
 };
@@ -523,7 +527,7 @@ extern "C" int devias_agg_block_bwd(const devias_agg_args* a, const void* x, con
         const devias_agg_layer_params& P = a->sets[si];
         const devias_agg_layer_grads& G = g->sets[si];
         AggSave::Layer& y = s.L[l];
-        const float acc = seen[si] ? 1.f : 0.f;
+
         float* attn = reinterpret_cast<float*>(reinterpret_cast<char*>(s.attn_stack) + l * s.attn_layer);
         float* rsum = reinterpret_cast<float*>(reinterpret_cast<char*>(s.rsum_stack) + l * s.rsum_layer);
         char* dz = t.dz_stack + l * t.dz_layer;
@@ -533,13 +537,27 @@ extern "C" int devias_agg_block_bwd(const devias_agg_args* a, const void* x, con
         // feed-forward: xs2 = xs1 + W2 gelu(W1 LN(xs1) + b1) + b2
         { Epi e; e.act = DEVIAS_ACT_DGELU; e.aux_in = y.fpre; RUN(gemm(c, dxs, P.W2, dfpre, R, F, D, D, F, 0, 1, e)); }
         { Epi e; RUN(gemm(c, dfpre, P.W1, t.df, R, D, F, F, D, 0, 1, e)); }
-        RUN(ln_bwd(c, t.df, y.xs1, P.ffn_w, y.mf, y.rf, dxs, dxs1, G.dffn_w, G.dffn_b, acc, nullptr, R, D));
+        const int li = a->tied ? l : 0;                 // this layer's place among the layers of its weight set
+        RUN(devias_layernorm_bwd_parts(t.df, y.xs1, P.ffn_w, y.mf, y.rf, dxs, dxs1, t.lnp_ffn[si] + li * t.lnp_layer, R, D, a->dtype, (hipStream_t)stream));
         // cross attention: xs1 = xs + Wov z + bo
         { Epi e; RUN(gemm(c, dxs1, s.Wov[si], dz, R, hD, D, D, hD, 0, 1, e)); }
         RUN(devias_slotf_bwd(s.c[si], attn, rsum, y.z, dz, l == a->depth - 1 ? dattn : nullptr, dqp, ds, B, S, N, heads, D, scale, a->dtype, a->ws, stream));
         { Epi e; RUN(gemm(c, dqp, s.Wqk[si], t.dqn, R, D, hD, hD, D, 0, 1, e)); }
-        RUN(ln_bwd(c, t.dqn, y.xs_in, P.norm_w, y.mq, y.rq, dxs1, dxs_of(l - 1), G.dnorm_w, G.dnorm_b, acc, nullptr, R, D));
+        RUN(devias_layernorm_bwd_parts(t.dqn, y.xs_in, P.norm_w, y.mq, y.rq, dxs1, dxs_of(l - 1), t.lnp_q[si] + li * t.lnp_layer, R, D, a->dtype, (hipStream_t)stream));
         seen[si] = true;
+    }
+    {   // the two LayerNorms' parameter gradients of every weight set: ONE fixed-order reduce per parameter over the partials of all the set's layers (four
+        // reduces per set, sixteen jobs per launch) instead of a single-workgroup LayerNorm backward per layer that accumulates into them
+        DeviasDeferList dl; dl.n = 0;
+        const int nl = a->tied ? a->depth : 1, np = (int)devias_layernorm_bwd_parts_count(R) * nl;
+        for (int si = 0; si < nset; ++si) {
+            const devias_agg_layer_grads& G = g->sets[si];
+            const DeviasReduceJob j[4] = {{t.lnp_ffn[si], np, 3 * D, D, G.dffn_w, 0.f}, {t.lnp_ffn[si] + D, np, 3 * D, D, G.dffn_b, 0.f},
+                                          {t.lnp_q[si], np, 3 * D, D, G.dnorm_w, 0.f}, {t.lnp_q[si] + D, np, 3 * D, D, G.dnorm_b, 0.f}};
+            for (int k = 0; k < 4; ++k) dl.jobs[dl.n++] = j[k];
+            if (dl.n + 4 > DeviasDeferList::MAX) RUN(devias_flush_deferred(&dl, (hipStream_t)stream));
+        }
+        RUN(devias_flush_deferred(&dl, (hipStream_t)stream));
     }
     const char* dxs = dxs_of(-1);
     RUN(devias_rows_reduce_mod(dxs, a->dtype, R, D, S, g->dlatents, stream));

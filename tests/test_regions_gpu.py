@@ -62,7 +62,8 @@ def _data(cfg, B):
 
 
 # the agg block's matrices and biases whose gradients the region reduces over all layers of a tied weight set at once (csrc/regions.hip: devias_agg_block_bwd)
-_DEFERRED = ("to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight", "to_out.0.bias", ".net.0.weight", ".net.0.bias", ".net.3.weight", ".net.3.bias")
+_DEFERRED = ("to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight", "to_out.0.bias", ".net.0.weight", ".net.0.bias", ".net.3.weight", ".net.3.bias",
+             ".norm.weight", ".norm.bias")       # (round 5: also the two pre-norms' parameters -- partials of all layers, one reduce per parameter)
 
 
 def _assert_bitwise(a, b, what, order_tol=0.0):
@@ -71,9 +72,15 @@ def _assert_bitwise(a, b, what, order_tol=0.0):
         if torch.equal(a[k], b[k]):
             continue
         if order_tol and "agg_block" in k and k.endswith(_DEFERRED):
-            err = (a[k].float() - b[k].float()).abs().max().item() / (a[k].float().abs().max().item() + 1e-30)
+            # relative to the tensor's own scale -- or, for the attention pre-norm's bias, to its weight gradient's: the slot softmax does not see a shift common
+            # to all slot queries, so that bias gradient is rounding noise around zero in either summation order
+            scale = a[k].float().abs().max().item()
+            if k.endswith(".0.norm.bias"):
+                scale = max(scale, a[k[:-4] + "weight"].float().abs().max().item())
+            err = (a[k].float() - b[k].float()).abs().max().item() / (scale + 1e-30)
             if err <= order_tol:
                 continue
+            k = f"{k} (err {err:.2e}, scale {scale:.2e})"
         bad.append(k)
     assert not bad, f"{what}: not bitwise equal: {bad[:6]} ({len(bad)} of {len(a)})"
 
