@@ -35,7 +35,8 @@ struct GemmP {
     int epi_swap;         // 1 = register-transposed epilogue (epilogue_swap), 0 = LDS-staged (epilogue_staged)
     int debug;            // timing ablations, compiled in only with -DDEVIAS_GEMM_DEBUG (option "gemm_debug"): 1 = one K-tile, 2 = no epilogue,
                           // 4 = no LDS-DMA after tile 0, 8 = s_memrealtime stamps into ws, 64 = epilogue without its C stores,
-                          // 128 = without its pre-activation stores, 256 = without the GELU / dGELU polynomial
+                          // 128 = without its pre-activation stores, 256 = without the GELU / dGELU polynomial, 1024 = the fc1 epilogue saves GELU'(pre) in place of pre
+                          // (a second polynomial there), 2048 = the dGELU epilogue multiplies by the saved value (with 1024: the "saved derivative" form, measured in DESIGN.md section 5 round 5)
     int tail_split;       // gemm256p_kernel: split the tiles of the last partial round between two workgroups (128-row halves)
     int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
     // dynamic tile queue of gemm256p_kernel<.., true>: this launch's queue slot (8 per-XCD heads, one per 128-byte line, + the line of claim masks; all zero
@@ -383,7 +384,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
             if (dact) {
                 const bf16x8 a8 = has_res ? *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)m * p.ld_aux + ncol) : side8;
                 if (p.act == DEVIAS_ACT_DGELU) {
-                    if (GDBG(256)) {
+                    if (GDBG(256) || GDBG(2048)) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] *= (float)a8[e];
                     } else {
@@ -400,6 +401,13 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
             } else if (p.act == DEVIAS_ACT_GELU) {
                 if (aux_out) {
                     bf16x8 pre = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+                    if (GDBG(1024)) {          // measurement of "save GELU'(pre) instead of pre" (with 2048 in the consumer the pair is a correct dGELU): the second polynomial's cost HERE
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 d = dgelu_fast2(f32x2{v[e], v[e + 1]});
+                            pre[e] = (bf16)d[0]; pre[e + 1] = (bf16)d[1];
+                        }
+                    }
                     if constexpr (DEFER) store16_asm(aux_out + (int64_t)(mrow0 + i * 16) * p.ld_aux + ncol0 + 32 * pr, vo_x, *reinterpret_cast<const u32x4*>(&pre));
                     else if (!GDBG(128) || v[0] == 12345.678f) *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
                 }
