@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: bench lines, rocprofv3 kernel trace + stats, PMC passes (JSON keyed by the kernel-source hash), on the code as committed
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5fin3; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5fin4; mkdir -p $O
 cd $R
 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
