@@ -770,12 +770,13 @@ def test_mhsa_bwd_grids_and_ragged_shapes(B, N, H, xcd, attn_options):
         assert torch.equal(o.mhsa_bwd(qkv, out, d_o, lse, B, N, H, scale), res), it
 
 
-@pytest.mark.parametrize("B,N,H", [(40, 512, 8), (8, 1568, 12), (11, 2048, 24), (16, 1311, 16), (2, 257, 12)])
+@pytest.mark.parametrize("B,N,H", [(40, 512, 8), (8, 1568, 12), (11, 2048, 24), (16, 1311, 16), (2, 257, 12), (24, 288, 16), (40, 288, 16)])
 def test_mhsa_bwd_dkdv_forms_agree(B, N, H, attn_options):
     """the dK / dV kernel in its three forms (option attn_dkdv): 1 = one wave per SIMD, a workgroup per 256-key block (default); 2 = the same kernel with one
     PERSISTENT workgroup per CU walking the blocks (the Q / dO ring keeps running across blocks, the next block's K / V rows are requested before the
     epilogue of the current one; shapes with more blocks than CUs -- otherwise the launcher falls back to form 1) -- BITWISE equal to form 1, run to run
-    too; 0 = the two-waves-per-SIMD kernel of rounds 2-4: equal within bf16 rounding (a different summation order)"""
+    too; 0 = the two-waves-per-SIMD kernel of rounds 2-4: equal within bf16 rounding (a different summation order).  The shapes also walk the rest launch's three
+    forms (a head's last <= 64 keys shared by four, two or one wave: B * H <= 256, <= 512, more) and check everything against the fp32 statement where it is affordable"""
     o = attn_options
     scale = 0.125
     qkv = rnd(B * N, 3 * H * 64, dtype=torch.bfloat16, seed=70)
@@ -795,6 +796,12 @@ def test_mhsa_bwd_dkdv_forms_agree(B, N, H, attn_options):
         assert torch.equal(a[:, :, 0], b[:, :, 0])                       # dQ: the same kernel in every form
         for w in (1, 2):
             assert rel(a[:, :, w], b[:, :, w]) < 2.5e-2, w
+        if B * H * N * N <= 2e8:                                          # fp32 autograd of softmax(scale q k^T) v on the bf16-rounded inputs
+            x = qkv.float().view(B, N, 3, H, 64).detach().requires_grad_(True)
+            q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+            (torch.softmax((q * scale) @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * N, H * 64).backward(d_o.float())
+            for w in range(3):
+                assert rel(a[:, :, w], x.grad[:, :, w]) < 3e-2, w
     finally:
         o.set_option("attn_dkdv", 1)
 
