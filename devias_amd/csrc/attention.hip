@@ -742,17 +742,6 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
                 for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
-#ifdef ATTN_PACKED_SOFTMAX
-                        const f32x2 e = f32x2{acc_s[h2][qt][r], acc_s[h2][qt][r + 1]} * sl2v + nl;
-                        const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
-                        f32x2 dp = {acc_dp[h2][qt][r], acc_dp[h2][qt][r + 1]};
-                        if constexpr (DROP) {                          // dP_ij = mask_ij (dO_i . V_j)
-                            const uint32_t key = (uint32_t)(k0 + 16 * (2 * s + h2) + 4 * g + r);
-                            dp = dp * f32x2{drop_scale(drop, rowkey[qt], key), drop_scale(drop, rowkey[qt], key + 1)};
-                        }
-                        const f32x2 ds = p * (dp - dlv);               // dS^T / scale (scale applied once at the end)
-                        acc_s[h2][qt][r] = ds[0]; acc_s[h2][qt][r + 1] = ds[1];
-#else
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {                  // (scalar on purpose: packed fp32 instructions beside MFMAs cost more issue time than the two they replace)
                             if constexpr (!DROP) {
@@ -764,7 +753,6 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
                             acc_s[h2][qt][r + u] = p1 * (dp1 - dlv[0]);                                                                     // dS^T / scale (scale applied once at the end)
                             }
                         }
-#endif
                     }
             }
             bf16x8 dsf[QT];
@@ -915,20 +903,6 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {                                    // packed fp32: two scores per VALU op
-#ifdef ATTN_PACKED_SOFTMAX
-                    const f32x2 e = f32x2{acc_s[qt][kt][r], acc_s[qt][kt][r + 1]} * sl2v - f32x2{l4[r], l4[r + 1]};
-                    const f32x2 p = {fast_exp2(e[0]), fast_exp2(e[1])};
-                    f32x2 dp = {acc_dp[qt][kt][r], acc_dp[qt][kt][r + 1]}, pd = p;
-                    if constexpr (DROP) {                              // queries 64 t + 16 qt + 4 g + r (+ 1), key key0 + 16 kt + c: dV takes P * mask, dP = mask (dO . V)
-                        const uint32_t q = (uint32_t)min(t * 64 + 16 * qt + 4 * g + r, N - 1), key = (uint32_t)(key0 + 16 * kt + c);
-                        const f32x2 m = {drop_scale(drop, drop_rowkey(drop, (uint32_t)(b * H + h), q), key),
-                                         drop_scale(drop, drop_rowkey(drop, (uint32_t)(b * H + h), (uint32_t)min((int)q + 1, N - 1)), key)};
-                        dp = dp * m; pd = p * m;
-                    }
-                    const f32x2 ds = p * (dp - f32x2{d4[r], d4[r + 1]});   // dS / scale
-                    acc_s[qt][kt][r] = pd[0]; acc_s[qt][kt][r + 1] = pd[1];
-                    acc_dp[qt][kt][r] = ds[0]; acc_dp[qt][kt][r + 1] = ds[1];
-#else
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {                      // (scalar on purpose: see the dQ kernel)
                         const float p1 = fast_exp2(acc_s[qt][kt][r + u] * sl2v[0] - l4[r + u]);
@@ -940,7 +914,6 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
                         acc_s[qt][kt][r + u] = pd1;
                         acc_dp[qt][kt][r + u] = p1 * (dp1 - d4[r + u]);                                          // dS / scale
                     }
-#endif
                 }
         }
 #pragma unroll

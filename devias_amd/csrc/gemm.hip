@@ -312,22 +312,36 @@ __device__ __forceinline__ float row16_sum(float t) {
 // SIDE: which rows the epilogue reads, as a compile-time fact (-1 = decided at run time): 0 none, 1 residual, 2 saved pre-activation of
 // dGELU / dReLU.  The persistent kernels need it: a load whose use sits behind a different run-time condition than its issue looks
 // "possibly still pending" to the compiler's wait insertion at the K loop's head, which then drains the memory pipeline every iteration.
-template <int NI, bool DEFER = false, int SIDE = -1>
+// EPI (round 6): the epilogue's RUN-TIME switches as compile-time facts too -- activation code, bias / saved pre-activation / row scale / column sums present or not.
+// Why: with those decided at run time the compiler keeps every path in the per-piece body and speculates the cheap ones: a plain bias epilogue executed, per
+// 16-row x 64-byte piece, the row-scale multiplies (four v_pk_mul + eight v_cndmask), the column-sum adds of zero, eight register moves that join the
+// activation paths and ~ten scalar branches -- 60 vector instructions where 17 are needed (8 adds, 4 lane-group swaps, 4 converts, the store) -- and the
+// epilogue interval of the persistent kernels is vector-instruction time.  EPI < 0: the generic form (every combination, decided at run time);
+// EPI >= 0: bits 0-2 the activation code, then EPI_BIAS / EPI_AUX / EPI_RS / EPI_CS.  The host picks the instantiation that matches a call's arguments
+// (the encoder block's six epilogues have one each) and falls back to the generic form otherwise; same arithmetic in the same order: bitwise equal (tested).
+enum { EPI_ACT = 7, EPI_BIAS = 8, EPI_AUX = 16, EPI_RS = 32, EPI_CS = 64 };
+template <int NI, bool DEFER = false, int SIDE = -1, int EPI = -1>
 __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4], int mrow0, int ncol0, int z, int lane) {
     const int lm = lane & 15, g = lane >> 4;
     const uint32_t col2 = (uint32_t)(16 * (g & 1) + 8 * (g >> 1)) * 2;
     const uint32_t vo_c = (uint32_t)lm * (uint32_t)p.ldc * 2 + col2, vo_x = (uint32_t)lm * (uint32_t)p.ld_aux * 2 + col2;
     constexpr bool BIAS_ON = !(DEFER && SIDE == 2), CS_ON = !(DEFER && SIDE == 1);
+    constexpr bool GEN = EPI < 0;
+    const int act = GEN ? p.act : (EPI & EPI_ACT);
+    const bool on_bias = GEN ? p.bias != nullptr : (EPI & EPI_BIAS) != 0;
+    const bool on_aux = GEN ? p.aux_out != nullptr : (EPI & EPI_AUX) != 0;
+    const bool on_rs = GEN ? p.row_scale != nullptr : (EPI & EPI_RS) != 0;
+    const bool on_cs = GEN ? p.colsum_part != nullptr : (EPI & EPI_CS) != 0;
     f32x4 bias4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        bias4[j] = (BIAS_ON && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias4[j] = (BIAS_ON && on_bias) ? *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     // DEFER: the stochastic-depth row scales as two SCALARS (rows_per_scale >= 16 * NI, host: the wave's rows span at most two samples);
     // the register budget of the up-front row fetch also drops what the step never combines (host): bias with SIDE 2, column sums with SIDE 1
     float rs_lo = 1.f, rs_hi = 1.f;
     int rs_edge = 0;
     if constexpr (DEFER) {
-        if (p.row_scale) {
+        if (on_rs) {
             const int r0 = mrow0 / p.rows_per_scale, rl = (p.M - 1) / p.rows_per_scale;
             rs_lo = p.row_scale[r0]; rs_hi = p.row_scale[r0 < rl ? r0 + 1 : rl];
             rs_edge = (r0 + 1) * p.rows_per_scale;
@@ -344,7 +358,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
     // the rows the epilogue reads (residual, or the saved pre-activation of dGELU / dReLU) are fetched PF pieces ahead of their use
     constexpr int PF = DEFER ? 2 * NI : 4;
     const bool has_res = SIDE == 1 ? true : (SIDE == -1 ? res != nullptr : false);
-    const bool dact = SIDE == 2 ? true : (SIDE == -1 ? (p.act == DEVIAS_ACT_DGELU || p.act == DEVIAS_ACT_DRELU) : false);
+    const bool dact = SIDE == 2 ? true : (SIDE == -1 ? (act == DEVIAS_ACT_DGELU || act == DEVIAS_ACT_DRELU) : false);
     const bf16* side = has_res ? res : aux_in;
     const int side_ld = has_res ? p.ldr : p.ld_aux;
     const bool side_on = SIDE > 0 ? true : (SIDE == 0 ? false : (side != nullptr && p.split_k == 1));
@@ -366,7 +380,10 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
         for (int pr = 0; pr < 2; ++pr) {
             bf16x8 side8 = sbuf[(i * 2 + pr) % PF];
             if (side_on && i * 2 + pr + PF < 2 * NI) sbuf[(i * 2 + pr) % PF] = side_load(i * 2 + pr + PF);
-            const f32x4 A = acc[i][2 * pr] + bias4[2 * pr], B = acc[i][2 * pr + 1] + bias4[2 * pr + 1];
+            // (the generic form adds a zero bias where there is none; a specialised form without bias skips the add: an accumulator chain that starts at +0 never
+            //  holds -0 unless a negative sum underflows, the only value the add of +0 would change)
+            const bool add_bias = GEN || (BIAS_ON && on_bias);
+            const f32x4 A = add_bias ? acc[i][2 * pr] + bias4[2 * pr] : acc[i][2 * pr], B = add_bias ? acc[i][2 * pr + 1] + bias4[2 * pr + 1] : acc[i][2 * pr + 1];
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -383,7 +400,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
             }
             if (dact) {
                 const bf16x8 a8 = has_res ? *reinterpret_cast<const bf16x8*>(aux_in + (int64_t)m * p.ld_aux + ncol) : side8;
-                if (p.act == DEVIAS_ACT_DGELU) {
+                if (act == DEVIAS_ACT_DGELU) {
                     if (GDBG(256) || GDBG(2048)) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] *= (float)a8[e];
@@ -398,8 +415,8 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (float)a8[e] > 0.f ? v[e] : 0.f;
                 }
-            } else if (p.act == DEVIAS_ACT_GELU) {
-                if (aux_out) {
+            } else if (act == DEVIAS_ACT_GELU) {
+                if (on_aux) {
                     bf16x8 pre = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
                     if (GDBG(1024)) {          // measurement of "save GELU'(pre) instead of pre" (with 2048 in the consumer the pair is a correct dGELU): the second polynomial's cost HERE
 #pragma unroll
@@ -418,14 +435,14 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                     v[e] = y[0]; v[e + 1] = y[1];
                 }
                 }
-            } else if (p.act == DEVIAS_ACT_RELU) {
+            } else if (act == DEVIAS_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-            } else if (p.act == DEVIAS_ACT_SIGMOID) {
+            } else if (act == DEVIAS_ACT_SIGMOID) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
             }
-            if (p.row_scale) {
+            if (on_rs) {
                 const float rs = DEFER ? (m >= rs_edge ? rs_hi : rs_lo) : p.row_scale[m / p.rows_per_scale];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= rs;
@@ -435,9 +452,12 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
             }
-            if (CS_ON && p.colsum_part) {
+            if (CS_ON && on_cs) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) cs[pr][e] += v[e];
+                // (specialised forms: pin the sums HERE -- with no branch between the pieces the compiler sank all 128 adds behind the last piece and kept every
+                //  piece's values alive for them: 256 registers + scratch, and a scratch reload's vmcnt(0) would expose the tile's whole store burst)
+                if constexpr (!GEN) asm volatile("" : "+v"(cs[pr][0]), "+v"(cs[pr][1]), "+v"(cs[pr][2]), "+v"(cs[pr][3]), "+v"(cs[pr][4]), "+v"(cs[pr][5]), "+v"(cs[pr][6]), "+v"(cs[pr][7]));
             }
             if (!DEFER && p.c_f32) {
                 float* C = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + ncol;
@@ -454,9 +474,12 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                 else if (!GDBG(64) || v[0] == 12345.678f)
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
             }
+            // a specialised form has no branches left between its pieces: without a fence the scheduler interleaves all sixteen and the forms that also carry
+            // column sums run out of registers (256 + scratch); one piece at a time keeps them where the generic form is
+            if constexpr (!GEN) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (CS_ON && p.colsum_part && p.split_k == 1) {
+    if (CS_ON && on_cs && p.split_k == 1) {
         // the 16 lanes of a group (same g, rows lm = 0..15) own the same columns: fold them in a fixed order
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
@@ -990,7 +1013,7 @@ __device__ __forceinline__ int tq_read(const char* word, unsigned seq) {
     return (v >> 28) == (seq & 15u) ? (int)(v & 0x0fffffffu) : -2;
 }
 
-template <bool TB, int SIDE, bool DYN>
+template <bool TB, int SIDE, bool DYN, int EPI = -1>
 __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2 + (DYN ? 16 : 0)];     // (+ the published next item: ONE LDS object -- a second __shared__ object makes the compiler fence every LDS read behind the LDS-DMA in flight)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1126,18 +1149,20 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     // gemm_debug & 8: thread 0 logs (100 MHz clock << 4 | code) into ws + 64 * blockIdx.x: 1 = first K-tile of a tile about to be multiplied,
     // 2 = K loop done, 3 = epilogue done (stores issued), 4 = first K-iteration of the next tile done (its wait passed)
     int nlog = 0;
+    // (with fused column sums the partials own the head of ws: the stamps then live behind them, at float offset M / 128 * N)
+    unsigned long long* const stamp_base = reinterpret_cast<unsigned long long*>(p.ws + (p.colsum_part ? (size_t)(p.M / 128) * p.N : 0));
     auto stamp = [&](int code) {
         if (GDBG(8) && tid == 0 && nlog < 64) {
             // codes >= 8 log the SHADER clock counter instead (s_memtime): with the matching 100 MHz stamps that gives the clock the CU really runs at
             const unsigned long long v = ((code >= 8 ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime()) << 4) | (unsigned long long)code;
-            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)nlog * 8), "v"(v), "s"(reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 64) : "memory");
+            asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)nlog * 8), "v"(v), "s"(stamp_base + (size_t)blockIdx.x * 64) : "memory");
         }
         ++nlog;
     };
 #define PSTAMP(c) stamp(c)
     if (GDBG(8) && tid == 0) {           // slot 63: the workgroup's entry time
         const unsigned long long v = (t_entry << 4) | 7ull;
-        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)63 * 8), "v"(v), "s"(reinterpret_cast<unsigned long long*>(p.ws) + (size_t)blockIdx.x * 64) : "memory");
+        asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"((uint32_t)63 * 8), "v"(v), "s"(stamp_base + (size_t)blockIdx.x * 64) : "memory");
     }
 #else
 #define PSTAMP(c)
@@ -1241,7 +1266,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             PSTAMP(2); PSTAMP(10);
             int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             asm volatile("" : "+v"(lane_e));                   // opaque: keeps the epilogue's per-lane address arithmetic out of the registers that live across the K loop
-            if (act) epilogue_swap<8, true, SIDE>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
+            if (act) epilogue_swap<8, true, SIDE, EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, 0, lane_e);
             if (!has_next) break;
             int m0x = 0, n0x = 0, halfx = -1;
             bool issued = false;                               // (wave 0) one dequeue was issued BEHIND the epilogue's stores
@@ -2014,6 +2039,7 @@ struct GemmKnobs {
     int group_m;       // "gemm_groupm"     DEVIAS_GEMM_GROUPM   0 = measured policy, > 0 forces the rasterisation group height
     int persistent;    // "gemm_persistent" DEVIAS_GEMM_PERSIST  != 0: persistent 256x256 kernel where it applies (default), 0 = one tile per workgroup
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
+    int epi_spec;      // "gemm_epi_spec"   DEVIAS_GEMM_EPI_SPEC 1 (default): the eight-wave persistent kernel runs the instantiation whose epilogue switches are compile-time facts where one exists (same bits); 0: always the generic form (A/B aid)
     int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K), a workgroup per 16-row tile where there are few column groups; 2: one workgroup per column group always (A/B aid)
     int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups (1), whose idle waves
                        //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
@@ -2049,6 +2075,7 @@ GemmKnobs& knobs() {
         x.w4 = env_int("DEVIAS_GEMM_W4", -1);
         x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 2);
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
+        x.epi_spec = env_int("DEVIAS_GEMM_EPI_SPEC", 1);
         x.ncu = 0;                                        // (unused: the CU count is the current device's at every call, devias_device_cus())
         return x;
     }();
@@ -2117,6 +2144,7 @@ static int* gemm_option_slot(const char* name) {
     if (!strcmp(name, "gemm_w4")) return &k.w4;
     if (!strcmp(name, "gemm_tail_split")) return &k.tail_split;
     if (!strcmp(name, "gemm_smallm")) return &k.smallm;
+    if (!strcmp(name, "gemm_epi_spec")) return &k.epi_spec;
     if (!strcmp(name, "gemm_reserve_cus")) return &k.reserve;
     if (!strcmp(name, "gemm_splitk_xcd")) return &k.splitk_xcd;
     if (!strcmp(name, "gemm_dynamic")) return &k.dynamic;
@@ -2135,6 +2163,33 @@ int devias_gemm_get_option(const char* name, int* value) {
     *value = *slot;
     return 1;
 }
+
+// The eight-wave persistent kernel's instantiation for a call: operand layout, the rows its epilogue reads (SIDE), static lists or dynamic queues, and -- option
+// gemm_epi_spec, on by default -- the epilogue's switches as compile-time facts (EPI, see epilogue_swap) where the call's combination has an instantiation:
+// the encoder block's six (qkv: bias; fc1: bias + GELU + saved pre-activation; proj / fc2 / patch embedding: bias + residual; dfc1 / dqkv: nothing; dproj: column
+// sums; dfc2: dGELU + column sums).  Everything else (stochastic depth's row scale, ReLU / Sigmoid heads, ...) runs the generic form.
+namespace {
+template <bool TB, int SIDE, bool DYN, int EPI>
+void pers_launch1(dim3 grid, hipStream_t st, const GemmP& p) { hipLaunchKernelGGL((gemm256p_kernel<TB, SIDE, DYN, EPI>), grid, dim3(NT2), 0, st, p); }
+template <bool DYN>
+void pers_launch(bool tb, int side, int epi, dim3 grid, hipStream_t st, const GemmP& p) {
+    if (!tb && side == 0) {
+        if (epi == EPI_BIAS) pers_launch1<false, 0, DYN, EPI_BIAS>(grid, st, p);
+        else if (epi == (DEVIAS_ACT_GELU | EPI_BIAS | EPI_AUX)) pers_launch1<false, 0, DYN, DEVIAS_ACT_GELU | EPI_BIAS | EPI_AUX>(grid, st, p);
+        else pers_launch1<false, 0, DYN, -1>(grid, st, p);
+    } else if (!tb) {
+        if (epi == EPI_BIAS) pers_launch1<false, 1, DYN, EPI_BIAS>(grid, st, p);
+        else pers_launch1<false, 1, DYN, -1>(grid, st, p);
+    } else if (side == 0) {
+        if (epi == 0) pers_launch1<true, 0, DYN, 0>(grid, st, p);
+        else if (epi == EPI_CS) pers_launch1<true, 0, DYN, EPI_CS>(grid, st, p);
+        else pers_launch1<true, 0, DYN, -1>(grid, st, p);
+    } else {
+        if (epi == (DEVIAS_ACT_DGELU | EPI_CS)) pers_launch1<true, 2, DYN, DEVIAS_ACT_DGELU | EPI_CS>(grid, st, p);
+        else pers_launch1<true, 2, DYN, -1>(grid, st, p);
+    }
+}
+}  // namespace
 
 static int gemm_impl(const devias_gemm_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -2276,8 +2331,6 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
 #define PERS_LAUNCH(KERNEL, ...) do { \
             if (!tb) { if (side == 0) hipLaunchKernelGGL((KERNEL<false, 0 __VA_ARGS__>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<false, 1 __VA_ARGS__>), grid, block, 0, st, p); } \
             else { if (side == 0) hipLaunchKernelGGL((KERNEL<true, 0 __VA_ARGS__>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<true, 2 __VA_ARGS__>), grid, block, 0, st, p); } } while (0)
-#define COMMA_TRUE , true
-#define COMMA_FALSE , false
         // Four-wave form (gemm256w_kernel).  gemm_w4 is a mask over its four instantiations: 1 = B k-contiguous, no side rows; 2 = B k-contiguous + residual;
         // 4 = B k-strided, no side rows; 8 = B k-strided + saved pre-activation; -1 (default) = all four where K >= 1024 and N >= 1024 (every GEMM of ViT-L, none of ViT-B).  Measured IN the step, one process,
         // the option toggled between blocks of ten steps (tools/ab_inproc.py, profiles/r4_dormant_kernels.txt): ViT-L/16 16x224^2 (K = 1024 / 4096) -3.0 ms of
@@ -2297,7 +2350,9 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
             devias_count(DEVIAS_CNT_GEMM256P);
             devias_count(DEVIAS_CNT_GEMM256W);
         } else if (kn.persistent && pers_ok && nt > gp) {
-            dim3 grid(gp), block(NT2);
+            dim3 grid(gp);
+            // the epilogue's switches of this call (EPI of epilogue_swap); -1 = the generic instantiation
+            const int epi = !kn.epi_spec ? -1 : (a->act | (a->bias ? EPI_BIAS : 0) | (a->aux_out ? EPI_AUX : 0) | (a->row_scale ? EPI_RS : 0) | (p.colsum_part ? EPI_CS : 0));
             // dynamic queue: every XCD queue has at least one (reserved) item per workgroup, at most 32 workgroups per XCD (one claim-mask word)
             unsigned int *tq = nullptr, *tq_clear = nullptr;
             if (!(dyn && a->K >= 128 && (gp >> 3) <= 32 && (nt >> 3) >= (gp >> 3) && tile_queue_slot(st, &tq, &tq_clear))) tq = nullptr;
@@ -2314,10 +2369,10 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
                     p.tq_nwhole[v] = split ? rfull * stride : cnt;
                     p.tq_items[v] = split ? rfull * stride + 2 * rem : cnt;
                 }
-                PERS_LAUNCH(gemm256p_kernel, COMMA_TRUE);
+                pers_launch<true>(tb != 0, side, epi, grid, st, p);
                 devias_count(DEVIAS_CNT_GEMM256D);
             } else {
-                PERS_LAUNCH(gemm256p_kernel, COMMA_FALSE);
+                pers_launch<false>(tb != 0, side, epi, grid, st, p);
             }
             devias_count(DEVIAS_CNT_GEMM256P);
         } else {

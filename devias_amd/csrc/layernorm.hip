@@ -13,7 +13,18 @@ namespace {
 #ifndef DEVIAS_LNF_WGS_PER_CU
 #define DEVIAS_LNF_WGS_PER_CU 8
 #endif
-enum { LN_WAVES = 4, LN_MAXIT = 16, LNB_MIN_ROWS = 32, LNB_ONE_WG_ROWS = 256, LNF_WGS_PER_CU = DEVIAS_LNF_WGS_PER_CU };
+// the backward kernel at D <= 768, bf16 (the measured step's 27 launches): waves per workgroup, rows a wave keeps in flight ahead of its current one, workgroups per CU
+#ifndef DEVIAS_LNB_NW
+#define DEVIAS_LNB_NW 16
+#endif
+#ifndef DEVIAS_LNB_PF
+#define DEVIAS_LNB_PF 1
+#endif
+#ifndef DEVIAS_LNB_WGS
+#define DEVIAS_LNB_WGS 1
+#endif
+enum { LN_WAVES = 4, LN_MAXIT = 16, LNB_MIN_ROWS = 32, LNB_ONE_WG_ROWS = 256, LNF_WGS_PER_CU = DEVIAS_LNF_WGS_PER_CU, LNB_NW = DEVIAS_LNB_NW, LNB_PF = DEVIAS_LNB_PF,
+       LNB_WGS_PER_CU = DEVIAS_LNB_WGS };
 int ln_ncu() { return devias_device_cus(); }
 
 
@@ -90,7 +101,12 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const T* __restri
 
 // backward: workgroup = NW waves, each wave walks every NW-th row of the workgroup's rows; lane-owned columns are fixed so the
 // dgamma/dbeta partial sums live in registers and are combined across the waves through LDS at the end.
-template <typename T, int NIT, int NW>
+// PF = rows a wave keeps in flight AHEAD of the one it works on (a ring of PF register sets, the row loop unrolled over it so that every set has a compile-time name).
+// The kernel is a latency machine: a wave waits for a row, reduces it (two wave sums), stores it; what it has in flight meanwhile is PF rows of dy / x / dres.
+// Round 3's form (16 waves, PF = 1: 16 x 4.6 KB = 74 KB per CU at best, less while waves compute) held 4.3-4.5 TB/s; Little's law at the ~3 us loaded latency of this
+// part asks for >= 70 KB ALWAYS in flight to reach the 6 TB/s copy rate (MI355X_MICROARCH.md, "Indexed rows").
+// FULL: D == NIT * 256 as a compile-time fact (the measured step's D = 768): no per-chunk column guards -- with them the PF = 3 form is 2700 lines of branches and spills
+template <typename T, int NIT, int NW, int PF = 1, bool FULL = false>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -102,46 +118,51 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         int c = (it * 64 + lane) * 4;
-        g[it] = c < D ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g[it] = (FULL || c < D) ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         dg[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         dc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int r0 = blockIdx.x * rows;
-    // software pipeline over rows: the (packed) loads of row r+4 are issued before the reductions of row r, so each wave keeps
-    // two rows of dy / x / dres in flight (the kernel is latency-bound otherwise: one dependent HBM round trip per row)
+    // software pipeline over rows: the (packed) loads of row r + PF * NW are issued before the reductions of row r
     typedef typename Raw4<T>::type raw4;
-    raw4 nd[NIT], nx[NIT], nr[NIT];
-    float nmu = 0.f, nrs = 0.f;
-    auto issue = [&](int row) {
+    raw4 nd[PF][NIT], nx[PF][NIT], nr[PF][NIT];
+    float nmu[PF], nrs[PF];
+    auto issue = [&](int row, raw4 (&d_)[NIT], raw4 (&x_)[NIT], raw4 (&r_)[NIT], float& mu_, float& rs_) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int c = (it * 64 + lane) * 4;
-            if (c < D) {
-                nd[it] = *reinterpret_cast<const raw4*>(dy + (int64_t)row * D + c);
-                nx[it] = *reinterpret_cast<const raw4*>(x + (int64_t)row * D + c);
-                if (dres) nr[it] = *reinterpret_cast<const raw4*>(dres + (int64_t)row * D + c);
+            if (FULL || c < D) {
+                d_[it] = *reinterpret_cast<const raw4*>(dy + (int64_t)row * D + c);
+                x_[it] = *reinterpret_cast<const raw4*>(x + (int64_t)row * D + c);
+                if (dres) r_[it] = *reinterpret_cast<const raw4*>(dres + (int64_t)row * D + c);
             }
         }
-        nmu = mean[row]; nrs = rstd[row];
+        mu_ = mean[row]; rs_ = rstd[row];
     };
-    if (r0 + wave < M) issue(r0 + wave);
-    for (int rr = wave; rr < rows; rr += NW) {
-        const int row = r0 + rr;
-        if (row >= M) break;
-        raw4 cd[NIT], cx[NIT], cr[NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) { cd[it] = nd[it]; cx[it] = nx[it]; cr[it] = nr[it]; }
-        const float mu = nmu, rs = nrs;
-        if (rr + NW < rows && row + NW < M) issue(row + NW);
+    for (int s = 0; s < PF; ++s) {
+        nmu[s] = 0.f; nrs[s] = 0.f;
+        if (wave + s * NW < rows && r0 + wave + s * NW < M) issue(r0 + wave + s * NW, nd[s], nx[s], nr[s], nmu[s], nrs[s]);
+    }
+    for (int rb = wave; rb < rows; rb += NW * PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+        const int rr = rb + s * NW;
+        const int row = r0 + rr;
+        if (rr >= rows || row >= M) break;
+        // pass 1 straight out of the ring set (no copies of dy / x: their registers are free for the next request as soon as the pass has read them)
+        const float mu = nmu[s], rs = nrs[s];
         f32x4 a[NIT], xh[NIT];
+        raw4 cr[NIT];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int c = (it * 64 + lane) * 4;
-            if (c < D) {
-                const f32x4 d = raw_to_f32(cd[it]);
-                const f32x4 xv = raw_to_f32(cx[it]);
+            cr[it] = nr[s][it];
+            if (FULL || c < D) {
+                const f32x4 d = raw_to_f32(nd[s][it]);
+                const f32x4 xv = raw_to_f32(nx[s][it]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float h = (xv[j] - mu) * rs;
@@ -154,12 +175,13 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
                 }
             } else { a[it] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[it] = a[it]; }
         }
+        if (rr + PF * NW < rows && row + PF * NW < M) issue(row + PF * NW, nd[s], nx[s], nr[s], nmu[s], nrs[s]);
         const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
         T* dxr = dx + (int64_t)row * D;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int c = (it * 64 + lane) * 4;
-            if (c < D) {
+            if (FULL || c < D) {
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rs * (a[it][j] - m1 - xh[it][j] * m2);
@@ -168,12 +190,14 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
                 store4(dxr + c, o);
             }
         }
+        }
     }
-    // combine the waves' partials in a fixed tree (waves [h, 2h) hand theirs to waves [0, h) through LDS, h = NW/2 ... 1) -> part[blockIdx][3][D]
+    // combine the waves' partials in a fixed tree (of the n waves left, waves [h, n) hand theirs to waves [0, n - h) through LDS, h = ceil(n / 2); n = NW ... 2) -> part[blockIdx][3][D]
     const int W = NIT * 256;
 #pragma unroll
-    for (int h = NW / 2; h >= 1; h >>= 1) {
-        if (wave >= h && wave < 2 * h) {
+    for (int n = NW; n > 1; n = (n + 1) / 2) {
+        const int h = (n + 1) / 2;
+        if (wave >= h && wave < n) {
             float* dst = sm + (size_t)(wave - h) * 3 * W;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -184,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
             }
         }
         __syncthreads();
-        if (wave < h) {
+        if (wave < n - h) {
             const float* src = sm + (size_t)wave * 3 * W;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -201,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int c = (it * 64 + lane) * 4;
-            if (c < D) {
+            if (FULL || c < D) {
                 const f32x4 a = dg[it], b = db[it], cc = dc[it];
                 if (dgamma) {      // a single workgroup: these ARE the results -- no reduce pass (same values: the pass adds zeros to them)
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -254,7 +278,7 @@ int ln_fwd_dispatch(const T* x, const float* g, const float* b, T* y, float* mea
 // workgroups and rows per workgroup of the backward kernel: up to LNB_ONE_WG_ROWS rows one workgroup (which then writes the parameter gradients itself),
 // otherwise the rows spread evenly over at most one workgroup per CU
 void ln_bwd_shape(int M, int& nwg, int& rows) {
-    nwg = M <= LNB_ONE_WG_ROWS ? 1 : (cdiv(M, LNB_MIN_ROWS) < ln_ncu() ? cdiv(M, LNB_MIN_ROWS) : ln_ncu());
+    nwg = M <= LNB_ONE_WG_ROWS ? 1 : (cdiv(M, LNB_MIN_ROWS) < ln_ncu() * LNB_WGS_PER_CU ? cdiv(M, LNB_MIN_ROWS) : ln_ncu() * LNB_WGS_PER_CU);
     rows = cdiv(M, nwg);
     nwg = cdiv(M, rows);
 }
@@ -268,9 +292,11 @@ int ln_bwd_dispatch(const T* dy, const T* x, const float* g, const float* mean, 
     // waves per workgroup: 16 where the row fits 128 registers per lane (bf16 up to D = 768, fp32 up to 512), 8 up to D = 1024, 4 beyond: no instantiation may spill
     // (the combine tree's LDS is NW / 2 x 3 x NIT x 1 KiB)
     constexpr bool half = sizeof(T) == 2;
-#define LNB(N, NW) hipLaunchKernelGGL((ln_bwd_kernel<T, N, NW>), dim3(nwg), dim3(NW * 64), (NW / 2) * 3 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D, rows, \
+#define LNB(N, NW, PF, FULL) hipLaunchKernelGGL((ln_bwd_kernel<T, N, NW, PF, FULL>), dim3(nwg), dim3(NW * 64), ((NW + 1) / 2) * 3 * N * 256 * sizeof(float), st, dy, x, g, mean, rstd, dres, dx, part, M, D, rows, \
                                       dgamma, dbeta, dxsum, beta_acc)
-    if (nit <= 2) LNB(2, 16); else if (nit <= 3) { if constexpr (half) LNB(3, 16); else LNB(3, 8); } else if (nit <= 4) LNB(4, 8); else LNB(8, 4);
+    if (nit <= 2) LNB(2, 16, 1, false);
+    else if (nit <= 3) { if constexpr (half) { if (D == 768) LNB(3, LNB_NW, LNB_PF, (LNB_NW != 16)); else LNB(3, 16, 1, false); } else LNB(3, 8, 1, false); }
+    else if (nit <= 4) LNB(4, 8, 1, false); else LNB(8, 4, 1, false);
 #undef LNB
     return 0;
 }

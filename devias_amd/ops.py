@@ -65,6 +65,14 @@ def set_option(name: str, value: int) -> None:
     _lib.check(_lib.load().devias_set_option(name.encode(), int(value)), "devias_set_option")
 
 
+def release_gemm_queue_stream(stream=None) -> None:
+    """devias_gemm_release_queue_stream: the dynamic tile queues of the persistent GEMM (option gemm_dynamic) live in one ring per device that belongs to the FIRST
+    stream that launched a dynamic-queue GEMM; launches on any other stream walk static tile lists (same bits, slower beside concurrent kernels).  A host that moves
+    its step to another stream calls this -- after every dynamic-queue launch of the old stream has completed -- to hand the ring to `stream` (default: the current one)."""
+    st = torch.cuda.current_stream() if stream is None else stream
+    _lib.check(_lib.load().devias_gemm_release_queue_stream(st.cuda_stream), "devias_gemm_release_queue_stream")
+
+
 def counters(reset: bool = False) -> dict:
     """launch counts per kernel family since the last reset (devias_counter): tests assert WHICH kernels served a step"""
     lib = _lib.load()

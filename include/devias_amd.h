@@ -106,6 +106,11 @@ void devias_shutdown(void);
  * The reference has no profiler ranges (utils/utils.py:120-164 keeps wall-clock meters only). */
 void devias_range_push(const char* name);
 void devias_range_pop(void);
+/* ---------------------------------------------------------------------------------------------------
+ * MEASUREMENT entry points (devias_debug_*).  Part of the ABI: bench.py's `roofline` object is built from three of them
+ * (devias_debug_gemm_timer_arm / _read: in-step kernel timing; devias_debug_mfma_probe: the sustained MFMA peak of the box), its
+ * --cu-hog flag from a fourth.  None of them changes what any other entry point computes; none has a reference counterpart.
+ * ------------------------------------------------------------------------------------------------- */
 /* Measurement aid (bench.py --cu-hog K): n_workgroups workgroups that each pin 128 KiB of LDS -- no 128-KiB-LDS GEMM workgroup can share their
  * CU -- and idle for `usec` microseconds, enqueued on `stream` (a side stream): a stand-in for the compute units a concurrent RCCL kernel
  * occupies during backward, so that the persistent GEMM grids' sensitivity to missing CUs can be measured on one GPU.  No reference analogue. */
@@ -138,6 +143,11 @@ int devias_device_info(int device, int64_t* out5);
  *   c_f32 = 1 with T = bf16 writes C (and reads it under beta) as fp32: weight-gradient GEMMs.
  *   split_k > 1: partial sums go to `ws` (split_k * M * N floats) and a second kernel reduces them in a fixed order and
  *     applies the same epilogue (used for the long-M weight-gradient reductions and the 64-row slot MLP GEMMs).
+ * Naming: SURVEY.md section 8(b) sketched this boundary as devias_gemm_bias_act_{fwd,dgrad,wgrad} and devias_patch_embed_{fwd,wgrad}.  They are ONE entry point here:
+ *   devias_gemm_bias_act_fwd   = devias_gemm(trans_a 0, trans_b 0, bias, act, aux_out, res)
+ *   devias_gemm_bias_act_dgrad = devias_gemm(trans_a 0, trans_b 1, act DGELU / DRELU + aux_in, colsum = the bias gradient)
+ *   devias_gemm_bias_act_wgrad = devias_gemm(trans_a 1, trans_b 1, c_f32 1, split_k, beta = gradient accumulation)
+ *   devias_patch_embed_fwd     = devias_patch_im2col + devias_gemm(bias, res = positional table with res_mod);  _wgrad = the wgrad form over the same im2col matrix
  * Replaces: F.linear / nn.Linear forward, its dgrad and wgrad ATen kernels (mm / addmm) at
  *   modeling_slot.py:60-67 (Mlp), :97-101 (qkv), :113 (proj), :167-177 (Conv3d patch embed as GEMM), :302/:393 (head),
  *   :199-204 (MaskPredictor), agg_block/attention.py:66-72 (FeedForward), :108-115,123-126,141 (to_q/to_k/to_v/to_out).
@@ -236,6 +246,8 @@ int64_t devias_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
  *   (csrc/attn_bwd1w.hip, bf16: one wave owns a SIMD and all 512 registers, dK / dV accumulators in AGPRs, the softmax arithmetic placed in the MFMAs' gaps);
  *   with ws = NULL, or option "attn_dkdv" = 0, the two-waves-per-SIMD dK / dV kernel of rounds 2-4 runs instead (same semantics, results equal to rounding);
  *   "attn_dkdv" = 2 runs the one-wave kernel as one persistent workgroup per CU (bitwise equal to the default, one workgroup per 256-key block).
+ *   CALLERS OF ABI <= 163: `ws` was documented as unused there.  It has no size argument: a non-NULL ws is WRITTEN with devias_mhsa_bwd_workspace_bytes(B, N, H)
+ *   bytes (B * H * 2 * ceil(N / 32) * 32 floats), so pass either NULL or a buffer of at least that size -- never a small dummy pointer.
  * ------------------------------------------------------------------------------------------------- */
 int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
                     int32_t dtype, void* stream);

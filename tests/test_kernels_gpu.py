@@ -531,18 +531,18 @@ def gemm_options():
     o = ops()
     yield o
     for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_w4", -1), ("gemm_tail_split", 2), ("gemm_smallm", 1),
-                 ("gemm_dynamic", -1), ("gemm_concurrent", 0)):
+                 ("gemm_dynamic", -1), ("gemm_concurrent", 0), ("gemm_epi_spec", 1)):
         o.set_option(k, v)
 
 
 def _persistent_serves(tb, epi):
     """the persistent kernels are compiled per kind of row the epilogue reads: none / residual for B k-contiguous (forward GEMMs),
     none / saved pre-activation for B k-strided (dgrad GEMMs); anything else runs the one-tile-per-workgroup kernel"""
-    return epi in (("bias", "plain", "gelu_aux", "dgelu_colsum") if tb else ("bias", "plain", "gelu_aux", "res", "res_rowscale"))
+    return epi in (("bias", "plain", "colsum", "gelu_aux", "dgelu_colsum") if tb else ("bias", "plain", "colsum", "gelu_aux", "res", "res_rowscale"))
 
 
 @pytest.mark.parametrize("tb", [False, True])
-@pytest.mark.parametrize("epi", ["bias", "res", "gelu_aux", "dgelu_colsum", "plain", "res_rowscale"])
+@pytest.mark.parametrize("epi", ["bias", "res", "gelu_aux", "dgelu_colsum", "plain", "colsum", "res_rowscale"])
 @pytest.mark.parametrize("M,N,K", [(256 * 70, 1024, 128), (256 * 300, 256, 320), (256 * 99, 768, 768), (256 * 131, 512, 64),
                                    (256 * 196, 768, 448), (256 * 196, 2304, 192)])
 def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
@@ -551,7 +551,9 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
     wave per SIMD, accumulators in literal AGPRs, two K-tiles of LDS-DMA in flight; the default where K >= 1024 and N >= 1024) against the fp32 op on the
     bf16-rounded inputs; the same call through the one-tile-per-workgroup kernel, with both epilogues, must agree BITWISE (same MFMA order, same
     fp32 epilogue arithmetic).  Tile counts are not multiples of the CU count (partial rounds of 1 to 5 rounds), K covers one to twelve K-tiles,
-    and the counters assert which kernel served each call."""
+    and the counters assert which kernel served each call.  Round 6: the eight-wave kernel has instantiations whose epilogue switches are compile-time facts
+    (option gemm_epi_spec, on: the encoder block's six epilogues -- bias; bias + GELU + saved pre-activation; bias + residual; nothing; column sums; dGELU + column
+    sums); modes pg / psg run the generic instantiation instead: every form must give the same bits."""
     o = gemm_options
     from devias_amd._lib import ACT_DGELU, ACT_GELU
     A = rnd(M, K, dtype=torch.bfloat16, seed=1)
@@ -577,16 +579,17 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
     outs = {}
     serves = _persistent_serves(tb, epi)
     # persistent (eight waves with the tail split in both forms / without it, four waves); one tile per workgroup with the register-transposed / the LDS-staged epilogue
-    for mode in ("p", "p1", "p0", "ps", "ps0", "w", "0", "0s"):
-        o.set_option("gemm_persistent", 1 if mode in ("p", "p1", "p0", "ps", "ps0", "w") else 0)
+    for mode in ("p", "p1", "p0", "ps", "ps0", "pg", "psg", "w", "0", "0s"):
+        o.set_option("gemm_persistent", 1 if mode in ("p", "p1", "p0", "ps", "ps0", "pg", "psg", "w") else 0)
         o.set_option("gemm_tail_split", {"p0": 0, "ps0": 0, "p1": 1}.get(mode, 2))
-        o.set_option("gemm_dynamic", 0 if mode in ("ps", "ps0", "w") else 1)          # (the four-wave kernel walks static lists: the queues take precedence)
+        o.set_option("gemm_dynamic", 0 if mode in ("ps", "ps0", "psg", "w") else 1)          # (the four-wave kernel walks static lists: the queues take precedence)
+        o.set_option("gemm_epi_spec", 0 if mode in ("pg", "psg") else 1)
         o.set_option("gemm_w4", 15 if mode == "w" else 0)
         o.set_option("gemm_epi", 0 if mode == "0s" else 1)
         kw2 = dict(kw)
         if epi == "gelu_aux":
             kw2["aux_out"] = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        if epi == "dgelu_colsum":
+        if epi in ("dgelu_colsum", "colsum"):
             kw2["colsum"] = torch.zeros(N, device=DEV)
         o.counters(reset=True)
         c = o.gemm(A, B, trans_b=tb, **kw2)
@@ -594,21 +597,24 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         cnt = o.counters()
         want = (1, 0) if (serves and mode not in ("0", "0s")) else (0, 1)
         assert (cnt["gemm256p"], cnt["gemm256"]) == want, (mode, cnt)
-        assert cnt["gemm256d"] == (1 if mode in ("p", "p1", "p0") and serves and K >= 128 else 0), (mode, cnt)   # (one K-tile per tile: the static list)
+        assert cnt["gemm256d"] == (1 if mode in ("p", "p1", "p0", "pg") and serves and K >= 128 else 0), (mode, cnt)   # (one K-tile per tile: the static list)
         assert cnt["gemm256w"] == (1 if mode == "w" and serves and K >= 128 else 0), (mode, cnt)       # (one K-tile: the eight-wave kernel)
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
     c, aux, cs = outs["0"]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]
-    for mode in ("p", "p1", "p0", "ps", "ps0", "w", "0s"):
+    others = ("p", "p1", "p0", "ps", "ps0", "pg", "psg", "w", "0s")
+    for mode in others:
         assert torch.equal(c, outs[mode][0]), mode
     if aux is not None:
         assert rel(aux.float(), ref_pre) < TOL[torch.bfloat16]
-        for mode in ("p", "p1", "p0", "ps", "ps0", "w", "0s"):
+        for mode in others:
             assert torch.equal(aux, outs[mode][1]), mode
     if cs is not None:
         assert rel(cs, c.float().sum(0)) < 1e-2                 # sums the fp32 values before bf16 rounding
-        for mode in ("p", "p1", "p0", "ps", "ps0", "w", "0s"):
+        for mode in others:
             assert rel(cs, outs[mode][2]) < 1e-5, mode
+        for mode in ("pg", "psg"):                              # the eight-wave kernel's two epilogue forms add the same values in the same order
+            assert torch.equal(outs["p"][2], outs[mode][2]), mode
 
 
 def test_gemm_persistent_kernels_repeatable(gemm_options):
@@ -705,6 +711,44 @@ def test_gemm_dynamic_queue_with_held_cus(gemm_options):
     t_dyn, t_static = min(times[1]), min(times[0])
     print(f"12 persistent GEMM launches with 48 CUs held: static lists {t_static:.2f} ms, dynamic queues {t_dyn:.2f} ms")
     assert t_dyn < 0.85 * t_static, (t_dyn, t_static)
+
+
+def test_gemm_dynamic_queue_ring_belongs_to_one_stream(gemm_options):
+    """the ring of queue slots belongs to the first stream that launches a dynamic-queue GEMM on the device; a launch on any other stream must fall back
+    to the static tile lists (gemm256d does not count it) with the same bits, and ops.release_gemm_queue_stream must hand the ring to a new owner."""
+    o = gemm_options
+    M, D = 256 * 196, 768
+    A = rnd(M, D, dtype=torch.bfloat16, seed=31)
+    W = rnd(3 * D, D, dtype=torch.bfloat16, scale=0.05, seed=32)
+    b = rnd(3 * D, seed=33)
+    o.set_option("gemm_persistent", 0)
+    ref = o.gemm(A, W, bias=b)
+    o.set_option("gemm_persistent", 1)
+    o.set_option("gemm_dynamic", 1)
+    torch.cuda.synchronize()
+    main = torch.cuda.current_stream()
+    o.release_gemm_queue_stream(main)                      # whatever ran before in this process: the ring is the current stream's now
+    other = torch.cuda.Stream()
+
+    def launch(stream):
+        with torch.cuda.stream(stream):
+            o.counters(reset=True)
+            c = o.gemm(A, W, bias=b)
+        torch.cuda.synchronize()
+        cnt = o.counters()
+        assert cnt["gemm256p"] == 1, cnt
+        assert torch.equal(c, ref)
+        return cnt["gemm256d"]
+
+    assert launch(main) == 1
+    assert launch(other) == 0                              # not the owner: static lists, same bits
+    assert launch(main) == 1
+    torch.cuda.synchronize()
+    o.release_gemm_queue_stream(other)                     # every dynamic-queue launch has completed: hand the ring over
+    assert launch(other) == 1
+    assert launch(main) == 0
+    torch.cuda.synchronize()
+    o.release_gemm_queue_stream(main)
 
 
 # ------------------------------------------------------------------------------------------------ attention backward: grids, ragged shapes, descriptors

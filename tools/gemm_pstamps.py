@@ -1,6 +1,6 @@
 """Per-tile timeline of the persistent 256 x 256 GEMM kernel (debug build, gemm_debug = 8): where a tile's time goes between the K loop, the
 epilogue, and the first K-iteration of the next tile (which has to wait for the epilogue's stores: vmcnt completes in issue order).
-Usage: python tools/gemm_pstamps.py [fc1|fc1g|proj|qkv]   (needs tools/exp/libdevias_amd_dbg.so: python tools/gemm_epi_ablate.py --rebuild)"""
+Usage: python tools/gemm_pstamps.py [fc1|fc1g|proj|qkv|fc2|dfc2|dfc1|dproj|dqkv]   (needs tools/exp/libdevias_amd_dbg.so: python tools/gemm_epi_ablate.py --rebuild)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,20 +9,31 @@ import ctypes, torch, numpy as np
 from devias_amd import ops as o, _lib
 which = sys.argv[1] if len(sys.argv) > 1 else "fc1"
 M = 50176
-N, K = {"fc1": (3072, 768), "fc1g": (3072, 768), "proj": (768, 768), "qkv": (2304, 768), "fc2": (768, 3072)}[which]
-a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
+N, K = {"fc1": (3072, 768), "fc1g": (3072, 768), "proj": (768, 768), "qkv": (2304, 768), "fc2": (768, 3072),
+        "dfc2": (3072, 768), "dfc1": (768, 3072), "dproj": (768, 768), "dqkv": (768, 2304)}[which]
+TB = which.startswith("d")
+a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(*((K, N) if TB else (N, K)), device="cuda") * 0.02).bfloat16()
+pre = torch.randn(M, N, device="cuda").bfloat16() if which == "dfc2" else None
+csum = torch.zeros(N, device="cuda")
+CS = which in ("dfc2", "dproj")                  # fused column sums: the partials own the head of ws ([M / 128][N] floats), the debug build puts its stamps behind them
 bias = torch.randn(N, device="cuda") * 0.1
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 aux = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 res = torch.randn(M, N, device="cuda").bfloat16()
-ws = torch.zeros(256 * 64, dtype=torch.int64, device="cuda")
+ws = torch.zeros(256 * 64 + (M // 128 * N // 2 if CS else 0), dtype=torch.int64, device="cuda")
 o.set_option("gemm_persistent", 2); o.set_option("gemm_debug", 8)
 if len(sys.argv) > 2: o.set_option("gemm_dynamic", int(sys.argv[2]))
 def call():
     g = _lib.GemmArgs()
     g.A, g.B, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
-    g.M, g.N, g.K = M, N, K; g.lda, g.ldb, g.ldc = K, K, N
-    g.dtype = 1; g.split_k = 1; g.ws = ws.data_ptr(); g.bias = bias.data_ptr()
+    g.M, g.N, g.K = M, N, K; g.lda, g.ldb, g.ldc = K, (N if TB else K), N
+    g.trans_b = 1 if TB else 0
+    g.dtype = 1; g.split_k = 1; g.ws = ws.data_ptr()
+    if not TB: g.bias = bias.data_ptr()
+    if which == "dfc2":
+        g.act = 4; g.aux_in = pre.data_ptr(); g.ld_aux = N
+    if CS:
+        g.colsum = csum.data_ptr()
     if which == "fc1g":
         g.act = 1; g.aux_out = aux.data_ptr(); g.ld_aux = N
     if which in ("proj", "fc2"):
@@ -31,7 +42,7 @@ def call():
 for _ in range(3): call()
 torch.cuda.synchronize()
 assert o.counters()["gemm256p"] >= 3
-d = ws.cpu().numpy().reshape(256, 64)
+d = ws.cpu().numpy()[(M // 128 * N // 2 if CS else 0):].reshape(256, 64)
 t = (d >> 4) / 100.0; code = d & 15
 kl, ep, first, steady, clk = [], [], [], [], []
 ep_a, ep_b, ep_c = [], [], []          # dynamic queue: K loop done -> epilogue stores issued (2 -> 5), dequeue block + decode (5 -> 6), counted wait (6 -> 3)
