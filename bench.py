@@ -137,6 +137,57 @@ def in_step_gemm_ms(step, M: int, N: int, K: int, trans_a: int, trans_b: int):
     return (ms.value / n.value, n.value) if n.value else (None, 0)
 
 
+def in_step_gemm_each(step, M: int, N: int, K: int, trans_a: int, trans_b: int):
+    """The devias_gemm launches of one signature inside ONE real step, one by one in launch order (milliseconds): forward launches come first.  Needed since round 6: a
+    dgrad GEMM on a transposed weight copy has the signature of a forward GEMM (fc1 / dfc2, proj / dproj, fc2 / dfc1)."""
+    import ctypes
+    from devias_amd import _lib as _dl
+    lib = _dl.load()
+    torch.cuda.synchronize()
+    _dl.check(lib.devias_debug_gemm_timer_arm(M, N, K, trans_a, trans_b), "devias_debug_gemm_timer_arm")
+    try:
+        step()
+        torch.cuda.synchronize()
+        n, each = ctypes.c_int32(0), (ctypes.c_float * 64)()
+        _dl.check(lib.devias_debug_gemm_timer_read_each(ctypes.byref(n), each, 64), "devias_debug_gemm_timer_read_each")
+    finally:
+        lib.devias_debug_gemm_timer_arm(0, 0, 0, 0, 0)
+    return [each[i] for i in range(n.value)]
+
+
+def gemm_shapes_probe(args, step) -> dict:
+    """`roofline.gemm_shapes`: the encoder block's GEMMs, each timed INSIDE a real step (one armed step per signature): median us over the blocks, TFLOP/s
+    and the fraction of the nominal bf16 peak.  The same shapes beside the vendor library's times and kernel names: profiles/r6_gemm_shapes.txt (tools/gemm_ledger.py)."""
+    import statistics as st
+    D = {"vit_base": 768, "vit_small": 384, "vit_large": 1024}[args.model]
+    depth = {"vit_base": 12, "vit_small": 12, "vit_large": 24}[args.model]
+    M = args.batch * (args.frames // 2) * (args.img_size // 16) ** 2
+    out = {}
+
+    def put(name, n_out, k_in, us):
+        fl = 2.0 * M * n_out * k_in
+        out[name] = {"us": round(us, 1), "tflops": round(fl / us / 1e6, 1), "frac": round(fl / us / 1e6 / PEAK_BF16_TFLOPS, 4)}
+
+    def med(v):
+        return st.median(v) if v else float("nan")
+    # (signature, names in launch order within a step: `depth` forward launches, then `depth` backward launches on the transposed weight copy)
+    for (n, k), (fwd, bwd, bn, bk) in {(3 * D, D): ("qkv fwd", None, 0, 0), (4 * D, D): ("fc1 fwd +GELU +pre", "dfc2 dgrad +dGELU +colsum", 4 * D, D),
+                                       (D, D): ("proj fwd +res", "dproj dgrad +colsum", D, D), (D, 4 * D): ("fc2 fwd +res", "dfc1 dgrad", D, 4 * D),
+                                       (D, 3 * D): ("dqkv dgrad", None, 0, 0)}.items():
+        ms = in_step_gemm_each(step, M, n, k, 0, 0)
+        if len(ms) == depth and bwd is None:
+            put(fwd, n, k, med(ms) * 1e3)
+        elif len(ms) == 2 * depth and bwd is not None:
+            put(fwd, n, k, med(ms[:depth]) * 1e3); put(bwd, bn, bk, med(ms[depth:]) * 1e3)
+        else:
+            out[fwd] = {"note": f"{len(ms)} launches of signature [{M}, {n}, {k}] in the step: not the {depth} / {2 * depth} this table assumes (dgrad without transposed weight copies?)"}
+    for name, n_out, k_in in (("wfc2 wgrad", D, 4 * D), ("wfc1 wgrad", 4 * D, D), ("wproj wgrad", D, D), ("wqkv wgrad", 3 * D, D)):
+        ms = in_step_gemm_each(step, n_out, k_in, M, 1, 1)
+        if ms:
+            put(name + " (+ split-K reduce)", n_out, k_in, med(ms) * 1e3)
+    return out
+
+
 def sustained_mfma_probe(device) -> dict:
     """What the matrix cores of THIS part sustain (VERDICT r4 missing 3): a bare v_mfma_f32_16x16x32_bf16 loop on random bf16 operands held in registers, one
     512-thread workgroup per CU, ~50 ms per launch after a warm launch (devias_debug_mfma_probe); TFLOP/s from HIP events around the launch, the clock the CUs held from
@@ -226,8 +277,15 @@ def fc1_fwd_probe(args, device, step=None):
     e1.record()
     torch.cuda.synchronize()
     loop_ms = e0.elapsed_time(e1) / n
-    ms, n_in_step = in_step_gemm_ms(step, M, 4 * D, D, 0, 0) if step is not None else (None, 0)
-    timed = "inside real steps (library events around each launch)" if ms is not None else "back-to-back loop on random operands"
+    ms, n_in_step = None, 0
+    if step is not None:
+        # (since round 6 the dfc2 dgrad on the transposed weight copy has fc1's signature: the step's first `depth` launches of it are the forward's)
+        each = in_step_gemm_each(step, M, 4 * D, D, 0, 0)
+        depth = {"vit_base": 12, "vit_small": 12, "vit_large": 24}[args.model]
+        fwd = each[:depth] if len(each) >= depth else each
+        if fwd:
+            ms, n_in_step = sum(fwd) / len(fwd), len(fwd)
+    timed = "inside a real step (library events around each launch)" if ms is not None else "back-to-back loop on random operands"
     if ms is None:
         ms = loop_ms
     fl = 2.0 * M * 4 * D * D
@@ -436,12 +494,14 @@ def main():
                                (f" + persistent GEMM grids sized for {args.reserve_cus} fewer CUs (--reserve-cus)" if args.reserve_cus else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,
-                   "kernels": "persistent 256x256 GEMM (forward + dgrad; tail tiles of a partial round split between two workgroups), 32x32x16 MFMA attention forward, two-kernel MFMA attention backward, folded slot "
+                   "kernels": "persistent 256x256 GEMM (forward + dgrad -- the dgrad on transposed bf16 weight copies made once per weight update, both operands k-contiguous; epilogue switches compile-time per call site; "
+                              "tail tiles of a partial round split between two workgroups), 32x32x16 MFMA attention forward, two-kernel MFMA attention backward, folded slot "
                               "cross-attention (K/V projections on the slot side); one library call per fused region and direction (csrc/regions.hip)"},
         # schema 5 (round 5): roofline.dominant_kernel = the trace's row 1 (the fc1 weight gradient), probe_fc1_fwd = the fc1 forward, both timed inside real steps;
         # roofline.sustained_peak / frac_of_sustained; `rccl` at N > 1.  schema 4 (round 4): `host_enqueue_ms_per_step` has its round-1/2 meaning again (host time to enqueue the K timed steps back to back: a full launch
         # queue throttles the host to the device's pace, so on a device-bound step it reads ~ the step time); the host's own cost is the idle-stream number
-        "schema": 5,
+        # schema 6 (round 6): roofline.gemm_shapes = every GEMM of an encoder block timed inside a real step (one armed step per signature)
+        "schema": 6,
         "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3, "host_library_calls_per_step": lib_calls,
         "host_idle_enqueue_ms_per_step": host_idle[len(host_idle) // 2] * 1e3,
         "host_idle_enqueue_method": "one step enqueued on an idle stream, median of 5, outside the timed region (python + fused-region library calls + HIP launches)",
@@ -462,7 +522,8 @@ def main():
                             # the nominal fraction above stays the headline; beside it the same rate against what this part's matrix cores sustain on random data
                             "sustained_peak": sus, "frac_of_sustained": (ach / sus["tflops"]) if sus else None,
                             "dominant_kernel": dom,                                  # row 1 of the step's rocprofv3 kernel trace
-                            "probe_fc1_fwd": fc1_fwd_probe(args, device, in_step)}     # (rounds 1-4 reported this one under the key `dominant_kernel`)
+                            "probe_fc1_fwd": fc1_fwd_probe(args, device, in_step),     # (rounds 1-4 reported this one under the key `dominant_kernel`)
+                            "gemm_shapes": gemm_shapes_probe(args, in_step) if in_step is not None else None}
     if world > 1:
         # proof of the rank count for a SCALE record: what the process group itself says, and every rank's device
         line["rccl"] = rccl_info

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DEVIAS_LIB_PATH") or os.path.join(_HERE, "libdevias_amd.so")     # (override: ablation builds of tools/)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 164                # devias_version() of the library these prototypes describe
+ABI_VERSION = 166                # devias_version() of the library these prototypes describe
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4, 5
 
 
@@ -49,7 +49,8 @@ _FP = POINTER(c_float)
 class BlockArgs(Structure):          # devias_block_args
     _fields_ = [(n, c_int32) for n in ("B", "N", "D", "H", "hidden", "dtype")] + [("eps", c_float)] + \
                [(n, c_void_p) for n in ("n1w", "n1b", "n2w", "n2b", "Wqkv", "Wp", "W1", "W2", "qkv_bias", "pb", "b1", "b2", "ds1", "ds2", "save", "ws")] + \
-               [("ws_bytes", c_int64), ("sk_ws", c_void_p), ("sk_ws_bytes", c_int64)]
+               [("ws_bytes", c_int64), ("sk_ws", c_void_p), ("sk_ws_bytes", c_int64)] + \
+               [(n, c_void_p) for n in ("WqkvT", "WpT", "W1T", "W2T")]          # ABI 166: optional transposed weight copies for the dgrad GEMMs
 
 
 class BlockGrads(Structure):         # devias_block_grads
@@ -108,6 +109,7 @@ PROTOTYPES = {
     "devias_debug_gemm_timer_arm": (c_int, [_I, _I, _I, _I, _I]),
     "devias_debug_dkdv_stamps": (c_int, [_P, _I]),
     "devias_debug_gemm_timer_read": (c_int, [POINTER(c_int32), POINTER(c_float)]),
+    "devias_debug_gemm_timer_read_each": (c_int, [POINTER(c_int32), POINTER(c_float), c_int32]),
     "devias_gemm_release_queue_stream": (c_int, [_P]),
     "devias_gemm": (c_int, [POINTER(GemmArgs), _P]),
     "devias_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
@@ -176,7 +178,8 @@ PROTOTYPES = {
     "devias_policy_wgrad_split": (c_int32, [_I, _I, _I, _I]),
 }
 COUNTERS = {"gemm128_f32": 0, "gemm128_bf16": 1, "gemm_ss": 2, "gemm256": 3, "gemm256p": 4, "splitk_reduce": 5,
-            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10, "gemm_sk": 11, "gemm256w": 12, "gemm_smallm": 13, "gemm256d": 14}     # DEVIAS_CNT_*
+            "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10, "gemm_sk": 11, "gemm256w": 12, "gemm_smallm": 13, "gemm256d": 14,
+            "dkdv1w": 15, "dkdv1w_pers": 16, "dkdv1w_rest": 17, "dkdv2w": 18}     # DEVIAS_CNT_*
 OPT_CHUNK = 16384          # DEVIAS_OPT_CHUNK
 OPT_TENSOR_BYTES = 64      # sizeof(devias_opt_tensor)
 

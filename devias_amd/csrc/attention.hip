@@ -1279,10 +1279,13 @@ static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const 
         if (w1) {
             const int rc = devias_attn_dkdv1w_launch(qkv, d_o, stat, dqkv, B, N, npad, H, scale, xcd, attn_knobs().dkdv == 2, st);
             if (rc != DEVIAS_OK) return rc;
-        } else if (drop) hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<true>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
-                                     lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_v);
-        else hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<false>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
-                                lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_v);
+        } else {
+            devias_count(DEVIAS_CNT_DKDV2W);
+            if (drop) hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<true>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
+                                         lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_v);
+            else hipLaunchKernelGGL(mhsa_bwd_dkdv_bf16_kernel<false>, BWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (const bf16*)d_o,
+                                    lse, delta, (bf16*)dqkv, N, H, scale, xcd, dp, part_v);
+        }
 #undef BWD_GRID
         DEVIAS_CHECK_LAUNCH("devias_mhsa_bwd(dkdv)");
     } else if (dtype == DEVIAS_F32) {

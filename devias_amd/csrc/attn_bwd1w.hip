@@ -625,12 +625,15 @@ int devias_attn_dkdv1w_launch(const void* qkv, const void* d_o, const float* sta
         const int items = nfull * H * B, ncu = devias_device_cus() & ~7;
         if (persistent && (xcd_flag & 1) && qbytes < 0x7fffffff && ncu >= 8 && items > ncu) {
             hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8, true>), dim3(ncu), dim3(256), 0, st, DKDV_ARGS, 0, nfull);
+            devias_count(DEVIAS_CNT_DKDV1W_PERS);
         } else {
             const dim3 grid = (xcd_flag & 1) ? dim3(items) : dim3(nfull, H, B);
             hipLaunchKernelGGL((mhsa_bwd_dkdv1w_kernel<4, 8, false>), grid, dim3(256), 0, st, DKDV_ARGS, 0, nfull);
+            devias_count(DEVIAS_CNT_DKDV1W);
         }
     }
     if (rest > 0) {
+        devias_count(DEVIAS_CNT_DKDV1W_REST);
         const dim3 grid = (xcd_flag & 1) ? dim3(H * B) : dim3(1, H, B);
         if (rest <= 64) {
             // one wave tile per head: as many waves on it (each with a share of the query slices) as keep the launch inside ONE round of one wave per SIMD

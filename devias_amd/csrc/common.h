@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define WAVE 64
 
 int devias_set_error(int code, const char* fmt, ...);
+int devias_policy_gemm_wt(void);                            // option gemm_wt (gemm.hip): the fused encoder block may run its dgrad GEMMs on transposed weight copies
 void devias_count(int id);                                  // launch counters (api.hip): DEVIAS_CNT_* of include/devias_amd.h
 int devias_gemm_set_option(const char* name, int value);    // per-module option handlers behind devias_set_option: 1 = name known
 int devias_attn_set_option(const char* name, int value);

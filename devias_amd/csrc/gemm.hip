@@ -37,6 +37,7 @@ struct GemmP {
                           // 4 = no LDS-DMA after tile 0, 8 = s_memrealtime stamps into ws, 64 = epilogue without its C stores,
                           // 128 = without its pre-activation stores, 256 = without the GELU / dGELU polynomial, 1024 = the fc1 epilogue saves GELU'(pre) in place of pre
                           // (a second polynomial there), 2048 = the dGELU epilogue multiplies by the saved value (with 1024: the "saved derivative" form, measured in DESIGN.md section 5 round 5)
+    int aux_nt;           // persistent kernels: the saved pre-activation (aux_out) is stored with the non-temporal hint (option gemm_aux_nt)
     int tail_split;       // gemm256p_kernel: split the tiles of the last partial round between two workgroups (128-row halves)
     int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
     // dynamic tile queue of gemm256p_kernel<.., true>: this launch's queue slot (8 per-XCD heads, one per 128-byte line, + the line of claim masks; all zero
@@ -160,6 +161,9 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+template <typename F, int... N> __device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, N...>) { (f(std::integral_constant<int, N>{}), ...); }
+template <int COUNT, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_seq(f, std::make_integer_sequence<int, COUNT>{}); }
 
 // bijective XCD-aware remap: consecutive logical tile ids land on one XCD (private L2) -- speed only
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -301,6 +305,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmP& p, f32x4 (&acc)[NI]
 __device__ __forceinline__ void store16_asm(const void* sbase, uint32_t voff, u32x4 data) {
     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(data), "s"(sbase) : "memory");
 }
+// the same store with the non-temporal hint: for bytes nobody reads before they have left every cache anyway (the saved pre-activation of fc1: read by the backward, ~20 ms later)
+__device__ __forceinline__ void store16_asm_nt(const void* sbase, uint32_t voff, u32x4 data) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(data), "s"(sbase) : "memory");
+}
 // sum over the 16 lanes of a DPP row, by four DPP adds (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8) instead of four ds_bpermute shuffles: lane 0 of the row (the
 // only one whose result the epilogues store) adds exactly the pairs the xor-1/2/4/8 butterfly adds, in the same order -- bitwise the same -- without the LDS crossbar round trips
 __device__ __forceinline__ float row16_sum(float t) {
@@ -367,7 +375,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
         const int i = n >> 1, pr = n & 1;
         int m = mrow0 + i * 16 + lm;
         if (has_res && p.res_mod > 0) m %= p.res_mod;
-        return *reinterpret_cast<const bf16x8*>(side + (int64_t)m * side_ld + ncol0 + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1));
+        return *reinterpret_cast<const bf16x8*>(side + (int64_t)m * side_ld + ncol0 + 16 * (2 * pr + (g & 1)) + 8 * (g >> 1));      // (the saved pre-activation read non-temporally: -0.02 ms, noise; not kept)
     };
     if (side_on) {
 #pragma unroll
@@ -425,7 +433,10 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                             pre[e] = (bf16)d[0]; pre[e + 1] = (bf16)d[1];
                         }
                     }
-                    if constexpr (DEFER) store16_asm(aux_out + (int64_t)(mrow0 + i * 16) * p.ld_aux + ncol0 + 32 * pr, vo_x, *reinterpret_cast<const u32x4*>(&pre));
+                    if constexpr (DEFER) {
+                        if (p.aux_nt) store16_asm_nt(aux_out + (int64_t)(mrow0 + i * 16) * p.ld_aux + ncol0 + 32 * pr, vo_x, *reinterpret_cast<const u32x4*>(&pre));
+                        else store16_asm(aux_out + (int64_t)(mrow0 + i * 16) * p.ld_aux + ncol0 + 32 * pr, vo_x, *reinterpret_cast<const u32x4*>(&pre));
+                    }
                     else if (!GDBG(128) || v[0] == 12345.678f) *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
                 }
                 if (!GDBG(256)) {
@@ -789,6 +800,10 @@ __device__ __forceinline__ void plain_fence(bf16x8 (&f)[N]) {
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) :: "memory");
 }
 
+// (Round 6, measured and removed -- profiles/r6_wgrad_kloop.txt: two re-schedules of the k-strided K-tile of the weight-gradient kernel, both bitwise equal, both SLOWER in the
+//  step: progressive counted lgkmcnt waits, row tile i's MFMAs as soon as B and A[0..i] have returned, +0.17 / +0.23 ms; waves 4-7 running half a K-tile behind waves 0-3 so
+//  that the read phase of one wave of a SIMD falls under the MFMA phase of the other, +0.43 / +0.48 ms.  As in round 4, the compiler's schedule stands: what holds this loop at
+//  2.0 us per K-tile is not the order of reads and MFMAs inside a wave or between the two waves of a SIMD.)
 // ---- one K-tile (64 deep) of the 256 x 256 tile: 64 MFMAs per wave ---------------------------------------------------------------------
 // NT layout, order pinned by hand: 16 steps of 4 MFMAs (one A row-tile x 4 B column-tiles); the 8 LDS-DMA instructions of the NEXT K-tile
 // (source origins a_next / b_next = first row of the tile at the K-tile's first k; nullptr = nothing to load) go one per step over the
@@ -950,7 +965,7 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
     }
     if (GDBG(2) && acc[0][0][0] != 12345.678f) return;
 #endif
-    if constexpr (PIN != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing re-read must land before the LDS is released
+    if constexpr (PIN == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing re-read must land before the LDS is released
     if (p.epi_swap) { epilogue_swap<8>(p, acc, m0 + wm * 128, n0 + wn * 64, z, lane); return; }
     __syncthreads();                                   // every wave is done reading the operand stages
     epilogue_staged<8, 4>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, z, lane);
@@ -1351,8 +1366,6 @@ __device__ __forceinline__ void acc_claim() {
 }
 __device__ __forceinline__ void acc_zero() { acc_zero_seq(std::make_integer_sequence<int, 256>{}); }
 template <int I> __device__ __forceinline__ float acc_read1() { float x; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(I)); return x; }
-template <typename F, int... N> __device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, N...>) { (f(std::integral_constant<int, N>{}), ...); }
-template <int COUNT, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_seq(f, std::make_integer_sequence<int, COUNT>{}); }
 
 // Epilogue of gemm256w_kernel: the wave's 128 x 128 tile in ONE pass of 32 pieces (column half h, row tile i, tile pair pr; 16 rows x 64 B per
 // store instruction), same arithmetic in the same order as epilogue_swap (acc + bias -> lane-group exchange -> GELU -> row scale -> + residual ->
@@ -2040,6 +2053,8 @@ struct GemmKnobs {
     int persistent;    // "gemm_persistent" DEVIAS_GEMM_PERSIST  != 0: persistent 256x256 kernel where it applies (default), 0 = one tile per workgroup
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
     int epi_spec;      // "gemm_epi_spec"   DEVIAS_GEMM_EPI_SPEC 1 (default): the eight-wave persistent kernel runs the instantiation whose epilogue switches are compile-time facts where one exists (same bits); 0: always the generic form (A/B aid)
+    int wt;            // "gemm_wt"         DEVIAS_GEMM_WT       1 (default): the encoder block's backward runs its dgrad GEMMs on the caller's transposed weight copies (devias_block_args.W*T) where given; 0: reads the weights k-strided (A/B aid; same bits)
+    int aux_nt;        // "gemm_aux_nt"     DEVIAS_GEMM_AUX_NT   1 (default; -0.17 ms per step, in-process A/B): the persistent kernels store the saved pre-activation of a GELU epilogue non-temporally -- nobody reads it before the backward
     int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K), a workgroup per 16-row tile where there are few column groups; 2: one workgroup per column group always (A/B aid)
     int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups (1), whose idle waves
                        //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
@@ -2076,6 +2091,8 @@ GemmKnobs& knobs() {
         x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 2);
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
         x.epi_spec = env_int("DEVIAS_GEMM_EPI_SPEC", 1);
+        x.wt = env_int("DEVIAS_GEMM_WT", 1);
+        x.aux_nt = env_int("DEVIAS_GEMM_AUX_NT", 1);
         x.ncu = 0;                                        // (unused: the CU count is the current device's at every call, devias_device_cus())
         return x;
     }();
@@ -2125,6 +2142,8 @@ extern "C" int devias_gemm_release_queue_stream(void* stream) {
     return DEVIAS_OK;
 }
 
+int devias_policy_gemm_wt(void) { return knobs().wt; }
+
 // CUs the big-tile grids may count on: the device's, minus the reserve (option gemm_reserve_cus), in whole XCD rows
 extern "C" int32_t devias_policy_gemm_cus(void) {
     const GemmKnobs& k = knobs();
@@ -2145,6 +2164,8 @@ static int* gemm_option_slot(const char* name) {
     if (!strcmp(name, "gemm_tail_split")) return &k.tail_split;
     if (!strcmp(name, "gemm_smallm")) return &k.smallm;
     if (!strcmp(name, "gemm_epi_spec")) return &k.epi_spec;
+    if (!strcmp(name, "gemm_wt")) return &k.wt;
+    if (!strcmp(name, "gemm_aux_nt")) return &k.aux_nt;
     if (!strcmp(name, "gemm_reserve_cus")) return &k.reserve;
     if (!strcmp(name, "gemm_splitk_xcd")) return &k.splitk_xcd;
     if (!strcmp(name, "gemm_dynamic")) return &k.dynamic;
@@ -2166,28 +2187,28 @@ int devias_gemm_get_option(const char* name, int* value) {
 
 // The eight-wave persistent kernel's instantiation for a call: operand layout, the rows its epilogue reads (SIDE), static lists or dynamic queues, and -- option
 // gemm_epi_spec, on by default -- the epilogue's switches as compile-time facts (EPI, see epilogue_swap) where the call's combination has an instantiation:
-// the encoder block's six (qkv: bias; fc1: bias + GELU + saved pre-activation; proj / fc2 / patch embedding: bias + residual; dfc1 / dqkv: nothing; dproj: column
-// sums; dfc2: dGELU + column sums).  Everything else (stochastic depth's row scale, ReLU / Sigmoid heads, ...) runs the generic form.
+// the encoder block's seven (qkv: bias; fc1: bias + GELU + saved pre-activation; proj / fc2 / patch embedding: bias + residual; and, on TRANSPOSED weight copies
+// (devias_block_args.W*T: the dgrad GEMMs then read both operands k-contiguous, 9-17 % less K-loop time than with transposing LDS reads), dfc1 / dqkv: nothing; dproj: column
+// sums; dfc2: dGELU + column sums).  Everything else (stochastic depth's row scale, ReLU / Sigmoid heads, B k-strided ...) runs the generic form.
 namespace {
 template <bool TB, int SIDE, bool DYN, int EPI>
 void pers_launch1(dim3 grid, hipStream_t st, const GemmP& p) { hipLaunchKernelGGL((gemm256p_kernel<TB, SIDE, DYN, EPI>), grid, dim3(NT2), 0, st, p); }
 template <bool DYN>
 void pers_launch(bool tb, int side, int epi, dim3 grid, hipStream_t st, const GemmP& p) {
     if (!tb && side == 0) {
-        if (epi == EPI_BIAS) pers_launch1<false, 0, DYN, EPI_BIAS>(grid, st, p);
-        else if (epi == (DEVIAS_ACT_GELU | EPI_BIAS | EPI_AUX)) pers_launch1<false, 0, DYN, DEVIAS_ACT_GELU | EPI_BIAS | EPI_AUX>(grid, st, p);
+        if (epi == EPI_BIAS) pers_launch1<false, 0, DYN, EPI_BIAS>(grid, st, p);                                                                        // qkv
+        else if (epi == (DEVIAS_ACT_GELU | EPI_BIAS | EPI_AUX)) pers_launch1<false, 0, DYN, DEVIAS_ACT_GELU | EPI_BIAS | EPI_AUX>(grid, st, p);         // fc1
+        else if (epi == 0) pers_launch1<false, 0, DYN, 0>(grid, st, p);                                                                                 // dfc1, dqkv on a transposed weight copy
+        else if (epi == EPI_CS) pers_launch1<false, 0, DYN, EPI_CS>(grid, st, p);                                                                       // dproj
         else pers_launch1<false, 0, DYN, -1>(grid, st, p);
-    } else if (!tb) {
-        if (epi == EPI_BIAS) pers_launch1<false, 1, DYN, EPI_BIAS>(grid, st, p);
+    } else if (!tb && side == 1) {
+        if (epi == EPI_BIAS) pers_launch1<false, 1, DYN, EPI_BIAS>(grid, st, p);                                                                        // proj, fc2, patch embedding
         else pers_launch1<false, 1, DYN, -1>(grid, st, p);
-    } else if (side == 0) {
-        if (epi == 0) pers_launch1<true, 0, DYN, 0>(grid, st, p);
-        else if (epi == EPI_CS) pers_launch1<true, 0, DYN, EPI_CS>(grid, st, p);
-        else pers_launch1<true, 0, DYN, -1>(grid, st, p);
-    } else {
-        if (epi == (DEVIAS_ACT_DGELU | EPI_CS)) pers_launch1<true, 2, DYN, DEVIAS_ACT_DGELU | EPI_CS>(grid, st, p);
-        else pers_launch1<true, 2, DYN, -1>(grid, st, p);
-    }
+    } else if (!tb) {
+        if (epi == (DEVIAS_ACT_DGELU | EPI_CS)) pers_launch1<false, 2, DYN, DEVIAS_ACT_DGELU | EPI_CS>(grid, st, p);                                     // dfc2 on a transposed weight copy
+        else pers_launch1<false, 2, DYN, -1>(grid, st, p);
+    } else if (side == 0) pers_launch1<true, 0, DYN, -1>(grid, st, p);       // B k-strided (a dgrad without a transposed weight copy: hosts of ABI <= 165, the per-kernel path): generic epilogues
+    else pers_launch1<true, 2, DYN, -1>(grid, st, p);
 }
 }  // namespace
 
@@ -2245,6 +2266,7 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
                        "devias_gemm: batched launches support bias / activation epilogues only (no split-K, residual, aux, colsum)");
     p.debug = kn.debug;
     p.tail_split = kn.tail_split;
+    p.aux_nt = kn.aux_nt;
     p.epi_swap = kn.epi_swap;
     p.tq = nullptr; p.tq_clear = nullptr; p.tq_nwhole[0] = p.tq_nwhole[1] = p.tq_items[0] = p.tq_items[1] = 0;
     // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
@@ -2325,7 +2347,7 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
         // dproj 81 -> 72; the long-K dgrad shapes unchanged (dfc1 252, dqkv 192)
         const bool dact = a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU;
         const int side = a->res ? 1 : (dact ? 2 : 0);      // rows the epilogue reads: a compile-time fact of the persistent kernels
-        const bool pers_ok = !ta && split == 1 && !p.c_f32 && p.epi_swap && gp >= 8 && !(a->res && dact) && (!tb ? side != 2 : side != 1) &&
+        const bool pers_ok = !ta && split == 1 && !p.c_f32 && p.epi_swap && gp >= 8 && !(a->res && dact) && !(tb && side == 1) &&
                              (!a->row_scale || p.rows_per_scale >= 128) && !(side == 2 && a->bias) && !(side == 1 && a->colsum) &&
                              !(side != 0 && a->aux_out);
 #define PERS_LAUNCH(KERNEL, ...) do { \
@@ -2342,7 +2364,7 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
         // BASELINE configuration once the tail split existed: ViT-L -0.2 ms of 153.7 (noise), 6400 tokens +1.5 ms, ViT-B +-0.0; git history has it.)
         const int w4_form = (tb ? 2 : 0) + (side != 0 ? 1 : 0);
         const int w4_mask = kn.w4 >= 0 ? kn.w4 : ((a->K >= 1024 && a->N >= 1024) ? 15 : 0);
-        const bool w4_ok = kn.persistent && !dyn && ((w4_mask >> w4_form) & 1) && pers_ok && nt > gp && a->K >= 128 &&
+        const bool w4_ok = kn.persistent && !dyn && ((w4_mask >> w4_form) & 1) && pers_ok && !(!tb && side == 2) && nt > gp && a->K >= 128 &&      // (B k-contiguous + saved pre-activation -- dfc2 on a transposed weight copy -- has no four-wave form)
                            (a->act == DEVIAS_ACT_NONE || a->act == DEVIAS_ACT_GELU || a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU);
         if (w4_ok) {
             dim3 grid(gp), block(NTW);
@@ -2461,6 +2483,22 @@ extern "C" int devias_debug_gemm_timer_read(int32_t* count, float* total_ms) {
         sum += ms;
     }
     *count = t.n; *total_ms = sum;
+    return DEVIAS_OK;
+}
+
+extern "C" int devias_debug_gemm_timer_read_each(int32_t* count, float* each_ms, int32_t cap) {
+    DEVIAS_REQUIRE(count && each_ms && cap > 0, "devias_debug_gemm_timer_read_each: null output");
+    GemmTimer& t = gemm_timer();
+    std::lock_guard<std::mutex> lock(t.mu);
+    for (int i = 0; i < t.n && i < cap; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.e1[i]) != hipSuccess || hipEventElapsedTime(&ms, t.e0[i], t.e1[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            return devias_set_error(DEVIAS_ELAUNCH, "devias_debug_gemm_timer_read_each: event %d not readable", i);
+        }
+        each_ms[i] = ms;
+    }
+    *count = t.n < cap ? t.n : cap;
     return DEVIAS_OK;
 }
 

@@ -277,8 +277,11 @@ int ln_fwd_dispatch(const T* x, const float* g, const float* b, T* y, float* mea
 }
 // workgroups and rows per workgroup of the backward kernel: up to LNB_ONE_WG_ROWS rows one workgroup (which then writes the parameter gradients itself),
 // otherwise the rows spread evenly over at most one workgroup per CU
+// (the CU count is the policy's: device CUs minus the option gemm_reserve_cus -- a workgroup of this kernel fills a CU, so with K CUs held by a concurrent kernel (RCCL during
+// backward) K workgroups of a one-per-CU grid would run as a second round: twice the launch's time, +1.3 ms per step with 16 held, profiles/r6_cu_hog.txt)
 void ln_bwd_shape(int M, int& nwg, int& rows) {
-    nwg = M <= LNB_ONE_WG_ROWS ? 1 : (cdiv(M, LNB_MIN_ROWS) < ln_ncu() * LNB_WGS_PER_CU ? cdiv(M, LNB_MIN_ROWS) : ln_ncu() * LNB_WGS_PER_CU);
+    const int cus = devias_policy_gemm_cus() * LNB_WGS_PER_CU;
+    nwg = M <= LNB_ONE_WG_ROWS ? 1 : (cdiv(M, LNB_MIN_ROWS) < cus ? cdiv(M, LNB_MIN_ROWS) : cus);
     rows = cdiv(M, nwg);
     nwg = cdiv(M, rows);
 }

@@ -203,6 +203,9 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
     const BlockSave s(a->save, B, N, D, H, hid, a->dtype);
     const BlockScratch t(scratch, B, N, D, H, hid, a->dtype);
     devias_range r("encoder_block_bwd");
+    // transposed weight copies for the dgrad GEMMs: bf16 only (the fp32 kernels stage through registers: no gain), option gemm_wt
+    const bool wt = a->dtype == DEVIAS_BF16 && devias_policy_gemm_wt() != 0;
+    const void *WqkvT = wt ? a->WqkvT : nullptr, *WpT = wt ? a->WpT : nullptr, *W1T = wt ? a->W1T : nullptr, *W2T = wt ? a->W2T : nullptr;
     // The second stages of this region's partial reductions (two LayerNorm parameter reduces, the column-sum finals of db1 / db2 / dbp / dq_bias / dv_bias:
     // 5-7 launches of 6-12 us) run as ONE launch at the end: each producer gets a private partial area in the scratch arena (Ctx with that `ws`).
     DeviasDeferList dl; dl.n = 0;
@@ -217,9 +220,11 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
         RUN(colsum(with_ws(t.p_b2), dx2, M, D, g->db2));                       // fc2 bias gradient (the caller had no ready-made column sums of dx2)
     }
     RUN(wgrad(c, g2, s.hact, g->dW2, M, D, hid));
-    { Epi e; e.act = DEVIAS_ACT_DGELU; e.aux_in = s.hpre; e.colsum = g->db1; RUN(gemm(with_ws(t.p_db1), g2, a->W2, t.big, M, hid, D, D, hid, 0, 1, e)); }   // (g2 W2) * gelu'(pre); db1 = colsum
+    // (the four dgrad GEMMs: on the caller's transposed weight copies where it keeps them -- both operands k-contiguous -- else the weight read k-strided; same bits)
+    { Epi e; e.act = DEVIAS_ACT_DGELU; e.aux_in = s.hpre; e.colsum = g->db1;                                                                                   // (g2 W2) * gelu'(pre); db1 = colsum
+      if (W2T) RUN(gemm(with_ws(t.p_db1), g2, W2T, t.big, M, hid, D, D, D, 0, 0, e)); else RUN(gemm(with_ws(t.p_db1), g2, a->W2, t.big, M, hid, D, D, hid, 0, 1, e)); }
     RUN(wgrad(c, t.big, s.u2, g->dW1, M, hid, D));
-    { Epi e; RUN(gemm(c, t.big, a->W1, t.small, M, D, hid, hid, D, 0, 1, e)); }                                                                 // du2
+    { Epi e; if (W1T) RUN(gemm(c, t.big, W1T, t.small, M, D, hid, hid, hid, 0, 0, e)); else RUN(gemm(c, t.big, a->W1, t.small, M, D, hid, hid, D, 0, 1, e)); }   // du2
     // + residual gradient; dbp = colsum(dx1) -- unless stochastic depth rescales dx1 first: then the column sum of the rescaled copy below is dbp (two deferred
     // jobs must not share a destination: they run side by side)
     RUN(ln_bwd(with_ws(t.p_ln2), t.small, s.x1, a->n2w, s.mean2, s.rstd2, dx2, t.dx1, g->dn2w, g->dn2b, 0.f, a->ds1 ? nullptr : g->dbp, M, D));
@@ -232,7 +237,9 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
     RUN(wgrad(c, g1, s.o, g->dWp, M, D, D));
     // v_bias gradient: the column sum of d_o where the attention backward says so (softmax rows sum to one: sum_keys dV = sum_queries dO), from this GEMM's epilogue
     const bool dv_from_do = g->dbq && g->dbv && devias_mhsa_bwd_bias_dv_from_do(a->dtype, 1.0f);
-    { Epi e; if (dv_from_do) e.colsum = g->dbv; RUN(gemm(dv_from_do ? with_ws(t.p_v) : c, g1, a->Wp, t.small, M, D, D, D, D, 0, 1, e)); }   // (p_v: the attention backward does not use it then)                                     // d_o
+    { Epi e; if (dv_from_do) e.colsum = g->dbv;                                                                                               // d_o (p_v: the attention backward does not use it then)
+      const Ctx k = dv_from_do ? with_ws(t.p_v) : c;
+      if (WpT) RUN(gemm(k, g1, WpT, t.small, M, D, D, D, D, 0, 0, e)); else RUN(gemm(k, g1, a->Wp, t.small, M, D, D, D, D, 0, 1, e)); }
     if (g->dbq && g->dbv)                                                   // dqkv + the q_bias / v_bias gradients (each to its own destination) from the same two kernels
         RUN(devias_mhsa_bwd_bias(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, 1.0f, 0, g->dbq, dv_from_do ? nullptr : g->dbv, t.p_q, t.p_v, stream));
     else
@@ -242,7 +249,7 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
     } else {
         RUN(colsum(with_ws(t.p_q), t.big, M, 3 * D, g->dbqkv));
     }
-    { Epi e; RUN(gemm(c, t.big, a->Wqkv, t.small, M, D, 3 * D, 3 * D, D, 0, 1, e)); }                                                           // du
+    { Epi e; if (WqkvT) RUN(gemm(c, t.big, WqkvT, t.small, M, D, 3 * D, 3 * D, 3 * D, 0, 0, e)); else RUN(gemm(c, t.big, a->Wqkv, t.small, M, D, 3 * D, 3 * D, D, 0, 1, e)); }   // du
     RUN(ln_bwd(with_ws(t.p_ln1), t.small, x, a->n1w, s.mean1, s.rstd1, t.dx1, dx, g->dn1w, g->dn1b, 0.f, g->dx_colsum, M, D));
     RUN(devias_flush_deferred(&dl, (hipStream_t)stream));
     return DEVIAS_OK;

@@ -108,7 +108,9 @@ class _WeightCache:
         self._c = _WeakIdDict()                      # Parameter -> (stamp, compute-dtype copy)
         self._cat = _WeakIdDict()                    # first Parameter of a concatenation -> {ids of the others: (stamps, weakrefs, copy)}
         self._qkvb = _WeakIdDict()                   # q_bias Parameter -> (stamps, weakref to v_bias, fp32 q_bias | 0 | v_bias)
+        self._t = _WeakIdDict()                      # Parameter -> (stamp, transposed compute-dtype copy)
         self.casts = 0                               # number of casts performed (tests)
+        self.transposes = 0
 
     @staticmethod
     def _stamp(p: torch.Tensor):
@@ -127,6 +129,19 @@ class _WeightCache:
         w = ops.cast(d.contiguous(), dtype)
         self.casts += 1
         self._c[p] = (stamp, w)
+        return w
+
+    def get_t(self, p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """the TRANSPOSE of a 2-D weight in the compute dtype ([in, out] for an nn.Linear weight [out, in]), cached like get(): what the encoder block's dgrad GEMMs
+        read (devias_block_args.W*T) -- dY W with W transposed is a product of two k-contiguous operands, the fast layout of the GEMM kernels (round 6: 9-17 % less
+        K-loop time than reading W through transposing LDS loads; same bits).  One extra copy per weight and weight update; bf16 mode only (callers)."""
+        stamp = self._stamp(p)
+        hit = self._t.get(p)
+        if hit is not None and hit[0] == stamp and hit[1].dtype == dtype:
+            return hit[1]
+        w = self.get(p, dtype).t().contiguous()
+        self.transposes += 1
+        self._t[p] = (stamp, w)
         return w
 
     def get_cat(self, ps, dtype: torch.dtype) -> torch.Tensor:
@@ -848,6 +863,11 @@ class EncoderBlockRegionFn(Function):
         a = _L.BlockArgs()
         a.B, a.N, a.D, a.H, a.hidden, a.dtype, a.eps = B, N, D, H, hid, dt, eps
         (a.n1w, a.n1b, a.n2w, a.n2b, a.Wqkv, a.Wp, a.W1, a.W2, a.qkv_bias, a.pb, a.b1, a.b2) = [t.data_ptr() for t in keep]
+        if cdt != torch.float32 and any(ctx.needs_input_grad):
+            # transposed weight copies for the four dgrad GEMMs of the backward (bf16 mode: the fp32 parity kernels stage through registers and do not care)
+            wt = [_WCACHE.get_t(w, cdt) for w in (qkvw, pw, f1w, f2w)]
+            keep = keep + wt
+            (a.WqkvT, a.WpT, a.W1T, a.W2T) = [t.data_ptr() for t in wt]
         a.ds1 = ds1.data_ptr() if ds1 is not None else None
         a.ds2 = ds2.data_ptr() if ds2 is not None else None
         a.save, a.ws, a.ws_bytes = save.data_ptr(), ws.data_ptr(), ws.numel() * 4

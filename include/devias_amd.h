@@ -67,7 +67,12 @@ const char* devias_last_error(void);
 #define DEVIAS_CNT_GEMM256D 14       /* 256x256 persistent kernel pulling its tiles from the per-XCD dynamic queues (option gemm_dynamic, on by default);
                                         every such launch also counts as DEVIAS_CNT_GEMM256P */
 #define DEVIAS_CNT_MHSA_BWD_FUSED 10 /* (retired with ABI 150: always 0) */
-#define DEVIAS_CNT_MAX 16
+/* which dK / dV kernel served a bf16 attention backward (ABI 165; each devias_mhsa_bwd* call also counts DEVIAS_CNT_MHSA_BWD_BF16) */
+#define DEVIAS_CNT_DKDV1W 15         /* one wave per SIMD (csrc/attn_bwd1w.hip), one workgroup per 256-key block: the default of the measured step */
+#define DEVIAS_CNT_DKDV1W_PERS 16    /* the same kernel as one persistent workgroup per CU (option attn_dkdv = 2) */
+#define DEVIAS_CNT_DKDV1W_REST 17    /* its second launch for the N mod 256 last keys of every head (32 keys at N = 1568) */
+#define DEVIAS_CNT_DKDV2W 18         /* the two-waves-per-SIMD kernel of rounds 2-4 (attention dropout, ws = NULL, option attn_dkdv = 0) */
+#define DEVIAS_CNT_MAX 24
 int64_t devias_counter(int32_t id);          /* -1 for an unknown id */
 void devias_counters_reset(void);
 /* Process-wide integer options (initialised once from the DEVIAS_* environment variables of the same meaning): "gemm_epi",
@@ -127,6 +132,9 @@ int64_t devias_debug_mfma_probe_flops(int32_t n_workgroups, int32_t iters);
  * launches behind it).  The dims are devias_gemm_args' M, N, K. */
 int devias_debug_gemm_timer_arm(int32_t M, int32_t N, int32_t K, int32_t trans_a, int32_t trans_b);
 int devias_debug_gemm_timer_read(int32_t* count, float* total_ms);
+/* the same launches one by one, in launch order (ABI 166): each_ms[0 .. min(count, cap) - 1].  bench.py's `roofline.gemm_shapes` arms a signature for ONE step: where a forward
+ * GEMM and a dgrad GEMM on a transposed weight copy share (M, N, K, layouts) -- fc1 and dfc2, proj and dproj, fc2 and dfc1 -- the step's first launches are the forward's. */
+int devias_debug_gemm_timer_read_each(int32_t* count, float* each_ms, int32_t cap);
 /* Diagnostic builds (-DDKDV_STAMP on csrc/attn_bwd1w.hip) only, DEVIAS_EUNSUPPORTED otherwise: shader-clock stamps of the one-wave-per-SIMD dK / dV kernel's last
  * launch -- per workgroup (the first n <= 4096) eight stamps (csrc/attn_bwd1w.hip: entry, loop entry, loop exit, exit, and four points of prologue / epilogue) -- copied
  * to host memory out[n][8]. */
@@ -449,6 +457,12 @@ typedef struct {
     void* save;                          /* devias_encoder_block_save_bytes() */
     float* ws; int64_t ws_bytes;         /* devias_encoder_block_workspace_bytes() */
     void* sk_ws; int64_t sk_ws_bytes;    /* ignored since ABI 160 (devias_gemm_args.sk_ws) */
+    /* ABI 166, optional (NULL: not used), backward only: TRANSPOSED copies of the four weights in T -- WqkvT [D,3D], WpT [D,D], W1T [D,hidden], W2T [hidden,D] -- that the
+     * caller keeps beside the nn.Linear-layout copies (made once per weight update, like those).  With them the four dgrad GEMMs of a block (dY W: the reduction runs over
+     * the weight's ROWS) read both operands k-contiguous instead of reading W through transposing LDS loads: the same products in the same order -- bitwise the same dx --
+     * with 9-17 % less K-loop time (profiles/r6_nt_vs_tb.txt).  A caller compiled against ABI <= 165 passes a shorter struct: it must zero-extend it or keep calling an
+     * ABI <= 165 library (devias_version() tells). */
+    const void *WqkvT, *WpT, *W1T, *W2T;
 } devias_block_args;
 typedef struct {
     float *dn1w, *dn1b, *dWqkv, *dbqkv /* [3D]: dq_bias | (k: unused) | dv_bias */, *dWp, *dbp, *dn2w, *dn2b, *dW1, *db1, *dW2, *db2;

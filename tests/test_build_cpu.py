@@ -12,17 +12,25 @@ import pytest
 from devias_amd import build
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ISA = {}
+
+
+def _isa(stem, extra=()):
+    """the gfx950 ISA of one translation unit under the production flags (+ extra), compiled once per session: gemm.hip takes over a minute"""
+    key = (stem, tuple(extra))
+    if key not in _ISA:
+        src = os.path.join(ROOT, "devias_amd", "csrc", stem + ".hip")
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, stem + ".s")
+            r = subprocess.run([build.HIPCC] + list(build._flags(stem + ".hip")) + list(extra) + ["--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            _ISA[key] = open(out).read()
+    return _ISA[key]
 
 
 @pytest.mark.timeout(900)
 def test_four_wave_gemm_kernels_own_their_accumulators():
-    src = os.path.join(ROOT, "devias_amd", "csrc", "gemm.hip")
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "gemm.s")
-        cmd = [build.HIPCC] + list(build.FLAGS) + ["--cuda-device-only", "-S", src, "-o", out]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-2000:]
-        lines = open(out).read().split("\n")
+    lines = _isa("gemm").split("\n")
     found = 0
     for i, l in enumerate(lines):
         m = re.match(r"^(_ZN\S*gemm256w_kernel\S*):", l)
@@ -52,17 +60,35 @@ def test_four_wave_gemm_kernels_own_their_accumulators():
     assert found == 4          # <B k-contiguous | k-strided> x <rows the epilogue reads>
 
 
+@pytest.mark.timeout(900)
+def test_eight_wave_persistent_gemm_kernels_do_not_spill():
+    """gemm256p_kernel sits at 185-245 of the 256 registers two waves per SIMD allow, and a scratch reload costs more than its instructions there: its s_waitcnt vmcnt(0)
+    drains the tile's whole store burst, which the kernel otherwise leaves in flight under the next tile's K loop.  Round 6 found how close that is: the first
+    specialised epilogues with column sums (EPI_CS) spilled 52-132 bytes -- with no branch left between the sixteen pieces the compiler sank all 128 column-sum adds
+    behind the last piece and kept every piece alive for them.  Every instantiation -- <B layout, side rows, static / dynamic, generic / specialised epilogue> --
+    must therefore have no scratch, exactly one K-tile of MFMAs, and every specialisation the host dispatches to must exist."""
+    text = _isa("gemm")
+    sizes = dict(re.findall(r"\.set (\S*gemm256p_kernel\S*)\.private_seg_size, (\d+)", text))
+    assert len(sizes) == 22, sorted(sizes)       # 2 (dynamic) x [ (F,0): generic, bias, bias+GELU+aux, none, colsum | (F,1): generic, bias | (F,2): generic, dGELU+colsum | (T,0): generic | (T,2): generic ]
+    assert all(int(v) == 0 for v in sizes.values()), {k[-34:]: v for k, v in sizes.items() if int(v)}
+    lines = text.split("\n")
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\S*gemm256p_kernel\S*):", l)
+        if not m:
+            continue
+        j = i
+        while not lines[j].startswith(".Lfunc_end"):        # (not the first s_endpgm: a workgroup that finds every queue empty leaves early)
+            j += 1
+        body = [b.split(";")[0] for b in lines[i:j + 1]]
+        assert sum("scratch_" in b for b in body) == 0, m.group(1)
+        assert sum("v_mfma" in b for b in body) == 64, m.group(1)
+
+
 @pytest.mark.timeout(600)
 def test_layernorm_kernels_do_not_spill():
     """the backward LayerNorm kernel's waves per workgroup are chosen per row width and element type so that the row fits the register budget of that
     occupancy (devias_amd/csrc/layernorm.hip: ln_bwd_dispatch): no instantiation may use scratch"""
-    src = os.path.join(ROOT, "devias_amd", "csrc", "layernorm.hip")
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "ln.s")
-        cmd = [build.HIPCC] + list(build.FLAGS) + ["--cuda-device-only", "-S", src, "-o", out]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-2000:]
-        text = open(out).read()
+    text = _isa("layernorm")
     sizes = re.findall(r"\.set (\S*ln_(?:fwd|bwd)_kernel\S*)\.private_seg_size, (\d+)", text)
     assert len(sizes) >= 16, len(sizes)
     assert all(int(v) == 0 for _, v in sizes), [(n[-40:], v) for n, v in sizes if int(v)]
@@ -77,15 +103,10 @@ def test_inline_asm_vmem_never_reads_an_sgpr_the_valu_just_wrote():
     come out of a spill lane went to an address with a stale high half (memory fault).  This audit walks the ISA of gemm.hip -- release and
     -DDEVIAS_GEMM_DEBUG builds -- and requires, for every inline-asm vector-memory instruction with an SGPR base, that none of the 5 issue slots before it
     (s_nop N counts N + 1) holds a VALU write of that SGPR."""
-    src = os.path.join(ROOT, "devias_amd", "csrc", "gemm.hip")
     vmem = re.compile(r"^\s*(global_(?:store|load|atomic)\w*|buffer_\w+)\s+(.*)$")
     valu_sgpr_write = re.compile(r"^\s*(v_readlane_b32|v_readfirstlane_b32)\s+s(\d+)\b")
     for extra in ([], ["-DDEVIAS_GEMM_DEBUG"]):
-        with tempfile.TemporaryDirectory() as td:
-            out = os.path.join(td, "gemm.s")
-            r = subprocess.run([build.HIPCC] + list(build.FLAGS) + extra + ["--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
-            assert r.returncode == 0, r.stderr[-2000:]
-            lines = [l.split(";")[0].rstrip() if not l.lstrip().startswith(";;#") else l.strip() for l in open(out).read().split("\n")]
+        lines = [l.split(";")[0].rstrip() if not l.lstrip().startswith(";;#") else l.strip() for l in _isa("gemm", extra).split("\n")]
         inasm, checked, bad = False, 0, []
         code = []                                      # (text, in_asm) of real instructions, in order
         for l in lines:

@@ -536,9 +536,9 @@ def gemm_options():
 
 
 def _persistent_serves(tb, epi):
-    """the persistent kernels are compiled per kind of row the epilogue reads: none / residual for B k-contiguous (forward GEMMs),
-    none / saved pre-activation for B k-strided (dgrad GEMMs); anything else runs the one-tile-per-workgroup kernel"""
-    return epi in (("bias", "plain", "colsum", "gelu_aux", "dgelu_colsum") if tb else ("bias", "plain", "colsum", "gelu_aux", "res", "res_rowscale"))
+    """the persistent kernels are compiled per kind of row the epilogue reads: none / residual / saved pre-activation for B k-contiguous (forward GEMMs, and since
+    round 6 the dgrad GEMMs on transposed weight copies), none / saved pre-activation for B k-strided (dgrad GEMMs); anything else runs the one-tile-per-workgroup kernel"""
+    return epi in (("bias", "plain", "colsum", "gelu_aux", "dgelu_colsum") if tb else ("bias", "plain", "colsum", "gelu_aux", "dgelu_colsum", "res", "res_rowscale"))
 
 
 @pytest.mark.parametrize("tb", [False, True])
@@ -598,7 +598,8 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         want = (1, 0) if (serves and mode not in ("0", "0s")) else (0, 1)
         assert (cnt["gemm256p"], cnt["gemm256"]) == want, (mode, cnt)
         assert cnt["gemm256d"] == (1 if mode in ("p", "p1", "p0", "pg") and serves and K >= 128 else 0), (mode, cnt)   # (one K-tile per tile: the static list)
-        assert cnt["gemm256w"] == (1 if mode == "w" and serves and K >= 128 else 0), (mode, cnt)       # (one K-tile: the eight-wave kernel)
+        w4_serves = serves and not (not tb and epi == "dgelu_colsum")                                  # (B k-contiguous + saved pre-activation: the eight-wave kernel only)
+        assert cnt["gemm256w"] == (1 if mode == "w" and w4_serves and K >= 128 else 0), (mode, cnt)    # (one K-tile: the eight-wave kernel)
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
     c, aux, cs = outs["0"]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]

@@ -137,6 +137,8 @@ def test_bf16_full_size_step_properties():
     # M = 50176: the four forward and four dgrad GEMMs of a block run on the eight-wave persistent kernel (tail tiles split; the
     # four-wave kernel is an option); the four wgrads split K on the one-tile-per-workgroup kernel
     assert cnt["gemm256p"] >= 12 * 8 and cnt["gemm256w"] == 0 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_bwd_bf16"] == 12 and cnt["gemm128_f32"] == 0, cnt
+    # the dK / dV kernel the measured step ran: the one-wave-per-SIMD kernel, one workgroup per 256-key block + the launch for the 32 last keys of every head
+    assert (cnt["dkdv1w"], cnt["dkdv1w_rest"], cnt["dkdv1w_pers"], cnt["dkdv2w"]) == (12, 12, 0, 0), cnt
     sh1 = out1[2][0].detach().clone()
     out2, t2, g2 = step(model, x, y, tl, fg)
     assert torch.isfinite(t1).all() and all(torch.isfinite(g).all() for g in g1.values())

@@ -72,6 +72,13 @@ e1.record(); torch.cuda.synchronize()
 print(f"{which}: back-to-back launch time {e0.elapsed_time(e1) / 20 * 1e3:.1f} us;  workgroup entry spread {ent.max() - ent.min():.1f} us;  entry -> first K-tile multiplied: med {np.median(first_kt - ent):.2f} max {np.max(first_kt - ent):.2f} us;  "
       f"first entry -> last epilogue issued {last.max() - ent.min():.1f} us")
 print(f"{which}: N={N} K={K}  kernel span {span:.1f} us, tiles/WG max {int((code == 2).sum(1).max())}")
+def dist(name, v):
+    v = np.asarray(v)
+    if len(v): print(f"  {name}: n {len(v)}  mean {v.mean():.2f}  p10 {np.percentile(v, 10):.2f}  p50 {np.median(v):.2f}  p90 {np.percentile(v, 90):.2f}  p99 {np.percentile(v, 99):.2f}  max {v.max():.2f} us")
+dist("first K-iteration", first); dist(f"remaining {nk - 1} K-iterations", steady); dist("epilogue interval", ep)
+# per workgroup: first stamp -> last stamp, and how the launch's span divides into K loops / epilogues / the rest (ramp, waiting for the slowest workgroup)
+busy = np.array([t[b][(code[b] != 0) & (code[b] < 8)].max() - t[b][(code[b] != 0) & (code[b] < 8)].min() for b in range(256)])
+print(f"  per workgroup, first K-tile -> last stamp: mean {busy.mean():.1f}  min {busy.min():.1f}  max {busy.max():.1f} us;  sum over the launch: K loops {(np.sum(first) + np.sum(steady)) / 256:.1f} us per CU, epilogue intervals {np.sum(ep) / 256:.1f} us per CU")
 print(f"  first K-iteration of a tile (incl. wait for the previous tile's stores): med {np.median(first):.2f}  p90 {np.percentile(first, 90):.2f} us")
 print(f"  remaining {nk - 1} K-iterations: med {np.median(steady):.2f} us  -> {np.median(steady) / max(nk - 1, 1):.3f} us per iteration")
 print(f"  shader clock during the K loops: med {np.median(clk):.0f} MHz (p10 {np.percentile(clk, 10):.0f}, p90 {np.percentile(clk, 90):.0f})")
