@@ -12,7 +12,7 @@ last round, ramp).  With a second argument (the text written by tools/vendor_gem
 shape stand beside it: calibration only, nothing in the product links it.
 
 usage: gemm_ledger.py <trace dir> [vendor file] [--json out.json] [--M rows]"""
-import csv, glob, json, statistics as st, sys
+import csv, glob, json, re, statistics as st, sys
 
 KT_US = 1.55          # one 256 x 256 x 64 K-tile on every CU (the eight-wave K loop, in-kernel stamps, DESIGN.md section 5 round 2)
 CUS = 256
@@ -46,18 +46,33 @@ def shapes(rows, M, D=768, depth=12):
     out = {}
     def put(name, m, n, k, kind, d):
         out[name] = dict(M=m, N=n, K=k, kind=kind, us=med(d), n=len(d))
-    f0 = seq(rows, "gemm256p_kernel<false, 0")
-    put("qkv fwd", M, 3 * D, D, "fwd", f0[0::2]); put("fc1 fwd +GELU +pre", M, 4 * D, D, "fwd", f0[1::2])
-    f1 = seq(rows, "gemm256p_kernel<false, 1")
-    # one patch-embed launch per step precedes the 2 x depth launches of the blocks
-    per = 2 * depth + 1
-    body = [x for i, x in enumerate(f1) if i % per != 0]
-    put("proj fwd +res", M, D, D, "fwd", body[0::2]); put("fc2 fwd +res", M, D, 4 * D, "fwd", body[1::2])
-    put("patch embed +pos", M, D, 1536, "fwd", f1[0::per])
-    b2 = seq(rows, "gemm256p_kernel<true, 2")
-    put("dfc2 dgrad +dGELU +colsum", M, 4 * D, D, "dgrad", b2)
-    b0 = seq(rows, "gemm256p_kernel<true, 0")
-    put("dfc1 dgrad", M, D, 4 * D, "dgrad", b0[0::3]); put("dproj dgrad", M, D, D, "dgrad", b0[1::3]); put("dqkv dgrad", M, D, 3 * D, "dgrad", b0[2::3])
+    # the instantiation names carry the epilogue code (EPI of epilogue_swap): <B k-strided, side rows, dynamic queues, EPI>
+    def fam(tb, side, epi):
+        return [dur(r) for r in rows if re.search(r"gemm256p_kernel<%s, %d, (?:true|false), %s>" % (tb, side, epi), r["Kernel_Name"])]
+    if any("gemm256p_kernel<false, 2" in r["Kernel_Name"] for r in rows):
+        # round 6: dgrad on transposed weight copies -- every GEMM of the block is a B-k-contiguous launch with its own epilogue instantiation
+        put("qkv fwd", M, 3 * D, D, "fwd", fam("false", 0, 8)); put("fc1 fwd +GELU +pre", M, 4 * D, D, "fwd", fam("false", 0, 25))
+        f1 = fam("false", 1, 8)
+        per = 2 * depth + 1
+        body = [x for i, x in enumerate(f1) if i % per != 0]
+        put("proj fwd +res", M, D, D, "fwd", body[0::2]); put("fc2 fwd +res", M, D, 4 * D, "fwd", body[1::2]); put("patch embed +pos", M, D, 1536, "fwd", f1[0::per])
+        put("dfc2 dgrad +dGELU +colsum", M, 4 * D, D, "dgrad", fam("false", 2, 68))
+        b0 = fam("false", 0, 0)
+        put("dfc1 dgrad", M, D, 4 * D, "dgrad", b0[0::2]); put("dqkv dgrad", M, D, 3 * D, "dgrad", b0[1::2])
+        put("dproj dgrad", M, D, D, "dgrad", fam("false", 0, 64))
+    else:
+        f0 = seq(rows, "gemm256p_kernel<false, 0")
+        put("qkv fwd", M, 3 * D, D, "fwd", f0[0::2]); put("fc1 fwd +GELU +pre", M, 4 * D, D, "fwd", f0[1::2])
+        f1 = seq(rows, "gemm256p_kernel<false, 1")
+        # one patch-embed launch per step precedes the 2 x depth launches of the blocks
+        per = 2 * depth + 1
+        body = [x for i, x in enumerate(f1) if i % per != 0]
+        put("proj fwd +res", M, D, D, "fwd", body[0::2]); put("fc2 fwd +res", M, D, 4 * D, "fwd", body[1::2])
+        put("patch embed +pos", M, D, 1536, "fwd", f1[0::per])
+        b2 = seq(rows, "gemm256p_kernel<true, 2")
+        put("dfc2 dgrad +dGELU +colsum", M, 4 * D, D, "dgrad", b2)
+        b0 = seq(rows, "gemm256p_kernel<true, 0")
+        put("dfc1 dgrad", M, D, 4 * D, "dgrad", b0[0::3]); put("dproj dgrad", M, D, D, "dgrad", b0[1::3]); put("dqkv dgrad", M, D, 3 * D, "dgrad", b0[2::3])
     # weight gradients: per step 4 x depth one-round launches (wfc2, wfc1, wproj, wqkv per block, last block first), then the patch embedding's; the small ones
     # (agg block, head) run fewer than 200 workgroups
     w = [dur(r) for r in rows if "gemm256_kernel<true, true" in r["Kernel_Name"] and int(r["Grid_Size_X"]) >= 200 * 512]
