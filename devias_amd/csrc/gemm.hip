@@ -972,6 +972,46 @@ __global__ __launch_bounds__(NT2) void gemm256_kernel(GemmP p) {
 }
 
 
+// ---- pieces of a split tail tile (gemm256p_kernel) --------------------------------------------------------------------------------------------------------------
+// piece code: -1 = the whole tile; 0 / 1 = the two 128-row halves (round 3); 16 + i = third i (row tiles [0, 5) [5, 11) [11, 16) of the tile's sixteen 16-row tiles: at most
+// five per wave row, the middle third three in each); 32 + i = quarter i (four row tiles each).  A wave row (wm) owns row tiles [8 wm, 8 wm + 8): its share [il, ih).
+__device__ __forceinline__ void piece_rows(int code, int& lo, int& hi) {
+    if (code < 0) { lo = 0; hi = 16; }
+    else if (code < 16) { lo = 8 * code; hi = lo + 8; }
+    else if (code < 32) { const int i = code - 16; lo = i == 0 ? 0 : (i == 1 ? 5 : 11); hi = i == 0 ? 5 : (i == 1 ? 11 : 16); }
+    else { lo = 4 * (code - 32); hi = lo + 4; }
+}
+__device__ __forceinline__ void piece_wave_rows(int code, int wm, int& il, int& ih) {
+    int lo, hi;
+    piece_rows(code, lo, hi);
+    il = max(lo - 8 * wm, 0); ih = min(hi - 8 * wm, 8);
+    if (ih < il) ih = il;
+}
+// does a piece multiply any of the 32 A rows wave w stages (row tiles 2 w, 2 w + 1)?
+__device__ __forceinline__ bool piece_needs_wave_rows(int code, int w) {
+    int lo, hi;
+    piece_rows(code, lo, hi);
+    return 2 * w < hi && 2 * w + 2 > lo;
+}
+// one K-tile of a wave that multiplies only row tiles [IL, IH) of its eight into accumulators of their own (B k-contiguous; compiler-scheduled: a tail piece's K loop is
+// bound by the operand stream -- the whole B tile and a part of A for a part of the MFMAs).  A compile-time range: MFMAs under a run-time condition, anywhere in the
+// kernel, make the register allocator copy accumulators (256 registers + scratch in every instantiation when this was one routine with a run-time range).
+template <int IL, int IH>
+__device__ __forceinline__ void ktile_nt_rows(f32x4 (&acc)[IH - IL][4], const char* cur, int lane, int wm, int wn) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag2<false>(cur + 32768, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+        for (int i = IL; i < IH; ++i) {
+            const bf16x8 fa = read_frag2<false>(cur, wm * 128 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i - IL][j] = mfma16(fb[j], fa, acc[i - IL][j]);
+        }
+    }
+}
+
 // =====================================================================================================================
 // Persistent form of the 256 x 256 kernel (split_k == 1, A k-contiguous): one workgroup per CU walks a static list of tiles and the
 // K-tile stream of the 2-stage LDS-DMA ring runs ACROSS tile boundaries -- the first K-tile of the next tile is requested before the
@@ -1060,12 +1100,22 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
     // tile's K loop takes a bit more than half its time; every output element is computed by the same wave code as before (bitwise equal).
     const int rfull = cnt / stride, rem = cnt - rfull * stride;
     const bool split = p.tail_split != 0 && rfull >= 1 && rem > 0 && 2 * rem <= stride;
-    // STATIC list (DYN = false): this workgroup's k-th tile: (logical index, half: -1 = whole tile); false = none
+    // Round 6: thirds and quarters.  A half tile costs 0.7 of a tile, not 0.5 (its K loop streams the whole B tile and half of A for half the MFMAs, its epilogue is the
+    // active waves' full one: profiles/r6_gemm_pstamps.txt); with 3 rem <= stride (the 588-tile shapes: 9-10 tail tiles for 32 workgroups) the tail tiles go to THREE
+    // workgroups, with 4 rem <= stride (fc1: 6 tail tiles) to FOUR: less K-loop stream per piece and a third / a quarter of the epilogue.  Static lists, B k-contiguous,
+    // no column sums (option gemm_tail_split >= 3 / 4; 2 = halves only).
+    const int parts = (!split || DYN || TB || p.colsum_part != nullptr || p.tail_split < 3) ? 2 : min(min(p.tail_split, 4), stride / rem);
+    // STATIC list (DYN = false): this workgroup's k-th tile: (logical index, piece code: -1 = whole tile, see piece_rows); false = none
     auto tile_at = [&](int k, int& l, int& half) -> bool {
         half = -1;
         if (k < rfull) { l = li0 + k * stride; return true; }
         if (k > rfull) return false;
-        if (split) { if (li0 >= 2 * rem) return false; l = rfull * stride + (li0 >> 1); half = li0 & 1; return true; }
+        if (split) {
+            if (li0 >= parts * rem) return false;
+            l = rfull * stride + li0 / parts;
+            half = (parts == 2 ? 0 : (parts == 3 ? 16 : 32)) + li0 % parts;
+            return true;
+        }
         if (li0 >= rem) return false;
         l = rfull * stride + li0;
         return true;
@@ -1239,7 +1289,9 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             if (has_next) decode(ncode, m0n, n0n, halfn);
             seq = 2;
         }
-        bool act = half < 0 || wm == half;                    // (wave-uniform)
+        bool act = half < 0 || wm == half;                    // (wave-uniform; thirds / quarters never run in this loop: see `tail_piece` below)
+        bool tail_piece = false;
+        int gtail = 0;
         // ONE flat loop over the K-tile stream (ring stage = g & 1); the wait for K-tile g + 1 sits at the END of iteration g so that the loop has
         // no first-iteration special case (a peeled copy is where the compiler re-inserts full vmcnt drains)
         for (int g = 0, kt = 0;; ++g) {
@@ -1259,6 +1311,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             // does K-tile g + 1 need the A rows this wave stages?  Not if it belongs to a half tile of the OTHER wave row (nobody multiplies them; tail_split >= 2).
             // With the static lists a half tile is a workgroup's last item; with the queues it can have a successor, whose first K-tile is staged by ITS halves
             // (a wave that multiplies the current tile stages its rows in any case)
+            // (K-tile g + 1 belongs to the current item, or to the next one's first K-tile; a wave that multiplies all of its row tiles stages its rows in any case)
             const bool stage_a = p.tail_split < 2 || act || (DYN && !same && has_next && (halfn < 0 || wm == halfn));
             if constexpr (!TB) {
                 if (act) ktile_nt_pinned(acc, cur, nxt, A + (int64_t)am * p.lda + kn, p.lda, B + (int64_t)bn * p.ldb + kn, p.ldb, wave, lane_k, wm, wn);
@@ -1317,6 +1370,7 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             kt = 0;
             ++tk;
             m0 = m0n; n0 = n0n; half = halfn;
+            if (!DYN && !TB && half >= 16) { tail_piece = true; gtail = g + 1; break; }      // a third / a quarter of a tail tile: its own loop below (its first K-tile has landed)
             act = half < 0 || wm == half;
             if constexpr (!DYN) {
                 int ln = li;
@@ -1330,6 +1384,52 @@ __global__ __launch_bounds__(NT2) void gemm256p_kernel(GemmP p) {
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- a third / a quarter of a tail tile (static lists, B k-contiguous, no column sums: `parts` above) -------------------------------------------------------------
+        // The workgroup's last item, run by its own K loop on accumulators of its own, the wave's row tiles a compile-time range: the K-tile stream continues (the piece's
+        // first K-tile was requested under the previous tile's last K-tile and has landed), every wave stages B and the A rows some wave multiplies, a wave with row tiles
+        // multiplies them and runs the epilogue over just those; waves of one workgroup take different branches here with the same barriers in each.
+        if constexpr (!DYN && !TB && !(EPI >= 0 && (EPI & EPI_CS))) {
+            if (tail_piece) {
+                int il, ih;
+                piece_wave_rows(half, wm, il, ih);
+                auto run = [&](auto ilc, auto ihc) {
+                    constexpr int IL = decltype(ilc)::value, IH = decltype(ihc)::value, NR = IH > IL ? IH - IL : 1;
+                    f32x4 tacc[NR][4];
+#pragma unroll
+                    for (int i = 0; i < NR; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const bool stage_a = p.tail_split < 2 || piece_needs_wave_rows(half, wave);
+                    for (int kt = 0, g = gtail; kt < nk; ++kt, ++g) {
+                        __builtin_amdgcn_s_barrier();          // K-tile g has landed for every wave, and everyone is done reading stage (g + 1) & 1
+                        asm volatile("" ::: "memory");
+                        char* cur = smem + (g & 1) * STAGE2;
+                        char* nxt = smem + ((g + 1) & 1) * STAGE2;
+                        int lane_k = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                        asm volatile("" : "+v"(lane_k));
+                        if (kt + 1 < nk) {
+                            if (stage_a) glds_tile<false>(A, p.lda, m0, (kt + 1) * 64, nxt, wave, lane_k);
+                            glds_tile<false>(B, p.ldb, n0, (kt + 1) * 64, nxt + 32768, wave, lane_k);
+                        }
+                        if constexpr (IH > IL) ktile_nt_rows<IL, IH>(tacc, cur, lane_k, wm, wn);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA for K-tile g + 1 has landed
+                    }
+                    if constexpr (IH > IL) {
+                        int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                        asm volatile("" : "+v"(lane_e));
+                        epilogue_swap<NR, true, SIDE, EPI>(p, tacc, m0 + wm * 128 + IL * 16, n0 + wn * 64, 0, lane_e);
+                    }
+                };
+                using std::integral_constant;
+                if (il >= ih) run(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+                else if (il == 0 && ih == 5) run(integral_constant<int, 0>{}, integral_constant<int, 5>{});
+                else if (il == 5 && ih == 8) run(integral_constant<int, 5>{}, integral_constant<int, 8>{});
+                else if (il == 0 && ih == 3) run(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+                else if (il == 3 && ih == 8) run(integral_constant<int, 3>{}, integral_constant<int, 8>{});
+                else if (il == 0 && ih == 4) run(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+                else run(integral_constant<int, 4>{}, integral_constant<int, 8>{});
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing re-read must land before the LDS is released
     }
@@ -2088,7 +2188,7 @@ GemmKnobs& knobs() {
         x.dynamic = env_int("DEVIAS_GEMM_DYNAMIC", -1);
         x.concurrent = env_int("DEVIAS_GEMM_CONCURRENT", 0);
         x.w4 = env_int("DEVIAS_GEMM_W4", -1);
-        x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 2);
+        x.tail_split = env_int("DEVIAS_GEMM_TAIL_SPLIT", 3);
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
         x.epi_spec = env_int("DEVIAS_GEMM_EPI_SPEC", 1);
         x.wt = env_int("DEVIAS_GEMM_WT", 1);

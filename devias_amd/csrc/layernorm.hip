@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
                                                      T* __restrict__ dx, float* __restrict__ part, int M, int D, int rows,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum, float beta_acc) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [NW / 2 waves][3][NIT*256]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: the row bookkeeping lives in scalar registers)
     f32x4 g[NIT], dg[NIT], db[NIT], dc[NIT];     // dc: column sums of the stored dx
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -123,7 +123,16 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
         db[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         dc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int r0 = blockIdx.x * rows;
+    // Each workgroup owns a contiguous block of `rows` rows, wave w every NW-th of them.  (Round 6, measured and not adopted -- profiles/r6_layernorm_variants.txt: the rows dealt
+    // INTERLEAVED over the whole grid, wave w of workgroup b taking rows b NW + w + k (workgroups x NW) so that the chip sweeps each tensor as one sequential window like the
+    // forward kernel: 58.2-59.7 us against 57.7-57.8 -- it is not the access pattern either; -DDEVIAS_LNB_INTERLEAVED keeps the form.)
+#ifndef DEVIAS_LNB_INTERLEAVED
+    const int rinc = NW, rend = min(M, (int)blockIdx.x * rows + rows);
+    int row = blockIdx.x * rows + wave;
+#else
+    const int rinc = NW * gridDim.x, rend = M;
+    int row = blockIdx.x * NW + wave;
+#endif
     // software pipeline over rows: the (packed) loads of row r + PF * NW are issued before the reductions of row r
     typedef typename Raw4<T>::type raw4;
     raw4 nd[PF][NIT], nx[PF][NIT], nr[PF][NIT];
@@ -135,7 +144,11 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
             if (FULL || c < D) {
                 d_[it] = *reinterpret_cast<const raw4*>(dy + (int64_t)row * D + c);
                 x_[it] = *reinterpret_cast<const raw4*>(x + (int64_t)row * D + c);
+#if defined(DEVIAS_LNB_ABL) && (DEVIAS_LNB_ABL & 2)
+                r_[it] = x_[it];
+#else
                 if (dres) r_[it] = *reinterpret_cast<const raw4*>(dres + (int64_t)row * D + c);
+#endif
             }
         }
         mu_ = mean[row]; rs_ = rstd[row];
@@ -143,14 +156,13 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
         nmu[s] = 0.f; nrs[s] = 0.f;
-        if (wave + s * NW < rows && r0 + wave + s * NW < M) issue(r0 + wave + s * NW, nd[s], nx[s], nr[s], nmu[s], nrs[s]);
+        if (row + s * rinc < rend) issue(row + s * rinc, nd[s], nx[s], nr[s], nmu[s], nrs[s]);
     }
-    for (int rb = wave; rb < rows; rb += NW * PF) {
+    for (; row < rend; row += rinc * PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
-        const int rr = rb + s * NW;
-        const int row = r0 + rr;
-        if (rr >= rows || row >= M) break;
+        const int r = row + s * rinc;
+        if (r >= rend) break;
         // pass 1 straight out of the ring set (no copies of dy / x: their registers are free for the next request as soon as the pass has read them)
         const float mu = nmu[s], rs = nrs[s];
         f32x4 a[NIT], xh[NIT];
@@ -175,9 +187,13 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
                 }
             } else { a[it] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[it] = a[it]; }
         }
-        if (rr + PF * NW < rows && row + PF * NW < M) issue(row + PF * NW, nd[s], nx[s], nr[s], nmu[s], nrs[s]);
+        if (r + PF * rinc < rend) issue(r + PF * rinc, nd[s], nx[s], nr[s], nmu[s], nrs[s]);
+#if defined(DEVIAS_LNB_ABL) && (DEVIAS_LNB_ABL & 4)      // (diagnostic builds only, results wrong on purpose: tools/exp/ln_ab.py)
+        const float m1 = s1 / (float)D, m2 = s2 / (float)D;
+#else
         const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
-        T* dxr = dx + (int64_t)row * D;
+#endif
+        T* dxr = dx + (int64_t)r * D;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int c = (it * 64 + lane) * 4;
@@ -187,6 +203,9 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
                 for (int j = 0; j < 4; ++j) o[j] = rs * (a[it][j] - m1 - xh[it][j] * m2);
                 if (dres) o += raw_to_f32(cr[it]);
                 dc[it] += o;
+#if defined(DEVIAS_LNB_ABL) && (DEVIAS_LNB_ABL & 1)
+                if (o[0] == 12345.678f)
+#endif
                 store4(dxr + c, o);
             }
         }

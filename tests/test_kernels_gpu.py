@@ -530,7 +530,7 @@ def gemm_options():
     """restores the process-wide kernel-selection options a test changes"""
     o = ops()
     yield o
-    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_w4", -1), ("gemm_tail_split", 2), ("gemm_smallm", 1),
+    for k, v in (("gemm_persistent", 1), ("gemm_epi", 1), ("gemm256", 1), ("gemm_ss", -1), ("gemm_w4", -1), ("gemm_tail_split", 3), ("gemm_smallm", 1),
                  ("gemm_dynamic", -1), ("gemm_concurrent", 0), ("gemm_epi_spec", 1)):
         o.set_option(k, v)
 
@@ -579,10 +579,10 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
     outs = {}
     serves = _persistent_serves(tb, epi)
     # persistent (eight waves with the tail split in both forms / without it, four waves); one tile per workgroup with the register-transposed / the LDS-staged epilogue
-    for mode in ("p", "p1", "p0", "ps", "ps0", "pg", "psg", "w", "0", "0s"):
-        o.set_option("gemm_persistent", 1 if mode in ("p", "p1", "p0", "ps", "ps0", "pg", "psg", "w") else 0)
-        o.set_option("gemm_tail_split", {"p0": 0, "ps0": 0, "p1": 1}.get(mode, 2))
-        o.set_option("gemm_dynamic", 0 if mode in ("ps", "ps0", "psg", "w") else 1)          # (the four-wave kernel walks static lists: the queues take precedence)
+    for mode in ("p", "p1", "p0", "ps", "ps0", "ps3", "ps4", "pg", "psg", "w", "0", "0s"):
+        o.set_option("gemm_persistent", 1 if mode in ("p", "p1", "p0", "ps", "ps0", "ps3", "ps4", "pg", "psg", "w") else 0)
+        o.set_option("gemm_tail_split", {"p0": 0, "ps0": 0, "p1": 1, "ps3": 3, "ps4": 4, "psg": 4}.get(mode, 2))      # (3 / 4: tail tiles as thirds / quarters where the round allows -- static lists, B k-contiguous, no column sums)
+        o.set_option("gemm_dynamic", 0 if mode in ("ps", "ps0", "ps3", "ps4", "psg", "w") else 1)          # (the four-wave kernel walks static lists: the queues take precedence)
         o.set_option("gemm_epi_spec", 0 if mode in ("pg", "psg") else 1)
         o.set_option("gemm_w4", 15 if mode == "w" else 0)
         o.set_option("gemm_epi", 0 if mode == "0s" else 1)
@@ -603,7 +603,7 @@ def test_gemm_persistent_kernels(tb, epi, M, N, K, gemm_options):
         outs[mode] = (c, kw2.get("aux_out"), kw2.get("colsum"))
     c, aux, cs = outs["0"]
     assert rel(c.float(), ref) < TOL[torch.bfloat16]
-    others = ("p", "p1", "p0", "ps", "ps0", "pg", "psg", "w", "0s")
+    others = ("p", "p1", "p0", "ps", "ps0", "ps3", "ps4", "pg", "psg", "w", "0s")
     for mode in others:
         assert torch.equal(c, outs[mode][0]), mode
     if aux is not None:
