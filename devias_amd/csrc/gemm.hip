@@ -37,7 +37,8 @@ struct GemmP {
                           // 4 = no LDS-DMA after tile 0, 8 = s_memrealtime stamps into ws, 64 = epilogue without its C stores,
                           // 128 = without its pre-activation stores, 256 = without the GELU / dGELU polynomial, 1024 = the fc1 epilogue saves GELU'(pre) in place of pre
                           // (a second polynomial there), 2048 = the dGELU epilogue multiplies by the saved value (with 1024: the "saved derivative" form, measured in DESIGN.md section 5 round 5)
-    int aux_nt;           // persistent kernels: the saved pre-activation (aux_out) is stored with the non-temporal hint (option gemm_aux_nt)
+    int aux_nt;           // persistent kernels: the saved pre-activation (aux_out) is stored with the non-temporal hint (option gemm_aux_nt, bit 0)
+    int c_nt;             // persistent kernels: so is the output C (option gemm_aux_nt, bits 2 / 3: the host decides per launch)
     int tail_split;       // gemm256p_kernel: split the tiles of the last partial round between two workgroups (128-row halves)
     int64_t sA, sB, sC;   // batched launches (128x128 kernel, blockIdx.z = batch index): element strides between consecutive problems
     // dynamic tile queue of gemm256p_kernel<.., true>: this launch's queue slot (8 per-XCD heads, one per 128-byte line, + the line of claim masks; all zero
@@ -434,7 +435,7 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                         }
                     }
                     if constexpr (DEFER) {
-                        if (p.aux_nt) store16_asm_nt(aux_out + (int64_t)(mrow0 + i * 16) * p.ld_aux + ncol0 + 32 * pr, vo_x, *reinterpret_cast<const u32x4*>(&pre));
+                        if (p.aux_nt & 1) store16_asm_nt(aux_out + (int64_t)(mrow0 + i * 16) * p.ld_aux + ncol0 + 32 * pr, vo_x, *reinterpret_cast<const u32x4*>(&pre));
                         else store16_asm(aux_out + (int64_t)(mrow0 + i * 16) * p.ld_aux + ncol0 + 32 * pr, vo_x, *reinterpret_cast<const u32x4*>(&pre));
                     }
                     else if (!GDBG(128) || v[0] == 12345.678f) *reinterpret_cast<bf16x8*>(aux_out + (int64_t)m * p.ld_aux + ncol) = pre;
@@ -481,7 +482,10 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
                 *reinterpret_cast<f32x4*>(C + 4) = o1;
             } else {
                 bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-                if constexpr (DEFER) store16_asm(reinterpret_cast<const bf16*>(p.C) + (int64_t)(mrow0 + i * 16) * p.ldc + ncol0 + 32 * pr, vo_c, *reinterpret_cast<const u32x4*>(&o));
+                if constexpr (DEFER) {
+                    if (p.c_nt) store16_asm_nt(reinterpret_cast<const bf16*>(p.C) + (int64_t)(mrow0 + i * 16) * p.ldc + ncol0 + 32 * pr, vo_c, *reinterpret_cast<const u32x4*>(&o));
+                    else store16_asm(reinterpret_cast<const bf16*>(p.C) + (int64_t)(mrow0 + i * 16) * p.ldc + ncol0 + 32 * pr, vo_c, *reinterpret_cast<const u32x4*>(&o));
+                }
                 else if (!GDBG(64) || v[0] == 12345.678f)
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + ncol) = o;
             }
@@ -2154,7 +2158,7 @@ struct GemmKnobs {
     int debug;         // "gemm_debug"      DEVIAS_GEMM_DEBUG    ablation bits; only honoured by a -DDEVIAS_GEMM_DEBUG build
     int epi_spec;      // "gemm_epi_spec"   DEVIAS_GEMM_EPI_SPEC 1 (default): the eight-wave persistent kernel runs the instantiation whose epilogue switches are compile-time facts where one exists (same bits); 0: always the generic form (A/B aid)
     int wt;            // "gemm_wt"         DEVIAS_GEMM_WT       1 (default): the encoder block's backward runs its dgrad GEMMs on the caller's transposed weight copies (devias_block_args.W*T) where given; 0: reads the weights k-strided (A/B aid; same bits)
-    int aux_nt;        // "gemm_aux_nt"     DEVIAS_GEMM_AUX_NT   1 (default; -0.17 ms per step, in-process A/B): the persistent kernels store the saved pre-activation of a GELU epilogue non-temporally -- nobody reads it before the backward
+    int aux_nt;        // "gemm_aux_nt"     DEVIAS_GEMM_AUX_NT   5 (default): bit 0: the persistent kernels store the saved pre-activation of a GELU epilogue non-temporally -- nobody reads it before the backward --, bit 2: that launch's first output too (fc1; together -0.4 ... -0.5 ms per step, in-process A/B)
     int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K), a workgroup per 16-row tile where there are few column groups; 2: one workgroup per column group always (A/B aid)
     int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups (1), whose idle waves
                        //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
@@ -2192,7 +2196,7 @@ GemmKnobs& knobs() {
         x.smallm = env_int("DEVIAS_GEMM_SMALLM", 1);
         x.epi_spec = env_int("DEVIAS_GEMM_EPI_SPEC", 1);
         x.wt = env_int("DEVIAS_GEMM_WT", 1);
-        x.aux_nt = env_int("DEVIAS_GEMM_AUX_NT", 1);
+        x.aux_nt = env_int("DEVIAS_GEMM_AUX_NT", 5);
         x.ncu = 0;                                        // (unused: the CU count is the current device's at every call, devias_device_cus())
         return x;
     }();
@@ -2367,6 +2371,10 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
     p.debug = kn.debug;
     p.tail_split = kn.tail_split;
     p.aux_nt = kn.aux_nt;
+    // C non-temporal too (bit 2) for the GELU launch with a second output: fc1 writes 2 x 308 MB per launch at B = 32, more than any cache keeps for its consumer, and written
+    // through the XCDs' L2s they displace the operand panels (the fat tail of fc1's K loops, profiles/r6_gemm_pstamps.txt).  In-process A/B (profiles/r6_ab_inproc.txt): the second
+    // output alone -0.03 ... -0.17 ms, BOTH -0.34 ... -0.41 ms on top (C alone +0.30); the same for qkv's output (+0.08) or dfc2's (+0.20, its consumers are the next two launches): no.
+    p.c_nt = ((kn.aux_nt & 4) && a->aux_out) ? 1 : 0;
     p.epi_swap = kn.epi_swap;
     p.tq = nullptr; p.tq_clear = nullptr; p.tq_nwhole[0] = p.tq_nwhole[1] = p.tq_items[0] = p.tq_items[1] = 0;
     // rasterisation (measured, tools/gemm_ablate.py): wide outputs (N >= 2048) gain 7-10 % from 8-row-tile groups (the
