@@ -2448,7 +2448,7 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
         const int nt = p.tiles_m * p.tiles_n;
         // grid of the persistent forms: one workgroup per CU the policy counts on.  With the dynamic queues a reserve is pointless for THEM (a workgroup that
         // finds no CU pulls nothing): they launch on every CU, and gemm_reserve_cus then only sizes the weight-gradient split-K (one round of the CUs left)
-        const bool dyn = kn.dynamic > 0 || (kn.dynamic < 0 && kn.concurrent != 0);
+        const bool dyn = kn.dynamic > 0 || (kn.dynamic < 0 && kn.concurrent != 0);      // (round 6: queues only for fc1, or fc1 + dfc2 -- the launches whose tiles vary most --: -0.09 / -0.03 / -0.04 ms, noise)
         const int gp = dyn ? (devias_device_cus() & ~7) : devias_policy_gemm_cus();
         // persistent form (more than one round of tiles, no split-K, bf16 output): measured per shape at M = 50176 (tools/gemm_block_shapes.py, same
         // box, one-tile-per-workgroup -> persistent): qkv 226 -> 204 us, fc1 278 -> 243, dfc2 + dGELU + colsum 415 -> 349, dfc2 plain 275 -> 248,
