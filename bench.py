@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--cu-hog", type=int, default=0, help="hold this many CUs (128 KiB LDS each) on a side stream during every backward: stand-in for the CUs "
                     "RCCL's kernels occupy at N > 1")
     ap.add_argument("--reserve-cus", type=int, default=0, help="persistent GEMM grids leave this many CUs free (library option gemm_reserve_cus)")
-    ap.add_argument("--cu-hog-us", type=int, default=36000, help="how long each --cu-hog workgroup holds its CU (about one backward)")
+    ap.add_argument("--cu-hog-us", type=int, default=0, help="how long each --cu-hog workgroup holds its CU; 0 (default) = 90 %% of the backward's device time, measured in two un-hogged steps "
+                                                               "(a longer hold than the backward makes the step wait for the hog, not for its work: round 6 found the old fixed 36 ms doing that)")
     return ap.parse_args()
 
 
@@ -93,7 +94,7 @@ def cpu_baseline(args):
                       f"{args.model} {args.frames}x{args.img_size}^2, {torch.get_num_threads()} of {os.cpu_count()} host cores (PyTorch CPU kernels stop scaling beyond)"}
 
 
-PMC_PROFILE = "profiles/r5_pmc/summary.json"      # written by tools/runs/r5_profile.sh (tools/pmc_summary.py --json), keyed by the kernel-source hash
+PMC_PROFILE = "profiles/r6_pmc/summary.json"      # written by tools/runs/r6fin.sh (tools/pmc_summary.py --json), keyed by the kernel-source hash
 
 
 def pmc_traffic(kernel_substr: str) -> dict:
@@ -110,7 +111,7 @@ def pmc_traffic(kernel_substr: str) -> dict:
             return {"traffic": None, "traffic_note": f"{kernel_substr} is not in {PMC_PROFILE}"}
         if prof.get("source_hash") != cur:
             return {"traffic": None, "traffic_note": f"{PMC_PROFILE} was taken on kernel sources {prof.get('source_hash')}, this run uses {cur}: "
-                                                     f"stale ({hit[0][1]['traffic_bytes']:.4g} B then); re-run tools/runs/r5_profile.sh"}
+                                                     f"stale ({hit[0][1]['traffic_bytes']:.4g} B then); re-run tools/runs/r6fin.sh"}
         k, v = hit[0]
         return {"traffic": v["traffic_bytes"], "traffic_dur_us_under_pmc": v["dur_us"],
                 "traffic_source": f"{PMC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; kernel sources {cur})"}
@@ -295,7 +296,7 @@ def fc1_fwd_probe(args, device, step=None):
              "timed": timed, "launches_timed": n_in_step, "avg_ms_back_to_back": loop_ms,
              "algorithmic_bytes": (M * D + 4 * D * D + 2 * M * 4 * D) * es}
     if args.model == "vit_base" and args.batch == 32 and args.frames == 16 and args.dtype == "bf16":
-        probe.update(pmc_traffic("gemm256p_kernel<false, 0"))
+        probe.update(pmc_traffic("gemm256p_kernel<false, 0, false, 25>"))
     return probe
 
 
@@ -380,6 +381,18 @@ def main():
             if (world > 1 or args.force_gradsync or args.rccl_world1) else None)
     from devias_amd import _lib as _dl
     hog_stream = torch.cuda.Stream(device=device) if args.cu_hog > 0 else None
+
+    if hog_stream is not None and args.cu_hog_us <= 0:   # size the hold to the backward it stands beside
+        eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        bw = []
+        for _ in range(3):
+            for p in model.parameters():
+                p.grad = None
+            out = model(x)
+            total, logits, ld = crit(model, out, (None, tl), y, fg_mask=(fg196, fgN))
+            eb0.record(); total.backward(); eb1.record(); torch.cuda.synchronize()
+            bw.append(eb0.elapsed_time(eb1))
+        args.cu_hog_us = int(0.9 * min(bw) * 1e3)
 
     def step():
         for p in model.parameters():
@@ -490,7 +503,7 @@ def main():
                                (" + gradient-bucket path with the collective replaced by a device copy (--force-gradsync)" if args.force_gradsync and world == 1 else "") +
                                (f" + gradient-bucket path over a ONE-rank RCCL group ({args.comm_dtype} wire format, --rccl-world1)" if args.rccl_world1 and world == 1 else "") +
                                (f" + stochastic depth {args.drop_path} (--drop-path; NOT the BASELINE configuration)" if args.drop_path else "") +
-                               (f" + {args.cu_hog} CUs held on a side stream during backward (--cu-hog)" if args.cu_hog else "") +
+                               (f" + {args.cu_hog} CUs held on a side stream for {args.cu_hog_us / 1e3:.1f} ms of every backward (--cu-hog)" if args.cu_hog else "") +
                                (f" + persistent GEMM grids sized for {args.reserve_cus} fewer CUs (--reserve-cus)" if args.reserve_cus else ""),
                    "global_batch": world * B, "tokens": N, "parallelism": f"dp{world}", "weights": "formula (devias_amd.synth)",
                    "teacher_logits": "input tensor (primary metric, SURVEY.md 8d)", "optimizer_in_step": False,

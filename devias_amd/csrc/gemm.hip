@@ -382,6 +382,11 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
 #pragma unroll
         for (int n = 0; n < PF; ++n) sbuf[n] = side_load(n);
     }
+    // (the generic form adds a zero bias where there is none; a specialised form without bias skips the add: an accumulator chain that starts at +0 never
+    //  holds -0 unless a negative sum underflows, the only value the add of +0 would change)
+    const bool add_bias = GEN || (BIAS_ON && on_bias);
+    // (Round 6, measured and removed: the specialised forms that read rows doing bias + lane-group exchange of EVERY piece first, in place, while those rows are in flight --
+    //  stamps proj 5.60 -> 5.53, dfc2 10.57 -> 10.52 us per tile, three interleaved bench pairs 45.41 vs 45.40 ms: the first piece's wait is not what the interval is made of.)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int m = mrow0 + i * 16 + lm;
@@ -389,11 +394,8 @@ __device__ __forceinline__ void epilogue_swap(const GemmP& p, f32x4 (&acc)[NI][4
         for (int pr = 0; pr < 2; ++pr) {
             bf16x8 side8 = sbuf[(i * 2 + pr) % PF];
             if (side_on && i * 2 + pr + PF < 2 * NI) sbuf[(i * 2 + pr) % PF] = side_load(i * 2 + pr + PF);
-            // (the generic form adds a zero bias where there is none; a specialised form without bias skips the add: an accumulator chain that starts at +0 never
-            //  holds -0 unless a negative sum underflows, the only value the add of +0 would change)
-            const bool add_bias = GEN || (BIAS_ON && on_bias);
-            const f32x4 A = add_bias ? acc[i][2 * pr] + bias4[2 * pr] : acc[i][2 * pr], B = add_bias ? acc[i][2 * pr + 1] + bias4[2 * pr + 1] : acc[i][2 * pr + 1];
             float v[8];
+            const f32x4 A = add_bias ? acc[i][2 * pr] + bias4[2 * pr] : acc[i][2 * pr], B = add_bias ? acc[i][2 * pr + 1] + bias4[2 * pr + 1] : acc[i][2 * pr + 1];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(A[r]), __float_as_uint(B[r]), false, false);

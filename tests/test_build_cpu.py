@@ -66,7 +66,7 @@ def test_eight_wave_persistent_gemm_kernels_do_not_spill():
     drains the tile's whole store burst, which the kernel otherwise leaves in flight under the next tile's K loop.  Round 6 found how close that is: the first
     specialised epilogues with column sums (EPI_CS) spilled 52-132 bytes -- with no branch left between the sixteen pieces the compiler sank all 128 column-sum adds
     behind the last piece and kept every piece alive for them.  Every instantiation -- <B layout, side rows, static / dynamic, generic / specialised epilogue> --
-    must therefore have no scratch, exactly one K-tile of MFMAs, and every specialisation the host dispatches to must exist."""
+    must therefore have no scratch, exactly the MFMAs of its K-tile bodies, and every specialisation the host dispatches to must exist."""
     text = _isa("gemm")
     sizes = dict(re.findall(r"\.set (\S*gemm256p_kernel\S*)\.private_seg_size, (\d+)", text))
     assert len(sizes) == 22, sorted(sizes)       # 2 (dynamic) x [ (F,0): generic, bias, bias+GELU+aux, none, colsum | (F,1): generic, bias | (F,2): generic, dGELU+colsum | (T,0): generic | (T,2): generic ]
@@ -81,7 +81,12 @@ def test_eight_wave_persistent_gemm_kernels_do_not_spill():
             j += 1
         body = [b.split(";")[0] for b in lines[i:j + 1]]
         assert sum("scratch_" in b for b in body) == 0, m.group(1)
-        assert sum("v_mfma" in b for b in body) == 64, m.group(1)
+        # one K-tile of MFMAs in the persistent loop; the static-list, B-k-contiguous, no-column-sum instantiations also carry the six row ranges of a tail tile's thirds /
+        # quarters ([0,5) [5,8) [0,3) [3,8) [0,4) [4,8): 24 row tiles x 4 column tiles x 2 k-steps)
+        t = re.search(r"gemm256p_kernelILb(\d)ELi(\d)ELb(\d)ELi(n?\d+)E", m.group(1))
+        tb, dyn, epi = t.group(1) == "1", t.group(3) == "1", int(t.group(4).replace("n", "-"))
+        pieces = not tb and not dyn and not (epi >= 0 and epi & 64)
+        assert sum("v_mfma" in b for b in body) == 64 + (192 if pieces else 0), m.group(1)
 
 
 @pytest.mark.timeout(600)

@@ -29,6 +29,7 @@ def main():
 
     from devias_amd import _lib as _dl
     hog = [0]
+    hog_us = [36000]                                  # set to 90 % of the backward's device time below (a hold longer than the backward makes the step wait for the hog itself)
     hog_stream = torch.cuda.Stream(device=dev)
 
     def step():
@@ -38,7 +39,7 @@ def main():
         total, logits, ld = crit(model, out, (None, tl), y, fg_mask=fg)
         if hog[0]:
             hog_stream.wait_stream(torch.cuda.current_stream(dev))
-            _dl.check(_dl.load().devias_debug_cu_hog(hog[0], 36000, hog_stream.cuda_stream), "devias_debug_cu_hog")
+            _dl.check(_dl.load().devias_debug_cu_hog(hog[0], hog_us[0], hog_stream.cuda_stream), "devias_debug_cu_hog")
         total.backward()
         if hog[0]:
             torch.cuda.current_stream(dev).wait_stream(hog_stream)
@@ -46,12 +47,21 @@ def main():
     for _ in range(8):
         step()
     torch.cuda.synchronize()
+    eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    bw = []
+    for _ in range(3):
+        for p in model.parameters():
+            p.grad = None
+        total, logits, ld = crit(model, model(x), (None, tl), y, fg_mask=fg)
+        eb0.record(); total.backward(); eb1.record(); torch.cuda.synchronize()
+        bw.append(eb0.elapsed_time(eb1))
+    hog_us[0] = int(0.9 * min(bw) * 1e3)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for spec in specs:
         name, vals = spec.split("=")
         if name == "hog":
             hog[0] = int(vals)
-            print(f"--- {hog[0]} CUs held during every backward from here on", flush=True)
+            print(f"--- {hog[0]} CUs held for {hog_us[0] / 1e3:.1f} ms of every backward ({min(bw):.1f} ms un-hogged) from here on", flush=True)
             for _ in range(3):
                 step()
             continue
