@@ -62,10 +62,22 @@ def test_weight_cache_invalidation_logic(monkeypatch):
     with torch.no_grad():
         q.zero_()
     assert float(cache.get_cat((p, q), torch.bfloat16)[8:].abs().max()) == 0.0
+    # the transposed copies of the encoder weights (round 6: the dgrad GEMMs' k-contiguous B operand) follow the same stamps
+    t0 = cache.get_t(p, torch.bfloat16)
+    assert t0.shape == (4, 8) and t0.is_contiguous() and torch.equal(t0, p.detach().bfloat16().t()) and cache.get_t(p, torch.bfloat16) is t0 and cache.transposes == 1
+    with torch.no_grad():
+        p.add_(1.0)
+    t1 = cache.get_t(p, torch.bfloat16)
+    assert t1 is not t0 and torch.equal(t1, p.detach().bfloat16().t()) and cache.transposes == 2
+    p.data.mul_(0.5)
+    assert cache.get_t(p, torch.bfloat16) is t1
+    ms.invalidate_weight_cache()
+    assert torch.equal(cache.get_t(p, torch.bfloat16), p.detach().bfloat16().t()) and cache.transposes == 3
     n = len(cache._c)
-    del p, q, w0, w1, w2, c0
+    nt_ = len(cache._t)
+    del p, q, w0, w1, w2, c0, t0, t1
     gc.collect()
-    assert len(cache._c) == n - 2 and len(cache._cat) == 0
+    assert len(cache._c) == n - 2 and len(cache._cat) == 0 and len(cache._t) == nt_ - 1
     # conv weights are viewed as matrices; fp32 mode never copies
     c = torch.nn.Parameter(torch.randn(6, 3, 2, 4, 4))
     assert cache.get(c, torch.float32).shape == (6, 96) and cache.get(c, torch.float32).data_ptr() == c.data_ptr()
