@@ -26,7 +26,7 @@ if len(sys.argv) > 2: o.set_option("gemm_dynamic", int(sys.argv[2]))
 def call():
     g = _lib.GemmArgs()
     g.A, g.B, g.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
-    g.M, g.N, g.K = M, N, K; g.lda, g.ldb, g.ldc = K, (N if TB else K), N
+    g.M, g.N, g.K = M, N, K; g.lda, g.ldb, g.ldc = (0 if os.environ.get("PSTAMP_LDA0") else K), (N if TB else K), N      # (PSTAMP_LDA0=1: every A row is row 0 -- the A stream from L2 instead of HBM: what the K loop does without A's memory latency)
     g.trans_b = 1 if TB else 0
     g.dtype = 1; g.split_k = 1; g.ws = ws.data_ptr()
     if not TB: g.bias = bias.data_ptr()
