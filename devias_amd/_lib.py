@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DEVIAS_LIB_PATH") or os.path.join(_HERE, "libdevias_amd.so")     # (override: ablation builds of tools/)
 
 F32, BF16 = 0, 1
-ABI_VERSION = 166                # devias_version() of the library these prototypes describe
+ATTN_Q_PRESCALED = 1                # DEVIAS_ATTN_Q_PRESCALED (devias_mhsa_*_flags)
+ABI_VERSION = 167                # devias_version() of the library these prototypes describe
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_DGELU, ACT_DRELU = 0, 1, 2, 3, 4, 5
 
 
@@ -50,7 +51,8 @@ class BlockArgs(Structure):          # devias_block_args
     _fields_ = [(n, c_int32) for n in ("B", "N", "D", "H", "hidden", "dtype")] + [("eps", c_float)] + \
                [(n, c_void_p) for n in ("n1w", "n1b", "n2w", "n2b", "Wqkv", "Wp", "W1", "W2", "qkv_bias", "pb", "b1", "b2", "ds1", "ds2", "save", "ws")] + \
                [("ws_bytes", c_int64), ("sk_ws", c_void_p), ("sk_ws_bytes", c_int64)] + \
-               [(n, c_void_p) for n in ("WqkvT", "WpT", "W1T", "W2T")]          # ABI 166: optional transposed weight copies for the dgrad GEMMs
+               [(n, c_void_p) for n in ("WqkvT", "WpT", "W1T", "W2T")] + \
+               [("WqkvS", c_void_p), ("qkv_biasS", c_void_p)]                     # ABI 166: optional transposed weight copies for the dgrad GEMMs; 167: the q-scaled copy of Wqkv / qkv_bias
 
 
 class BlockGrads(Structure):         # devias_block_grads
@@ -129,6 +131,9 @@ PROTOTYPES = {
     "devias_layernorm_bwd_workspace_bytes": (c_int64, [_I, _I]),
     "devias_mhsa_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "devias_mhsa_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P]),
+    "devias_mhsa_fwd_flags": (c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
+    "devias_mhsa_bwd_flags": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P]),
+    "devias_mhsa_bwd_bias_flags": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _F, ctypes.c_uint64, _P, _P, _P, _P, _I, _P]),
     "devias_mhsa_bwd_workspace_bytes": (c_int64, [_I, _I, _I]),
     "devias_mhsa_bwd_bias_dv_from_do": (c_int32, [_I, _F]),
     "devias_mhsa_fwd_dropout": (c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _F, ctypes.c_uint64, _P]),
@@ -179,7 +184,7 @@ PROTOTYPES = {
 }
 COUNTERS = {"gemm128_f32": 0, "gemm128_bf16": 1, "gemm_ss": 2, "gemm256": 3, "gemm256p": 4, "splitk_reduce": 5,
             "mhsa_fwd_bf16": 6, "mhsa_bwd_bf16": 7, "mhsa_fwd_f32": 8, "mhsa_bwd_f32": 9, "mhsa_bwd_fused": 10, "gemm_sk": 11, "gemm256w": 12, "gemm_smallm": 13, "gemm256d": 14,
-            "dkdv1w": 15, "dkdv1w_pers": 16, "dkdv1w_rest": 17, "dkdv2w": 18}     # DEVIAS_CNT_*
+            "dkdv1w": 15, "dkdv1w_pers": 16, "dkdv1w_rest": 17, "dkdv2w": 18, "mhsa_qpre": 19}     # DEVIAS_CNT_*
 OPT_CHUNK = 16384          # DEVIAS_OPT_CHUNK
 OPT_TENSOR_BYTES = 64      # sizeof(devias_opt_tensor)
 

@@ -12,7 +12,7 @@ int devias_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int devias_version(void) { return 166; }   // 166: devias_block_args grew by the optional transposed weight copies W*T (recompile callers); 165: launch counters per dK / dV kernel form (DEVIAS_CNT_DKDV*, DEVIAS_CNT_MAX 24), option gemm_epi_spec (additive); 164: devias_mhsa_bwd uses its ws again (row statistics of the one-wave-per-SIMD dK / dV kernel), devias_mhsa_bwd_bias accepts dbv = NULL where devias_mhsa_bwd_bias_dv_from_do() says so; 163: devias_get_option, devias_gemm_release_queue_stream (additive); 162: devias_mhsa_bwd_bias (additive); 161: devias_mhsa_fwd_dropout / _bwd_dropout (additive); 160: devias_loss_dims.scene_ce (struct grew); 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options, 140: stream-K GEMM (args struct grew), 150: fused regions, roctx ranges
+extern "C" int devias_version(void) { return 167; }   // 167: devias_mhsa_*_flags (DEVIAS_ATTN_Q_PRESCALED), devias_block_args grew by WqkvS / qkv_biasS (recompile callers), option attn_qpre; 166: devias_block_args grew by the optional transposed weight copies W*T (recompile callers); 165: launch counters per dK / dV kernel form (DEVIAS_CNT_DKDV*, DEVIAS_CNT_MAX 24), option gemm_epi_spec (additive); 164: devias_mhsa_bwd uses its ws again (row statistics of the one-wave-per-SIMD dK / dV kernel), devias_mhsa_bwd_bias accepts dbv = NULL where devias_mhsa_bwd_bias_dv_from_do() says so; 163: devias_get_option, devias_gemm_release_queue_stream (additive); 162: devias_mhsa_bwd_bias (additive); 161: devias_mhsa_fwd_dropout / _bwd_dropout (additive); 160: devias_loss_dims.scene_ce (struct grew); 110: multi-tensor optimizer entry points, 120: devias_fame_*, 130: counters + options, 140: stream-K GEMM (args struct grew), 150: fused regions, roctx ranges
 
 // ---- launch counters: which kernel family served a call (tests assert that the measured kernels are the ones under test) ----
 #include <atomic>

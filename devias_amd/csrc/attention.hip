@@ -23,6 +23,10 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+// bit 1 of the kernels' `xcd` argument (bit 0: XCD-aware linear grid, bits 16..: B): the q third of qkv already holds q * scale * log2 e, rounded ONCE by its producer
+// (DEVIAS_ATTN_Q_PRESCALED, ABI 167).  Forward, dQ and dK / dV kernels then multiply the SAME bf16 operands -- the backward's scores are the forward's, the saved lse fits
+// them exactly -- where otherwise forward / dQ round q * c and the one-wave dK / dV kernel rounds k * c (~2x the dK / dV error at peaked logits)
+enum { ATTN_QPRE = 2 };
 constexpr float LN2 = 0.6931471805599453f;
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void mhsa_fwd_bf16_kernel(const bf16*
     const int64_t RS = 3 * (int64_t)D;
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
     const int q0 = hm.blk * (NW * 16 * QT) + wave * (16 * QT);
-    const float sl2 = scale * LOG2E;
+    const float sl2 = (xcd & ATTN_QPRE) ? 1.0f : scale * LOG2E;      // (Q already holds q * scale * log2 e: DEVIAS_ATTN_Q_PRESCALED)
 
     bf16x8 qf[QT][2];
 #pragma unroll
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mhsa_fwd32_bf16_kernel(const bf16*
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
     const int q0 = hm.blk * (NW * 32) + wave * 32;
     const bool active = q0 < N;                                        // (a wave without a valid query only stages and synchronises)
-    const float sl2 = scale * LOG2E;
+    const float sl2 = (xcd & ATTN_QPRE) ? 1.0f : scale * LOG2E;      // (Q already holds q * scale * log2 e: DEVIAS_ATTN_Q_PRESCALED)
     constexpr float THR = 6.0f;
     uint32_t rowkey = 0;                                               // DROP: this lane's query row of the mask
     if constexpr (DROP) rowkey = drop_rowkey(drop, (uint32_t)(b * H + h), (uint32_t)min(q0 + r32, N - 1));
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(NW * 64) void mhsa_bwd_dq_bf16_kernel(const bf16* _
     const int64_t RS = 3 * (int64_t)D;
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
     const int q0 = hm.blk * (NW * 16 * QT) + wave * (16 * QT);
-    const float sl2 = scale * LOG2E;
+    const float sl2 = (xcd & ATTN_QPRE) ? 1.0f : scale * LOG2E;      // (Q already holds q * scale * log2 e: DEVIAS_ATTN_Q_PRESCALED)
 
     bf16x8 qf[QT][2], dof[QT][2];
     float lse2[QT], dl[QT];
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
     const bf16* base = qkv + (int64_t)b * N * RS + h * 64;
     const bf16* dobase = d_o + (int64_t)b * N * D + h * 64;
     const int key0 = hm.blk * (64 * KT) + wave * (16 * KT);
-    const float sl2 = scale * LOG2E;
+    const float sl2 = (xcd & ATTN_QPRE) ? 1.0f : scale * LOG2E;      // (Q already holds q * scale * log2 e: DEVIAS_ATTN_Q_PRESCALED)
 
     bf16x8 kreg[KT][2], vreg[KT][2];
 #pragma unroll
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_bf16_kernel(const bf16* __r
             bf16* row = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                store4(row + D + 16 * dt, acc_dk[dt][kt] * scale);
+                store4(row + D + 16 * dt, acc_dk[dt][kt] * ((xcd & ATTN_QPRE) ? LN2 : scale));      // (dK = scale dS^T q = ln 2 dS^T q' with q' = q scale log2 e)
                 store4(row + 2 * D + 16 * dt, acc_dv[dt][kt]);
             }
         }
@@ -1147,7 +1151,7 @@ __global__ __launch_bounds__(128) void mhsa_bwd_dkdv_f32_kernel(const float* __r
 
 // process-wide options, read from the environment once; devias_set_option("attn_cfg" | "attn_xcd", v) changes them at run time
 namespace {
-struct AttnKnobs { int cfg, xcd, bias_fused, dkdv; };
+struct AttnKnobs { int cfg, xcd, bias_fused, dkdv, qpre; };
 AttnKnobs& attn_knobs() {
     static AttnKnobs k = [] {
         AttnKnobs x;
@@ -1155,6 +1159,7 @@ AttnKnobs& attn_knobs() {
         e = getenv("DEVIAS_ATTN_XCD"); x.xcd = e ? atoi(e) : 1;
         e = getenv("DEVIAS_ATTN_BIAS_FUSED"); x.bias_fused = e ? atoi(e) : 1;
         e = getenv("DEVIAS_ATTN_DKDV"); x.dkdv = e ? atoi(e) : 1;
+        e = getenv("DEVIAS_ATTN_QPRE"); x.qpre = e ? atoi(e) : 1;
         return x;
     }();
     return k;
@@ -1163,6 +1168,7 @@ AttnKnobs& attn_knobs() {
 static int* attn_option_slot(const char* name) {
     if (!strcmp(name, "attn_cfg")) return &attn_knobs().cfg;
     if (!strcmp(name, "attn_xcd")) return &attn_knobs().xcd;
+    if (!strcmp(name, "attn_qpre")) return &attn_knobs().qpre;              // 1 (default): a HOST-side policy read by devias_amd/modeling_slot.py -- bf16 encoder blocks without attention dropout run their qkv GEMM on a q-scaled weight copy and the attention kernels with DEVIAS_ATTN_Q_PRESCALED; 0: q unscaled, every kernel applies scale * log2 e itself (A/B aid).  The library itself follows the caller's flags / devias_block_args.WqkvS
     if (!strcmp(name, "attn_dkdv")) return &attn_knobs().dkdv;              // 1 (default): dK / dV by the one-wave-per-SIMD kernel (attn_bwd1w.hip), one workgroup per 256-key block; 2: the same kernel, one persistent workgroup per CU (the kernel alone -2 %, the step +-0: DESIGN.md section 5 round 5); 0: the two-waves-per-SIMD kernel
     if (!strcmp(name, "attn_bias_fused")) return &attn_knobs().bias_fused;      // 0: devias_mhsa_bwd_bias takes the bias gradients by column-sum passes in bf16 too (A/B aid)
     return nullptr;
@@ -1194,18 +1200,20 @@ static bool drop_params(float keep, uint64_t seed, DropP& d) {
 }
 
 static int mhsa_fwd_impl(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
-                         int32_t dtype, float keep, uint64_t seed, void* stream) {
+                         int32_t dtype, float keep, uint64_t seed, void* stream, int32_t flags = 0) {
     hipStream_t st = (hipStream_t)stream;
     DropP dp{};
     const bool drop = drop_params(keep, seed, dp);
     DEVIAS_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0, "devias_mhsa_fwd: bad args");
     DEVIAS_REQUIRE(aligned16(qkv) && aligned16(o), "devias_mhsa_fwd: qkv/o must be 16-byte aligned");
     DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_fwd: H and B must be <= 65535");
+    DEVIAS_REQUIRE((flags & ~DEVIAS_ATTN_Q_PRESCALED) == 0 && (flags == 0 || dtype == DEVIAS_BF16), "devias_mhsa_fwd: bad flags %d (DEVIAS_ATTN_Q_PRESCALED: bf16 only)", flags);
     if (dtype == DEVIAS_BF16)
         {
         const int cfg = attn_knobs().cfg;
-        const int xcd = attn_xcd_flag(B, H);
+        const int xcd = attn_xcd_flag(B, H) | ((flags & DEVIAS_ATTN_Q_PRESCALED) ? ATTN_QPRE : 0);
         devias_count(DEVIAS_CNT_MHSA_FWD_BF16);
+        if (xcd & ATTN_QPRE) devias_count(DEVIAS_CNT_MHSA_QPRE);
 #define FWD_GRID(QB) (xcd & 1) ? dim3(cdiv(N, QB) * H * B) : dim3(cdiv(N, QB), H, B)
         if (drop) hipLaunchKernelGGL((mhsa_fwd32_bf16_kernel<4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd, dp);
         else if (cfg == 6) hipLaunchKernelGGL((mhsa_fwd_bf16_kernel<2, 4, true>), FWD_GRID(128), dim3(256), 0, st, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, xcd);
@@ -1225,6 +1233,10 @@ static int mhsa_fwd_impl(const void* qkv, void* o, float* lse, int32_t B, int32_
 extern "C" int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
                                int32_t dtype, void* stream) {
     return mhsa_fwd_impl(qkv, o, lse, B, N, H, scale, dtype, 1.0f, 0, stream);
+}
+extern "C" int devias_mhsa_fwd_flags(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
+                                     int32_t dtype, int32_t flags, void* stream) {
+    return mhsa_fwd_impl(qkv, o, lse, B, N, H, scale, dtype, 1.0f, 0, stream, flags);
 }
 extern "C" int devias_mhsa_fwd_dropout(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
                                        int32_t dtype, float keep, uint64_t seed, void* stream) {
@@ -1250,17 +1262,19 @@ static inline bool attn_use_dkdv1w(int dtype, float keep) { return dtype == DEVI
 
 static int mhsa_bwd_impl(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                          int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream,
-                         float* part_q = nullptr, float* part_v = nullptr, float* stat = nullptr) {
+                         float* part_q = nullptr, float* part_v = nullptr, float* stat = nullptr, int32_t flags = 0) {
     hipStream_t st = (hipStream_t)stream;
     DropP dp{};
     const bool drop = drop_params(keep, seed, dp);
     DEVIAS_REQUIRE(qkv && o && d_o && lse && delta && dqkv && B > 0 && N > 0 && H > 0, "devias_mhsa_bwd: bad args");
     DEVIAS_REQUIRE(aligned16(qkv) && aligned16(o) && aligned16(d_o) && aligned16(dqkv), "devias_mhsa_bwd: unaligned pointer");
     DEVIAS_REQUIRE(H <= 65535 && B <= 65535, "devias_mhsa_bwd: H and B must be <= 65535");
+    DEVIAS_REQUIRE((flags & ~DEVIAS_ATTN_Q_PRESCALED) == 0 && (flags == 0 || dtype == DEVIAS_BF16), "devias_mhsa_bwd: bad flags %d (DEVIAS_ATTN_Q_PRESCALED: bf16 only)", flags);
     if (dtype == DEVIAS_BF16) {
         const int cfg = attn_knobs().cfg;
-        const int xcd = attn_xcd_flag(B, H);
+        const int xcd = attn_xcd_flag(B, H) | ((flags & DEVIAS_ATTN_Q_PRESCALED) ? ATTN_QPRE : 0);
         devias_count(DEVIAS_CNT_MHSA_BWD_BF16);
+        if (xcd & ATTN_QPRE) devias_count(DEVIAS_CNT_MHSA_QPRE);
         // dK / dV by the one-wave-per-SIMD kernel when the caller gave room for the row statistics it streams (option attn_dkdv = 0: the two-waves-per-SIMD
         // kernel, which also serves attention dropout)
         const bool w1 = stat && attn_use_dkdv1w(dtype, keep);
@@ -1308,6 +1322,11 @@ extern "C" int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, 
     DEVIAS_REQUIRE(!ws || aligned16(ws), "devias_mhsa_bwd: unaligned workspace");
     return mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, 1.0f, 0, stream, nullptr, nullptr, (float*)ws);
 }
+extern "C" int devias_mhsa_bwd_flags(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                                     int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* ws, int32_t flags, void* stream) {
+    DEVIAS_REQUIRE(!ws || aligned16(ws), "devias_mhsa_bwd: unaligned workspace");
+    return mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, 1.0f, 0, stream, nullptr, nullptr, (float*)ws, flags);
+}
 extern "C" int devias_mhsa_bwd_dropout(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                                        int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, float keep, uint64_t seed, void* stream) {
     DEVIAS_REQUIRE(keep > 0.f && keep <= 1.f, "devias_mhsa_bwd_dropout: keep must be in (0, 1]");
@@ -1324,8 +1343,18 @@ extern "C" int64_t devias_mhsa_bwd_bias_workspace_bytes(int32_t B, int32_t N, in
     return a > c ? a : c;
 }
 extern "C" int32_t devias_mhsa_bwd_bias_dv_from_do(int32_t dtype, float keep) { return attn_use_dkdv1w(dtype, keep) ? 1 : 0; }
+static int mhsa_bwd_bias_impl(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
+                              float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, void* stream, int32_t flags);
 extern "C" int devias_mhsa_bwd_bias(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
                                     float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, void* stream) {
+    return mhsa_bwd_bias_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, dbq, dbv, ws_q, ws_v, stream, 0);
+}
+extern "C" int devias_mhsa_bwd_bias_flags(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
+                                          float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, int32_t flags, void* stream) {
+    return mhsa_bwd_bias_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, dbq, dbv, ws_q, ws_v, stream, flags);
+}
+static int mhsa_bwd_bias_impl(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
+                              float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, void* stream, int32_t flags) {
     DEVIAS_REQUIRE(dbq && ws_q && ws_v, "devias_mhsa_bwd_bias: null bias-gradient / workspace pointer");
     DEVIAS_REQUIRE(keep > 0.f && keep <= 1.f, "devias_mhsa_bwd_bias: keep must be in (0, 1]");
     const int D = H * 64;
@@ -1335,7 +1364,7 @@ extern "C" int devias_mhsa_bwd_bias(const void* qkv, const void* o, const void* 
         // to one, so sum_keys dV = sum_keys sum_queries P dO = sum_queries dO -- the v_bias gradient IS the column sum of d_o.  A caller that has those column sums
         // from the producer of d_o (the projection's dgrad GEMM: devias_gemm's colsum epilogue, csrc/regions.hip) passes dbv = NULL; otherwise one pass over d_o here.
         float* stat = reinterpret_cast<float*>(reinterpret_cast<char*>(ws_q) + attn_bias_part_bytes(B, N, H));
-        const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream, ws_q, nullptr, stat);
+        const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream, ws_q, nullptr, stat, flags);
         if (rc != DEVIAS_OK) return rc;
         const int r1 = devias_colsum_finish(ws_q, B * cdiv(N, 128), D, dbq, 0.f, (hipStream_t)stream);
         if (r1 != DEVIAS_OK || !dbv) return r1;
@@ -1343,13 +1372,13 @@ extern "C" int devias_mhsa_bwd_bias(const void* qkv, const void* o, const void* 
     }
     DEVIAS_REQUIRE(dbv, "devias_mhsa_bwd_bias: dbv may be NULL only where devias_mhsa_bwd_bias_dv_from_do() says so");
     if (dtype == DEVIAS_BF16 && attn_knobs().bias_fused) {
-        const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream, ws_q, ws_v);
+        const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream, ws_q, ws_v, nullptr, flags);
         if (rc != DEVIAS_OK) return rc;
         const int rows = B * cdiv(N, 128);
         const int r1 = devias_colsum_finish(ws_q, rows, D, dbq, 0.f, (hipStream_t)stream);
         return r1 != DEVIAS_OK ? r1 : devias_colsum_finish(ws_v, rows, D, dbv, 0.f, (hipStream_t)stream);
     }
-    const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream);
+    const int rc = mhsa_bwd_impl(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, keep, seed, stream, nullptr, nullptr, nullptr, flags);
     if (rc != DEVIAS_OK) return rc;
     const int r1 = devias_colsum(dqkv, dtype, B * N, D, 3 * D, dbq, 0.f, ws_q, stream);
     return r1 != DEVIAS_OK ? r1 : devias_colsum(static_cast<const char*>(dqkv) + (int64_t)2 * D * es, dtype, B * N, D, 3 * D, dbv, 0.f, ws_v, stream);

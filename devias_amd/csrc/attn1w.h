@@ -8,6 +8,7 @@
 namespace {
 
 constexpr float LOG2E_1W = 1.4426950408889634f;
+constexpr float LN2_1W = 0.6931471805599453f;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef __attribute__((address_space(3))) const char* lds_cptr;

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NW * QS * 64) void mhsa_bwd_dkdv1w_kernel(const bf1
     // ---- K / V fragments -> AGPRs (B operands: lane = key r32 of key block kb, d = 16 ks + 8 hi .. + 8); accumulators = 0 ------------------------------------------
     agpr_claim();
     auto fill_kv = [&]() {
-        const float ksc = scale * LOG2E;
+        const float ksc = (xcd & 2) ? 1.0f : scale * LOG2E;      // (xcd bit 1 = ATTN_QPRE, attention.hip: q already holds q * scale * log2 e -- the scores are then the forward's own products)
         sfor<8>([&](auto I) {
             constexpr int f = decltype(I)::value;
             sfor<4>([&](auto J) {
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(NW * QS * 64) void mhsa_bwd_dkdv1w_kernel(const bf1
                         sk[e] += *reinterpret_cast<const f32x4*>(smem_all + w * 32768 + off);
                         sv[e] += *reinterpret_cast<const f32x4*>(smem_all + w * 32768 + off + 256);
                     }
-                    sk[e] *= scale;
+                    sk[e] *= (xcd & 2) ? LN2_1W : scale;
                 }
                 if (key < N) {
                     bf16* dst = dqkv + ((int64_t)b * N + key) * RS + h * 64 + 8 * c8;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(NW * QS * 64) void mhsa_bwd_dkdv1w_kernel(const bf1
         // 128-byte half), then stores of eight whole rows per instruction.  Lane (hi, key r32 of block kb) holds d = 32 db + 8 jj + 4 hi .. + 4 of its key's rows ------
         if constexpr (!(DKDV_ABL & 2048)) {
             char* tile = smem + EPI_OFF + wave * 16384;
-            const float dksc = scale;
+            const float dksc = (xcd & 2) ? LN2_1W : scale;      // dK = scale dS^T q = ln 2 dS^T q'
             sfor<16>([&](auto I) {
                 constexpr int db = (decltype(I)::value >> 3) & 1, kb = (decltype(I)::value >> 2) & 1, jj = decltype(I)::value & 3;
                 constexpr int ra = (db * 2 + kb) * 16 + 4 * jj;

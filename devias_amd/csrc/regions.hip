@@ -145,12 +145,15 @@ struct BlockScratch {
         bytes = off;
     }
 };
+// forward ran the qkv GEMM on the caller's q-scaled copies (ABI 167): bf16, both pointers given
+inline bool block_qpre(const devias_block_args* a) { return a->dtype == DEVIAS_BF16 && a->WqkvS && a->qkv_biasS; }
 int block_check(const devias_block_args* a, const char* who) {
     DEVIAS_REQUIRE(a, "%s: null args", who);
     DEVIAS_REQUIRE(a->B > 0 && a->N > 0 && a->D > 0 && a->H > 0 && a->hidden > 0 && a->D == a->H * 64, "%s: bad dims (B=%d N=%d D=%d H=%d hidden=%d; head dim must be 64)", who,
                    a->B, a->N, a->D, a->H, a->hidden);
     DEVIAS_REQUIRE(a->dtype == DEVIAS_BF16 || a->dtype == DEVIAS_F32, "%s: bad dtype %d", who, a->dtype);
     DEVIAS_REQUIRE(a->n1w && a->n1b && a->n2w && a->n2b && a->Wqkv && a->Wp && a->W1 && a->W2 && a->qkv_bias && a->pb && a->b1 && a->b2, "%s: null parameter", who);
+    DEVIAS_REQUIRE((a->WqkvS != nullptr) == (a->qkv_biasS != nullptr) && (!a->WqkvS || a->dtype == DEVIAS_BF16), "%s: WqkvS and qkv_biasS go together (bf16 only)", who);
     DEVIAS_REQUIRE(a->save && a->ws && aligned16(a->save) && aligned16(a->ws), "%s: save / ws must be 16-byte aligned, non-null", who);
     DEVIAS_REQUIRE(a->ws_bytes >= devias_encoder_block_workspace_bytes(a->B, a->N, a->D, a->H, a->hidden, a->dtype), "%s: workspace too small", who);
     return DEVIAS_OK;
@@ -182,8 +185,11 @@ extern "C" int devias_encoder_block_fwd(const devias_block_args* a, const void* 
     const BlockSave s(a->save, B, N, D, H, hid, a->dtype);
     devias_range r("encoder_block_fwd");
     RUN(ln_fwd(c, x, a->n1w, a->n1b, s.u, s.mean1, s.rstd1, M, D, a->eps));
-    { Epi e; e.bias = a->qkv_bias; RUN(gemm(c, s.u, a->Wqkv, s.qkv, M, 3 * D, D, D, D, 0, 0, e)); }            // [M, 3D] == [B,N,3,H,64]
-    RUN(devias_mhsa_fwd(s.qkv, s.o, s.lse, B, N, H, 0.125f, a->dtype, stream));
+    // q pre-multiplied by scale * log2 e where the caller keeps such a copy of Wqkv / qkv_bias (ABI 167): the arena's q third is then q', rounded once, and the attention
+    // kernels of both directions multiply the same bf16 operands (devias_mhsa_fwd_flags)
+    const bool qpre = block_qpre(a);
+    { Epi e; e.bias = qpre ? a->qkv_biasS : a->qkv_bias; RUN(gemm(c, s.u, qpre ? a->WqkvS : a->Wqkv, s.qkv, M, 3 * D, D, D, D, 0, 0, e)); }            // [M, 3D] == [B,N,3,H,64]
+    RUN(devias_mhsa_fwd_flags(s.qkv, s.o, s.lse, B, N, H, 0.125f, a->dtype, qpre ? DEVIAS_ATTN_Q_PRESCALED : 0, stream));
     { Epi e; e.bias = a->pb; e.res = x; e.row_scale = a->ds1; e.rows_per_scale = N; RUN(gemm(c, s.o, a->Wp, s.x1, M, D, D, D, D, 0, 0, e)); }      // x + drop_path(proj(.))
     RUN(ln_fwd(c, s.x1, a->n2w, a->n2b, s.u2, s.mean2, s.rstd2, M, D, a->eps));
     { Epi e; e.bias = a->b1; e.act = DEVIAS_ACT_GELU; e.aux_out = s.hpre; RUN(gemm(c, s.u2, a->W1, s.hact, M, hid, D, D, D, 0, 0, e)); }
@@ -237,13 +243,14 @@ extern "C" int devias_encoder_block_bwd(const devias_block_args* a, const void* 
     RUN(wgrad(c, g1, s.o, g->dWp, M, D, D));
     // v_bias gradient: the column sum of d_o where the attention backward says so (softmax rows sum to one: sum_keys dV = sum_queries dO), from this GEMM's epilogue
     const bool dv_from_do = g->dbq && g->dbv && devias_mhsa_bwd_bias_dv_from_do(a->dtype, 1.0f);
+    const int aflags = block_qpre(a) ? DEVIAS_ATTN_Q_PRESCALED : 0;      // (the arena's q third is q' = q * scale * log2 e: what forward decided from the same struct)
     { Epi e; if (dv_from_do) e.colsum = g->dbv;                                                                                               // d_o (p_v: the attention backward does not use it then)
       const Ctx k = dv_from_do ? with_ws(t.p_v) : c;
       if (WpT) RUN(gemm(k, g1, WpT, t.small, M, D, D, D, D, 0, 0, e)); else RUN(gemm(k, g1, a->Wp, t.small, M, D, D, D, D, 0, 1, e)); }
     if (g->dbq && g->dbv)                                                   // dqkv + the q_bias / v_bias gradients (each to its own destination) from the same two kernels
-        RUN(devias_mhsa_bwd_bias(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, 1.0f, 0, g->dbq, dv_from_do ? nullptr : g->dbv, t.p_q, t.p_v, stream));
+        RUN(devias_mhsa_bwd_bias_flags(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, 1.0f, 0, g->dbq, dv_from_do ? nullptr : g->dbv, t.p_q, t.p_v, aflags, stream));
     else
-        RUN(devias_mhsa_bwd(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, t.p_q, stream));                          // dqkv
+        RUN(devias_mhsa_bwd_flags(s.qkv, s.o, t.small, s.lse, t.delta, t.big, B, N, H, 0.125f, a->dtype, t.p_q, aflags, stream));                          // dqkv
     RUN(wgrad(c, t.big, s.u, g->dWqkv, M, 3 * D, D));
     if (g->dbq && g->dbv) {
     } else {

@@ -109,8 +109,10 @@ class _WeightCache:
         self._cat = _WeakIdDict()                    # first Parameter of a concatenation -> {ids of the others: (stamps, weakrefs, copy)}
         self._qkvb = _WeakIdDict()                   # q_bias Parameter -> (stamps, weakref to v_bias, fp32 q_bias | 0 | v_bias)
         self._t = _WeakIdDict()                      # Parameter -> (stamp, transposed compute-dtype copy)
+        self._qs = _WeakIdDict()                     # qkv weight Parameter / fp32 qkv bias tensor -> (stamp, copy with the q third scaled)
         self.casts = 0                               # number of casts performed (tests)
         self.transposes = 0
+        self.qscaled = 0                             # q-scaled copies made (tests)
 
     @staticmethod
     def _stamp(p: torch.Tensor):
@@ -142,6 +144,22 @@ class _WeightCache:
         w = self.get(p, dtype).t().contiguous()
         self.transposes += 1
         self._t[p] = (stamp, w)
+        return w
+
+    def get_qscaled(self, p: torch.Tensor, rows: int, factor: float, dtype: torch.dtype) -> torch.Tensor:
+        """the compute-dtype copy of a [3D, D] qkv weight (or a [3D] fp32 qkv bias: dtype = torch.float32) whose first `rows` rows / entries -- the q third -- are multiplied
+        by `factor` = scale * log2(e) IN FP32, before the rounding: the qkv GEMM then leaves q' = q * scale * log2(e) rounded ONCE, and forward, dQ and dK / dV kernels
+        multiply the same bf16 operands (DEVIAS_ATTN_Q_PRESCALED, devias_block_args.WqkvS).  Cached like get(); backward reads the unscaled copies."""
+        stamp = self._stamp(p) + (rows, factor)
+        hit = self._qs.get(p)
+        if hit is not None and hit[0] == stamp and hit[1].dtype == dtype:
+            return hit[1]
+        d = p.detach().float()
+        d = d.reshape(d.shape[0], -1).clone() if d.dim() > 1 else d.clone()
+        d[:rows] *= factor
+        w = d if dtype == torch.float32 else ops.cast(d.contiguous(), dtype)
+        self.qscaled += 1
+        self._qs[p] = (stamp, w)
         return w
 
     def get_cat(self, ps, dtype: torch.dtype) -> torch.Tensor:
@@ -316,8 +334,15 @@ class EncoderBlockFn(Function):
         Wqkv, Wp, W1, W2 = (_WCACHE.get(w, cdt) for w in (qkvw, pw, f1w, f2w))
         u, mean1, rstd1 = ops.layernorm_fwd(x, n1w_, n1b_, eps)
         qkv_bias = torch.cat((_f32(qb), torch.zeros_like(_f32(vb)), _f32(vb)))         # modeling_slot.py:97-99
-        qkv = ops.gemm(u, Wqkv, bias=qkv_bias)                                          # [M, 3D] == [B,N,3,H,64]
-        o, lse = ops.mhsa_fwd(qkv, B, N, H, scale, drop=adrop)
+        qpre = _use_q_prescale(cdt, adrop)               # q' = q * scale * log2(e) straight from the GEMM (a weight / bias copy whose q third carries the factor): see _use_q_prescale
+        if qpre:
+            D3 = qkv_bias.shape[0] // 3
+            qkv_bias = qkv_bias.clone()
+            qkv_bias[:D3] *= _Q_PRESCALE
+            qkv = ops.gemm(u, _WCACHE.get_qscaled(qkvw, D3, _Q_PRESCALE, cdt), bias=qkv_bias)
+        else:
+            qkv = ops.gemm(u, Wqkv, bias=qkv_bias)                                      # [M, 3D] == [B,N,3,H,64]
+        o, lse = ops.mhsa_fwd(qkv, B, N, H, scale, drop=adrop, q_prescaled=qpre)
         if E1 is None:
             x1 = ops.gemm(o, Wp, bias=_f32(pb), res=x, row_scale=ds1, rows_per_scale=N)   # x + drop_path(proj(.))
         else:
@@ -331,6 +356,7 @@ class EncoderBlockFn(Function):
             x2 = ops.mul_mask(ops.gemm(hact, W2, bias=_f32(f2b)), E2, x1)                 # x1 + drop_path(drop(fc2(.)))
         ctx.meta = meta
         ctx.drop = (E1, E2, adrop)
+        ctx.qpre = qpre
         ctx.ds = (ds1, ds2)
         ctx.params = (n1w, n1b, qkvw, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, qb, vb)
         ctx.saved = (x, u, mean1, rstd1, qkv, o, lse, x1, u2, mean2, rstd2, hpre, hact, n1w_, n2w_, Wqkv, Wp, W1, W2)
@@ -385,10 +411,10 @@ class EncoderBlockFn(Function):
         if ops.mhsa_bwd_dv_from_do(g1.dtype, adrop):
             # softmax rows sum to one: sum_keys dV = sum_queries dO -- the v_bias gradient is the column sum of d_o, taken from the GEMM that produces it
             d_o = ops.gemm(g1, Wp, trans_b=True, colsum=dbv)
-            dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop, bias_out=(dbq, None))
+            dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop, bias_out=(dbq, None), q_prescaled=ctx.qpre)
         else:
             d_o = ops.gemm(g1, Wp, trans_b=True)
-            dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop, bias_out=(dbq, dbv))
+            dqkv = ops.mhsa_bwd(qkv, o, d_o, lse, B, N, H, scale, drop=adrop, bias_out=(dbq, dbv), q_prescaled=ctx.qpre)
         with lane.after_main():
             dWqkv = ops.wgrad(dqkv, u, out=_gout(p_qkvw))
         du = ops.gemm(dqkv, Wqkv, trans_b=True)
@@ -844,6 +870,16 @@ def _qkv_bias(qb: torch.Tensor, vb: torch.Tensor) -> torch.Tensor:
     return t
 
 
+# scale * log2(e) for head dim 64: the factor the q third of the qkv projection carries where the attention kernels run with DEVIAS_ATTN_Q_PRESCALED
+_Q_PRESCALE = (64 ** -0.5) * 1.4426950408889634
+
+
+def _use_q_prescale(cdt, drop=None) -> bool:
+    """bf16 encoder blocks without attention dropout: the qkv GEMM runs on a copy of its weight / bias whose q third carries scale * log2(e), so that forward, dQ and
+    dK / dV kernels multiply the same bf16 operands (library option attn_qpre, default 1; 0 = every kernel scales on its own: A/B aid)."""
+    return cdt == torch.bfloat16 and drop is None and ops.get_option("attn_qpre") != 0
+
+
 class EncoderBlockRegionFn(Function):
     """EncoderBlockFn as one devias_encoder_block_fwd / _bwd call (Block.forward, modeling_slot.py:142-152)"""
 
@@ -863,6 +899,10 @@ class EncoderBlockRegionFn(Function):
         a = _L.BlockArgs()
         a.B, a.N, a.D, a.H, a.hidden, a.dtype, a.eps = B, N, D, H, hid, dt, eps
         (a.n1w, a.n1b, a.n2w, a.n2b, a.Wqkv, a.Wp, a.W1, a.W2, a.qkv_bias, a.pb, a.b1, a.b2) = [t.data_ptr() for t in keep]
+        if _use_q_prescale(cdt):
+            qs = [_WCACHE.get_qscaled(qkvw, D, _Q_PRESCALE, cdt), _WCACHE.get_qscaled(keep[8], D, _Q_PRESCALE, torch.float32)]
+            keep = keep + qs
+            a.WqkvS, a.qkv_biasS = qs[0].data_ptr(), qs[1].data_ptr()
         if cdt != torch.float32 and any(ctx.needs_input_grad):
             # transposed weight copies for the four dgrad GEMMs of the backward (bf16 mode: the fp32 parity kernels stage through registers and do not care)
             wt = [_WCACHE.get_t(w, cdt) for w in (qkvw, pw, f1w, f2w)]

@@ -291,7 +291,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, 
     return dx, dgamma, dbeta
 
 
-def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, out: Optional[torch.Tensor] = None, drop=None):
+def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, out: Optional[torch.Tensor] = None, drop=None, q_prescaled: bool = False):
     """drop = (keep, seed): nn.Dropout(1 - keep) on the softmax matrix, mask = the library's hash of (seed, b, h, i, j) (include/devias_amd.h)"""
     _chk(qkv, "mhsa_fwd.qkv")
     assert qkv.numel() == B * N * 3 * H * 64, "mhsa: head dim must be 64"
@@ -301,9 +301,14 @@ def mhsa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, scale: float, out: Optio
         o = _chk(out, "mhsa_fwd.out", qkv.dtype)
         assert o.shape == (B * N, H * 64)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    assert not (q_prescaled and drop is not None and float(drop[0]) < 1.0), "mhsa_fwd: q_prescaled is not offered with attention dropout"
     if drop is not None and float(drop[0]) < 1.0:
         _lib.check(_lib.load().devias_mhsa_fwd_dropout(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, scale, dt_code(qkv.dtype),
                                                        float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, _stream()), "devias_mhsa_fwd_dropout")
+        return o, lse
+    if q_prescaled:          # the q third of qkv holds q * scale * log2(e) (DEVIAS_ATTN_Q_PRESCALED, bf16; not with attention dropout)
+        _lib.check(_lib.load().devias_mhsa_fwd_flags(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), _lib.ATTN_Q_PRESCALED, _stream()),
+                   "devias_mhsa_fwd_flags")
         return o, lse
     _lib.check(_lib.load().devias_mhsa_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), _stream()),
                "devias_mhsa_fwd")
@@ -317,7 +322,7 @@ def mhsa_bwd_dv_from_do(dtype: torch.dtype, drop=None) -> bool:
     return bool(_lib.load().devias_mhsa_bwd_bias_dv_from_do(dt_code(dtype), keep))
 
 
-def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None, bias_out=None):
+def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None, bias_out=None, q_prescaled: bool = False):
     """bias_out = (dbq, dbv): fp32 [H * 64] destinations of the q_bias / v_bias gradients (column sums of dQ / dV over all rows), produced by the same call
     (devias_mhsa_bwd_bias: from the kernels' accumulators in bf16, by two column-sum passes in fp32)"""
     _chk(qkv, "mhsa_bwd.qkv"); _chk(o, "mhsa_bwd.o", qkv.dtype); _chk(d_o, "mhsa_bwd.d_o", qkv.dtype)
@@ -329,10 +334,16 @@ def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None, 
         wsb = int(_lib.load().devias_mhsa_bwd_bias_workspace_bytes(B, N, H))
         ws = torch.empty((2, (wsb + 3) // 4), dtype=torch.float32, device=qkv.device)
         keep, seed = (float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF) if drop is not None else (1.0, 0)
+        if q_prescaled:
+            _lib.check(_lib.load().devias_mhsa_bwd_bias_flags(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N, H, scale,
+                                                              dt_code(qkv.dtype), keep, seed, dbq.data_ptr(), None if dbv is None else dbv.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                                                              _lib.ATTN_Q_PRESCALED, _stream()), "devias_mhsa_bwd_bias_flags")
+            return dqkv
         _lib.check(_lib.load().devias_mhsa_bwd_bias(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N, H, scale,
                                                     dt_code(qkv.dtype), keep, seed, dbq.data_ptr(), None if dbv is None else dbv.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), _stream()),
                    "devias_mhsa_bwd_bias")
         return dqkv
+    assert not (q_prescaled and drop is not None and float(drop[0]) < 1.0), "mhsa_bwd: q_prescaled is not offered with attention dropout"
     if drop is not None and float(drop[0]) < 1.0:
         _lib.check(_lib.load().devias_mhsa_bwd_dropout(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(),
                                                        B, N, H, scale, dt_code(qkv.dtype), float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, _stream()),
@@ -340,6 +351,10 @@ def mhsa_bwd(qkv, o, d_o, lse, B: int, N: int, H: int, scale: float, drop=None, 
         return dqkv
     wsb = int(_lib.load().devias_mhsa_bwd_workspace_bytes(B, N, H))      # row statistics of the one-wave-per-SIMD dK / dV kernel (bf16)
     ws = torch.empty(((wsb + 3) // 4,), dtype=torch.float32, device=qkv.device)
+    if q_prescaled:
+        _lib.check(_lib.load().devias_mhsa_bwd_flags(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                                     dqkv.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), ws.data_ptr(), _lib.ATTN_Q_PRESCALED, _stream()), "devias_mhsa_bwd_flags")
+        return dqkv
     _lib.check(_lib.load().devias_mhsa_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
                                            dqkv.data_ptr(), B, N, H, scale, dt_code(qkv.dtype), ws.data_ptr(), _stream()), "devias_mhsa_bwd")
     return dqkv

@@ -72,6 +72,7 @@ const char* devias_last_error(void);
 #define DEVIAS_CNT_DKDV1W_PERS 16    /* the same kernel as one persistent workgroup per CU (option attn_dkdv = 2) */
 #define DEVIAS_CNT_DKDV1W_REST 17    /* its second launch for the N mod 256 last keys of every head (32 keys at N = 1568) */
 #define DEVIAS_CNT_DKDV2W 18         /* the two-waves-per-SIMD kernel of rounds 2-4 (attention dropout, ws = NULL, option attn_dkdv = 0) */
+#define DEVIAS_CNT_MHSA_QPRE 19      /* bf16 attention calls (forward or backward) served with DEVIAS_ATTN_Q_PRESCALED (ABI 167): 2 per encoder block and step in the measured path */
 #define DEVIAS_CNT_MAX 24
 int64_t devias_counter(int32_t id);          /* -1 for an unknown id */
 void devias_counters_reset(void);
@@ -263,6 +264,18 @@ int devias_mhsa_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t N, 
 int devias_mhsa_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                     int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* ws, void* stream);
 int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H);
+/* ABI 167: the same three calls with a `flags` word (0 = the calls without it).
+ * DEVIAS_ATTN_Q_PRESCALED (bf16 only): the q third of qkv holds  q' = q * scale * log2(e)  -- rounded to bf16 ONCE, by whoever produced it (devias_encoder_block_fwd: the
+ * qkv GEMM on a weight copy whose first D rows and bias entries carry the factor, devias_block_args.WqkvS) -- instead of q.  Without the flag every kernel applies that
+ * factor itself on operands it holds in registers: the forward and the dQ kernel round q * c, the one-wave-per-SIMD dK / dV kernel rounds k * c, so the backward's
+ * scores differ from the ones the saved lse was built from by two bf16 roundings (~2x the dK / dV error at peaked logits; the advisor's round-5 finding).  With the
+ * flag all three kernels multiply the SAME bf16 operands: the backward's scores ARE the forward's.  Outputs keep their meaning: o, lse (natural log, of the scores
+ * scale * q k^T), and dqkv = the gradients with respect to the UNSCALED q, k, v (dQ = scale * dS k as always; dK = ln 2 * dS^T q'). */
+#define DEVIAS_ATTN_Q_PRESCALED 1
+int devias_mhsa_fwd_flags(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
+                          int32_t dtype, int32_t flags, void* stream);
+int devias_mhsa_bwd_flags(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                          int32_t B, int32_t N, int32_t H, float scale, int32_t dtype, void* ws, int32_t flags, void* stream);
 /* The same with nn.Dropout(attn_drop) on the softmax matrix (Attention.attn_drop, modeling_slot.py:90,110), ABI 161.  The matrix never exists, so neither
  * does its mask: element (b, h, query i, key j) is KEPT when  mix(rowkey + j * 0xC2B2AE35) < floor(keep * 2^32)  with
  *   rowkey = mix(mix(seed_lo ^ ((b * H + h) * 0x9E3779B1)) + seed_hi + i * 0x85EBCA6B),   mix(x): x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16
@@ -284,6 +297,8 @@ int devias_mhsa_bwd_dropout(const void* qkv, const void* o, const void* d_o, con
 int32_t devias_mhsa_bwd_bias_dv_from_do(int32_t dtype, float keep);
 int devias_mhsa_bwd_bias(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
                          float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, void* stream);
+int devias_mhsa_bwd_bias_flags(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv, int32_t B, int32_t N, int32_t H,
+                               float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, int32_t flags, void* stream);   /* ABI 167 */
 int64_t devias_mhsa_bwd_bias_workspace_bytes(int32_t B, int32_t N, int32_t H);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -464,6 +479,11 @@ typedef struct {
      * with 9-17 % less K-loop time (profiles/r6_nt_vs_tb.txt).  A caller compiled against ABI <= 165 passes a shorter struct: it must zero-extend it or keep calling an
      * ABI <= 165 library (devias_version() tells). */
     const void *WqkvT, *WpT, *W1T, *W2T;
+    /* ABI 167, optional (both or neither; bf16 only): a copy of Wqkv / qkv_bias whose q third -- rows [0, D) of the matrix, entries [0, D) of the bias -- is multiplied by
+     * scale * log2(e) = 0.125 * 1.4426950408889634 (in fp32, BEFORE the rounding to T).  Forward then runs the qkv GEMM on these, so that the q it leaves in the arena is
+     * q' = q * scale * log2(e) rounded once, and the attention kernels of both directions run with DEVIAS_ATTN_Q_PRESCALED (see devias_mhsa_fwd_flags).  Backward reads
+     * Wqkv / WqkvT (the unscaled copies) as before: dqkv holds the gradients with respect to the unscaled q, k, v.  The SAME struct must reach _fwd and _bwd of a block. */
+    const void* WqkvS; const float* qkv_biasS;
 } devias_block_args;
 typedef struct {
     float *dn1w, *dn1b, *dWqkv, *dbqkv /* [3D]: dq_bias | (k: unused) | dv_bias */, *dWp, *dbp, *dn2w, *dn2b, *dW1, *db1, *dW2, *db2;

@@ -139,6 +139,7 @@ def test_bf16_full_size_step_properties():
     assert cnt["gemm256p"] >= 12 * 8 and cnt["gemm256w"] == 0 and cnt["gemm256"] >= 12 * 4 and cnt["mhsa_bwd_bf16"] == 12 and cnt["gemm128_f32"] == 0, cnt
     # the dK / dV kernel the measured step ran: the one-wave-per-SIMD kernel, one workgroup per 256-key block + the launch for the 32 last keys of every head
     assert (cnt["dkdv1w"], cnt["dkdv1w_rest"], cnt["dkdv1w_pers"], cnt["dkdv2w"]) == (12, 12, 0, 0), cnt
+    assert cnt["mhsa_qpre"] == 24, cnt          # every block's attention, both directions, on q' = q * scale * log2(e) from the qkv GEMM (DEVIAS_ATTN_Q_PRESCALED)
     sh1 = out1[2][0].detach().clone()
     out2, t2, g2 = step(model, x, y, tl, fg)
     assert torch.isfinite(t1).all() and all(torch.isfinite(g).all() for g in g1.values())

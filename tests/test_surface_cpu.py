@@ -73,6 +73,21 @@ def test_weight_cache_invalidation_logic(monkeypatch):
     assert cache.get_t(p, torch.bfloat16) is t1
     ms.invalidate_weight_cache()
     assert torch.equal(cache.get_t(p, torch.bfloat16), p.detach().bfloat16().t()) and cache.transposes == 3
+    # the q-scaled copy of a qkv weight / bias (ABI 167: DEVIAS_ATTN_Q_PRESCALED): the first `rows` rows carry the factor, applied in fp32 before the rounding; same stamps
+    c_ = 0.125 * 1.4426950408889634
+    s0 = cache.get_qscaled(p, 3, c_, torch.bfloat16)
+    want = p.detach().clone(); want[:3] *= c_
+    assert torch.equal(s0, want.bfloat16()) and cache.get_qscaled(p, 3, c_, torch.bfloat16) is s0 and cache.qscaled == 1
+    assert torch.equal(s0[3:], p.detach().bfloat16()[3:]) and not torch.equal(s0[:3], p.detach().bfloat16()[:3])
+    with torch.no_grad():
+        p.add_(1.0)
+    s1 = cache.get_qscaled(p, 3, c_, torch.bfloat16)
+    want = p.detach().clone(); want[:3] *= c_
+    assert s1 is not s0 and torch.equal(s1, want.bfloat16()) and cache.qscaled == 2
+    bvec = torch.randn(12)                                                          # the fp32 q_bias | 0 | v_bias vector: a plain tensor, fp32 in and out
+    sb = cache.get_qscaled(bvec, 4, c_, torch.float32)
+    assert sb.dtype == torch.float32 and torch.equal(sb[4:], bvec[4:]) and torch.allclose(sb[:4], bvec[:4] * c_) and cache.get_qscaled(bvec, 4, c_, torch.float32) is sb
+    del s0, s1, sb, bvec, want
     n = len(cache._c)
     nt_ = len(cache._t)
     del p, q, w0, w1, w2, c0, t0, t1
