@@ -2164,8 +2164,8 @@ struct GemmKnobs {
     int smallm;        // "gemm_smallm"     DEVIAS_GEMM_SMALLM   1 (default): bf16 products with M <= 128 and B k-contiguous run on gemm_smallm_kernel (one launch, no split-K), a workgroup per 16-row tile where there are few column groups; 2: one workgroup per column group always (A/B aid)
     int tail_split;    // "gemm_tail_split" DEVIAS_GEMM_TAIL_SPLIT  eight-wave persistent kernel: last partial round's tiles as 128-row halves on two workgroups (1), whose idle waves
                        //                                        also skip the LDS-DMA of the A rows nobody multiplies (2, default); 0 = whole tiles
-    int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm; default 0,
-                       //                                        15 = all four; -1, default: all four where K >= 1024 and N >= 1024)
+    int w4;            // "gemm_w4"         DEVIAS_GEMM_W4       mask of the forms the four-wave persistent kernel (gemm256w_kernel) serves (see devias_gemm;
+                       //                                        15 = all four; -1, default: the measured policy -- none since round 6, all four where K >= 1024 and N >= 1024 before)
     int splitk_xcd;    // "gemm_splitk_xcd" DEVIAS_GEMM_SPLITK_XCD 1 (default): split-K launches of the 256 x 256 kernel (the weight gradients) order their (slab, tile) pairs XCD-major; 0: (tile, slab) grid
     int dynamic;       // "gemm_dynamic"    DEVIAS_GEMM_DYNAMIC  1: the persistent kernel's workgroups pull their tiles from per-XCD queues at run time (robust to CUs
                        //                                        held or slowed by a concurrent kernel: -2.5 ms per step with 16 CUs held during backward, profiles/
@@ -2464,7 +2464,7 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
             if (!tb) { if (side == 0) hipLaunchKernelGGL((KERNEL<false, 0 __VA_ARGS__>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<false, 1 __VA_ARGS__>), grid, block, 0, st, p); } \
             else { if (side == 0) hipLaunchKernelGGL((KERNEL<true, 0 __VA_ARGS__>), grid, block, 0, st, p); else hipLaunchKernelGGL((KERNEL<true, 2 __VA_ARGS__>), grid, block, 0, st, p); } } while (0)
         // Four-wave form (gemm256w_kernel).  gemm_w4 is a mask over its four instantiations: 1 = B k-contiguous, no side rows; 2 = B k-contiguous + residual;
-        // 4 = B k-strided, no side rows; 8 = B k-strided + saved pre-activation; -1 (default) = all four where K >= 1024 and N >= 1024 (every GEMM of ViT-L, none of ViT-B).  Measured IN the step, one process,
+        // 4 = B k-strided, no side rows; 8 = B k-strided + saved pre-activation; -1 (default) = the measured policy (rounds 4-5: all four where K >= 1024 and N >= 1024 -- every GEMM of ViT-L, none of ViT-B; since round 6: none, below).  Measured IN the step, one process,
         // the option toggled between blocks of ten steps (tools/ab_inproc.py, profiles/r4_dormant_kernels.txt): ViT-L/16 16x224^2 (K = 1024 / 4096) -3.0 ms of
         // 155.8 with all four forms, -2.4 with the k-contiguous two; ViT-B/16 32x320^2 (6400 tokens) -0.4 of 94.3; ViT-B/16 16x224^2 +-0.0 of 53.4 (round 3: +0.3):
         // with "all four where K >= 1024" (ViT-B: fc2, dfc1, dqkv) ViT-B 16x224^2 +0.06 / +0.11 ms, 6400 tokens -0.5, ViT-L -2.45: where the K loop dominates
@@ -2473,7 +2473,10 @@ static int gemm_impl(const devias_gemm_args* a, void* stream) {
         // (The stream-K schedule of rounds 2-3 -- gemm256sk_kernel, options gemm_streamk / gemm_sk_* -- is gone: in the same A/B it gained nothing on any
         // BASELINE configuration once the tail split existed: ViT-L -0.2 ms of 153.7 (noise), 6400 tokens +1.5 ms, ViT-B +-0.0; git history has it.)
         const int w4_form = (tb ? 2 : 0) + (side != 0 ? 1 : 0);
-        const int w4_mask = kn.w4 >= 0 ? kn.w4 : ((a->K >= 1024 && a->N >= 1024) ? 15 : 0);
+        // Round 6, second session: with the eight-wave kernel's specialised epilogues, tail thirds and non-temporal fc1 outputs the measured policy (-1) is NONE -- ViT-L in
+        // process (tools/ab_inproc.py --model vit_large gemm_w4=-1,0, the old policy "all four where K >= 1024 and N >= 1024" against none): -0.84 / -0.52 ms of 137.2; forms 1 / 2
+        // alone against none +0.22 / -0.01 (profiles/r6_side_configs.txt).  Its N = 1024 shapes have 3.06 rounds of tiles and the four-wave kernel has no tail split.
+        const int w4_mask = kn.w4 >= 0 ? kn.w4 : 0;
         const bool w4_ok = kn.persistent && !dyn && ((w4_mask >> w4_form) & 1) && pers_ok && !(!tb && side == 2) && nt > gp && a->K >= 128 &&      // (B k-contiguous + saved pre-activation -- dfc2 on a transposed weight copy -- has no four-wave form)
                            (a->act == DEVIAS_ACT_NONE || a->act == DEVIAS_ACT_GELU || a->act == DEVIAS_ACT_DGELU || a->act == DEVIAS_ACT_DRELU);
         if (w4_ok) {

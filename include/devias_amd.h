@@ -80,7 +80,7 @@ void devias_counters_reset(void);
  * "gemm256", "gemm_ss", "gemm_groupm", "gemm_persistent", "gemm_tail_split" (the tiles of a persistent launch's last partial round are computed in pieces by several
  * workgroups when enough CUs would idle: 3, default: as thirds where three pieces per tail tile fit the idle workgroups, else 128-row halves; 4: quarters / thirds / halves
  * (thirds and quarters on static tile lists, B k-contiguous, no column sums); 2: halves, their idle waves staging no A rows; 1: halves, staging all rows; 0: whole tiles), "gemm_smallm" (1, default: bf16 products with M <= 128 and B k-contiguous run as ONE launch of the small-M kernel instead of split-K
- * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves; -1, default: all four where K >= 1024 and N >= 1024, i.e. every GEMM of ViT-L and none of ViT-B), "gemm_debug", "gemm_dynamic" (1: the workgroups of
+ * product + reduce; same epilogue arithmetic, different K summation order), "gemm_w4" (mask of the forms the four-wave persistent kernel serves; -1, default: the measured policy -- none since round 6's work on the eight-wave kernel; rounds 4-5: all four where K >= 1024 and N >= 1024, i.e. every GEMM of ViT-L and none of ViT-B; 15 = all four), "gemm_debug", "gemm_dynamic" (1: the workgroups of
  * the persistent kernel pull their tiles from per-XCD queues at run time instead of walking static lists -- a CU held or slowed by a concurrent kernel, e.g. RCCL's during
  * backward, just takes fewer tiles; 0: static lists; -1, default: queues exactly when "gemm_concurrent" is set; same bits either way), "gemm_concurrent" (the host
  * announces that other kernels run beside the step's: devias_amd.parallel.GradSync sets it for N > 1), "gemm_reserve_cus" (CUs the big-tile grids and the weight-gradient split-K sizing leave free for such a kernel),
