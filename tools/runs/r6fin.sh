@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, final state: the whole GPU suite, bench lines (ViT-B + the two side configurations + the CU-hog pair), rocprofv3 kernel trace + stats, PMC passes (JSON keyed by the kernel-source hash)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG:-r6fin2}; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG:-r6fin3}; mkdir -p $O
 cd $R
 timeout 1500 python3 -m pytest tests -m gpu -x -q > $O/tests.txt 2>&1; grep -E "passed|failed" $O/tests.txt | tail -2
 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json
