@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--drop-path", type=float, default=0.0, help="stochastic depth rate (BASELINE.md quotes the metric at 0; the reference's training default is 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)      # (three timed steps; ~4.5 s each for B = 2 clips on 16 cores)
     ap.add_argument("--no-full-step", action="store_true", help="skip the secondary full-step number (teacher fwd + AdamW)")
     ap.add_argument("--no-probes", action="store_true", help="skip the kernel probes (dominant kernel, fc1 forward, sustained MFMA rate): for runs under rocprofv3, whose "
                     "per-step kernel statistics must contain the training steps only")
