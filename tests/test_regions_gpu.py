@@ -105,6 +105,35 @@ def test_regions_bitwise_equal_per_kernel_path(name, dtype, B):
         assert cnt["gemm256p"] + cnt["gemm256"] >= 12 * 12 and cnt["mhsa_bwd_bf16"] == cfg.depth, cnt
 
 
+def test_q_prescale_policy_both_paths_both_settings():
+    """host option attn_qpre (default 1: bf16 encoder blocks run their qkv GEMM on a q-scaled weight copy and the attention kernels with DEVIAS_ATTN_Q_PRESCALED, ABI 167):
+    with the option off the fused regions and the per-kernel path are bitwise equal too (the unscaled form of rounds 1-5), the launch counter says which form ran, and the
+    two settings agree to bf16 rounding (the scaled copy rounds q * c once where the unscaled form rounds q, then q * c)."""
+    from devias_amd import ops
+    fx, cfg, _ = gu.load("vits_t8")
+    model = _build(cfg, "bf16")
+    crit = _crit()
+    data = _data(cfg, 2)
+    res = {}
+    try:
+        for qpre in (1, 0):
+            ops.set_option("attn_qpre", qpre)
+            o0, g0 = _step(model, crit, data, regions=False)
+            ops.counters(reset=True)
+            o1, g1 = _step(model, crit, data, regions=True)
+            cnt = ops.counters()
+            assert cnt["mhsa_qpre"] == (2 * cfg.depth if qpre else 0), (qpre, cnt)
+            _assert_bitwise(o0, o1, f"attn_qpre = {qpre}: outputs")
+            _assert_bitwise(g0, g1, f"attn_qpre = {qpre}: gradients", order_tol=5e-3)
+            res[qpre] = (o1, g1)
+    finally:
+        ops.set_option("attn_qpre", 1)
+    for k in ("slots_head", "slots", "mask"):
+        a, b = res[1][0][k].float(), res[0][0][k].float()
+        assert float((a - b).abs().max() / b.abs().max()) < 3e-2, k
+    assert abs(float(res[1][0]["total"]) - float(res[0][0]["total"])) / abs(float(res[0][0]["total"])) < 2e-3
+
+
 @pytest.mark.parametrize("name,dtype,B", [("vits_t8", "fp32", 2), ("vits_t8", "bf16", 2), ("vitb_t16", "bf16", 8)])
 def test_regions_defer_is_bitwise_the_per_kernel_second_stages(name, dtype, B):
     """`regions_defer` (default 1): an encoder block's backward runs the second stages of its partial reductions (LayerNorm parameter gradients, bias-gradient
