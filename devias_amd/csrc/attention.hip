@@ -1357,6 +1357,7 @@ static int mhsa_bwd_bias_impl(const void* qkv, const void* o, const void* d_o, c
                               float scale, int32_t dtype, float keep, uint64_t seed, float* dbq, float* dbv, float* ws_q, float* ws_v, void* stream, int32_t flags) {
     DEVIAS_REQUIRE(dbq && ws_q && ws_v, "devias_mhsa_bwd_bias: null bias-gradient / workspace pointer");
     DEVIAS_REQUIRE(keep > 0.f && keep <= 1.f, "devias_mhsa_bwd_bias: keep must be in (0, 1]");
+    DEVIAS_REQUIRE(!(flags != 0 && keep < 1.f), "devias_mhsa_bwd_bias_flags: DEVIAS_ATTN_Q_PRESCALED is not offered with attention dropout (no forward entry point takes both)");
     const int D = H * 64;
     const int64_t es = dtype == DEVIAS_BF16 ? 2 : 4;
     if (attn_use_dkdv1w(dtype, keep)) {

@@ -270,7 +270,8 @@ int64_t devias_mhsa_bwd_workspace_bytes(int32_t B, int32_t N, int32_t H);
  * factor itself on operands it holds in registers: the forward and the dQ kernel round q * c, the one-wave-per-SIMD dK / dV kernel rounds k * c, so the backward's
  * scores differ from the ones the saved lse was built from by two bf16 roundings (~2x the dK / dV error at peaked logits; the advisor's round-5 finding).  With the
  * flag all three kernels multiply the SAME bf16 operands: the backward's scores ARE the forward's.  Outputs keep their meaning: o, lse (natural log, of the scores
- * scale * q k^T), and dqkv = the gradients with respect to the UNSCALED q, k, v (dQ = scale * dS k as always; dK = ln 2 * dS^T q'). */
+ * scale * q k^T), and dqkv = the gradients with respect to the UNSCALED q, k, v (dQ = scale * dS k as always; dK = ln 2 * dS^T q').  Not offered with attention dropout
+ * (devias_mhsa_bwd_bias_flags refuses flags != 0 with keep < 1: no forward entry point takes both). */
 #define DEVIAS_ATTN_Q_PRESCALED 1
 int devias_mhsa_fwd_flags(const void* qkv, void* o, float* lse, int32_t B, int32_t N, int32_t H, float scale,
                           int32_t dtype, int32_t flags, void* stream);
